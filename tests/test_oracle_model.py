@@ -1,0 +1,165 @@
+"""CPU: the PyTorch-CPU restatement (oracle/torch_ref.py) against golden vectors
+produced by the imported reference modules (model.py:60-362, loss.py:3-13)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref as tr
+
+# same ATen CPU kernels, same op order -> differences are thread-partition noise
+RTOL, ATOL = 1e-5, 1e-6
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def split(g):
+    feats = torch.from_numpy(g["features"])
+    coords = torch.from_numpy(g["coords"])
+    lens = [int(x) for x in g["feat_lens"]]
+    return list(torch.split(feats, lens)), list(torch.split(coords, lens))
+
+
+def digest(t):
+    f = t.detach().reshape(-1).double()
+    stride = max(1, f.numel() // 256)
+    return np.array([f.norm().item(), f.sum().item(), f.abs().sum().item()]), t.detach().reshape(-1)[::stride].numpy()
+
+
+def test_state_dict_shapes():
+    sd = tr.make_state_dict("Car")
+    params = tr.param_keys(sd)
+    assert len(params) == 104
+    assert sum(sd[k].numel() for k in params) == 6809392
+    assert sd["middle_rpn.deconv3.deconv.weight"].shape == (256, 256, 4, 4)
+    assert sd["middle_rpn.middle_layer.0.conv.weight"].shape == (64, 128, 3, 3, 3)
+
+
+def test_feature_net(golden):
+    g = golden("featnet_tiny")
+    feats, coords = split(g)
+    sd = tr.make_state_dict("Car")
+    dims = (10, 16, 24)
+    with torch.no_grad():
+        rows = tr.voxel_features(torch.cat(feats), sd, training=False)
+    close(rows, g["eval_rows"])
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in tr.param_keys(sd) if k.startswith("feature_net")}
+    work = dict(sd); work.update(leaves)
+    dense = tr.feature_net(feats, coords, work, dims, training=True)
+    c = torch.cat(coords)
+    close(dense[c[:, 0], c[:, 1], c[:, 2], c[:, 3]], g["train_rows"])
+    assert int((dense.abs().sum(-1) != 0).sum()) <= c.shape[0]
+    assert abs(dense.double().sum().item() - float(g["train_dense_sum"])) < 1e-3
+    up = torch.from_numpy((np.random.default_rng(31).standard_normal(tuple(dense.shape)) * 1e-2).astype(np.float32))
+    dense.backward(up)
+    for k, v in leaves.items():
+        close(v.grad, g["grad." + k[len("feature_net."):]], rtol=1e-4, atol=1e-6)
+    for k in sd:
+        if k.startswith("feature_net") and "running" in k:
+            close(sd[k], g["buf." + k[len("feature_net."):]])
+    # standalone VFELayer
+    sd2 = tr.make_state_dict("Car")
+    x = torch.cat(feats)
+    mask = x.max(dim=2, keepdim=True)[0] != 0
+    close(tr.vfe_layer(x, mask, sd2, "feature_net.vfe_1", True), g["vfe1_train_out"])
+    assert 0.5 < float(g["mask_fraction"]) < 1.0    # most padded slots pass the mask
+
+
+def _layer_cases():
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location(
+        "layer_cases", os.path.join(os.path.dirname(__file__), "layer_cases.py"))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m.LAYER_CASES
+
+
+@pytest.mark.parametrize("case", _layer_cases(), ids=lambda c: c[0])
+def test_single_layers(golden, case):
+    from layer_cases import build_layer_state, layer_input, layer_upstream
+    g = golden("layers_tiny")
+    name, kind, dim, cin, cout, k, s, p, sp = case
+    idx = [c[0] for c in _layer_cases()].index(name)
+    sd = build_layer_state(idx, case)
+    leaves = {k_: v.clone().requires_grad_(True) for k_, v in sd.items() if "running" not in k_ and "num_batches" not in k_}
+    work = dict(sd); work.update(leaves)
+    x = layer_input(idx, case).requires_grad_(True)
+    if kind == "deconv":
+        y = tr.deconv2d(x, work, "L", s, p, True)
+    else:
+        y = tr.conv_md(x, work, "L", dim, s, p, bn=(kind == "conv"), act=(kind == "conv"), training=True)
+    close(y, g[name + ".y"], rtol=1e-4, atol=1e-5)
+    y.backward(layer_upstream(idx, case, tuple(y.shape)))
+    close(x.grad, g[name + ".dx"], rtol=1e-4, atol=1e-5)
+    for k_, v in leaves.items():
+        short = k_[2:]
+        if f"{name}.grad.{short}" in g:
+            close(v.grad, g[f"{name}.grad.{short}"], rtol=1e-3, atol=1e-4)
+        else:
+            d, smp = digest(v.grad)
+            np.testing.assert_allclose(d, g[f"{name}.gdig.{short}"], rtol=1e-4)
+            close(smp, g[f"{name}.gsmp.{short}"], rtol=1e-3, atol=1e-4)
+    for k_ in sd:
+        if "running" in k_:
+            close(sd[k_], g[f"{name}.buf.{k_[2:]}"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("cls,tag", [("Car", "car"), ("Pedestrian", "ped")])
+def test_middle_rpn_fwd_bwd(golden, cls, tag):
+    g = golden(f"middle_tiny_{tag}")
+    feats, coords = split(g)
+    sd = tr.make_state_dict(cls)
+    dp = torch.from_numpy((np.random.default_rng(41).standard_normal(g["prob"].shape) * 1e-1).astype(np.float32))
+    dr = torch.from_numpy((np.random.default_rng(42).standard_normal(g["reg"].shape) * 1e-1).astype(np.float32))
+    prob, reg, grads = tr.forward_backward(feats, coords, sd, (10, 16, 24), cls, dp, dr)
+    close(prob, g["prob"], rtol=1e-4, atol=1e-5)
+    close(reg, g["reg"], rtol=1e-4, atol=1e-4)
+    for k, gr in grads.items():
+        d, smp = digest(gr)
+        np.testing.assert_allclose(d, g["gdig." + k], rtol=2e-3, atol=1e-5, err_msg=k)
+        np.testing.assert_allclose(smp, g["gsmp." + k], rtol=1e-2, atol=2e-4 * max(1e-3, np.abs(g["gsmp." + k]).max()), err_msg=k)
+    for k in sd:
+        if "running" in k:
+            close(sd[k], g["buf." + k], rtol=1e-4, atol=1e-5)
+
+
+def test_rpn3d_loss_and_grads(golden):
+    g = golden("rpn3d_tiny")
+    feats, coords = split(golden("middle_tiny_car"))
+    sd = tr.make_state_dict("Car")
+    leaves = {k: sd[k].clone().requires_grad_(True) for k in tr.param_keys(sd)}
+    work = dict(sd); work.update(leaves)
+    dense = tr.feature_net(feats, coords, work, (10, 16, 24), True)
+    prob, delta = tr.middle_rpn(dense, work, "Car", True)
+    prob.retain_grad(); delta.retain_grad()
+    f32 = lambda a: torch.from_numpy(a).float()   # model.py:327-332: .float() after from_numpy
+    loss, cls, reg, cpos, cneg = tr.rpn_loss(prob, delta, f32(g["pos"]), f32(g["neg"]), f32(g["targets"]))
+    np.testing.assert_allclose([loss.item(), cls.item(), reg.item(), cpos.item(), cneg.item()], g["scalars"], rtol=1e-4)
+    loss.backward()
+    close(prob.grad, g["dprob"], rtol=1e-3, atol=1e-6)
+    close(delta.grad, g["ddelta"], rtol=1e-3, atol=1e-6)
+    for k, v in leaves.items():
+        d, _ = digest(v.grad)
+        np.testing.assert_allclose(d, g["gdig." + k], rtol=5e-3, atol=1e-5, err_msg=k)
+
+
+def test_car_full_forward(golden):
+    """BASELINE config 1: full-size car frame, B=1, train-mode forward."""
+    from oracle import voxelize as ov
+    from voxelnet_amd import synth
+    g = golden("car_full")
+    w = synth.WORKLOADS[1]
+    cloud = synth.synth_cloud("Car", w["k0"], synth.frame_seed(1, 0), w["mean_extra"], w["T"])
+    np.random.seed(7); np.random.shuffle(cloud)
+    v = ov.voxelize(cloud, "Car")
+    assert v["coordinate_buffer"].shape[0] == int(g["K"])
+    f, _, c = ov.prepare_voxel([v])
+    sd = tr.make_state_dict("Car")
+    with torch.no_grad():
+        rows = tr.voxel_features(torch.from_numpy(f[0]), sd, True)
+        close(rows[::16], g["voxelwise_lattice"], rtol=1e-4, atol=1e-5)
+        dense = tr.scatter_dense(rows, torch.from_numpy(c[0]), (1, 10, 400, 352))
+        prob, reg = tr.middle_rpn(dense, sd, "Car", True)
+    close(prob[:, :, ::8, ::8], g["prob_lattice"], rtol=1e-3, atol=1e-5)
+    close(reg[:, :, ::8, ::8], g["reg_lattice"], rtol=1e-3, atol=1e-4)
