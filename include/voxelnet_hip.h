@@ -1,0 +1,223 @@
+/*
+ * voxelnet_hip.h — C ABI of libvoxelnet_hip.so (gfx950 / MI355X).
+ *
+ * The reference (johanngerberding/voxelnet-pytorch) has no FFI or operator
+ * registry: its hot path is Python calling ATen/NumPy.  This header is the
+ * boundary a maintainer would bind (ctypes stub in INTEGRATION.md) to replace
+ * those calls; every entry point cites the reference code it stands in for
+ * (paths relative to /root/reference/voxelnet/).
+ *
+ * Conventions:
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - every pointer is a DEVICE pointer unless the name ends in _host.
+ *   - the library never allocates or frees caller-visible memory: outputs and
+ *     workspaces are caller-allocated; *_workspace_bytes() say how much.
+ *   - asynchronous: work is enqueued on `stream` (a hipStream_t passed as
+ *     void*) and ordered only by it.  No entry point synchronises.
+ *   - return value: 0 ok, <0 invalid argument (VN_E*), >0 a hipError_t.
+ *   - no global mutable state; re-entrant.
+ *   - activations are channels-last: (B, D, H, W, C) / (B, H, W, C).
+ */
+#ifndef VOXELNET_HIP_H
+#define VOXELNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VN_OK 0
+#define VN_EINVAL (-1)     /* bad argument (null pointer, negative size, ...) */
+#define VN_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
+#define VN_EWORKSPACE (-3) /* workspace too small */
+
+typedef enum { VN_F32 = 0, VN_BF16 = 1 } vnDtype;
+
+typedef void *vnStream; /* hipStream_t */
+
+int vn_abi_version(void); /* bumps when a signature changes */
+const char *vn_build_info(void); /* "gfx950 <date> ..." static string */
+
+/* ------------------------------------------------------------------------
+ * Voxelizer — utils.py:10-100 (pcl_to_voxels), minus the host-side shuffle
+ * (utils.py:35), which the Python wrapper performs before upload.
+ * Grid literals: utils.py:24-33.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int32_t D, H, W;   /* grid (z,y,x) */
+    float vz, vy, vx;  /* voxel size (z,y,x), float32 as in the reference */
+    float ox, oy, oz;  /* lidar_coord added to (x,y,z) */
+    int32_t T;         /* max points per voxel (<= 64) */
+} vnGrid;
+
+size_t vn_voxelize_workspace_bytes(int64_t n_points, const vnGrid *grid);
+
+/* Phase 1 (utils.py:37-63): per-point voxel key (exact fp32 add / IEEE divide /
+ * floor), occupancy, ordered compaction.  Writes K (number of non-empty voxels,
+ * rows sorted by z,y,x) to *k_out (device int32).  The caller reads K back
+ * (one 4-byte copy) to size phase 2's outputs — the reference returns
+ * (K,T,7)/(K,3)/(K,) arrays, so K is part of the boundary format. */
+int vn_voxelize_index(const float *points /*[N,4]*/, int64_t n_points,
+                      const vnGrid *grid, void *workspace, size_t workspace_bytes,
+                      int32_t *k_out, vnStream stream);
+
+/* Phase 2 (utils.py:69-88 + dataset.py:110-117): first-T points per voxel in
+ * input order, centroid offsets on all T slots (float64 divide/subtract as
+ * numpy promotes), int64 coordinates with `coord_cols` = 3 (z,y,x) or
+ * 4 (batch_index,z,y,x; prepare_voxel's padding), int64 counts.
+ * Deterministic: no order-dependent atomics reach the outputs. */
+int vn_voxelize_gather(const float *points, int64_t n_points, const vnGrid *grid,
+                       void *workspace, size_t workspace_bytes, int64_t K,
+                       int64_t batch_index, int32_t coord_cols,
+                       float *feature /*[K,T,7]*/, int64_t *coord /*[K,coord_cols]*/,
+                       int64_t *number /*[K]*/, vnStream stream);
+
+/* ------------------------------------------------------------------------
+ * VFE layer — model.py:60-82 (VFELayer.forward), train- or eval-mode BN.
+ *   p   = BN1d(ReLU(x W^T + b))        stats over all K*T rows (padded too)
+ *   out = cat[p, max_T p] * mask       mask = max_c(x0) != 0 (model.py:95-96)
+ * `x0` is the raw (K,T,7) feature buffer the mask derives from; `x` is this
+ * layer's input (K,T,cin) (x == x0 for vfe_1).  cin in {7,32}, cout/2 in {16,64}.
+ * stats: [mean(c), invstd(c)] saved for backward.  If voxelwise != NULL the
+ * max over T of `out` (model.py:100) is also written, (K, 2c).
+ * `out` may be NULL when only voxelwise is wanted.
+ * ---------------------------------------------------------------------- */
+size_t vn_vfe_workspace_bytes(int64_t K, int32_t T, int32_t cin, int32_t c);
+
+int vn_vfe_fwd(const float *x0, const float *x, int64_t K, int32_t T, int32_t cin,
+               int32_t c, const float *weight /*[c,cin]*/, const float *bias,
+               const float *gamma, const float *beta, float *running_mean,
+               float *running_var, int32_t training, float momentum, float eps,
+               float *out /*[K,T,2c] or NULL*/, float *voxelwise /*[K,2c] or NULL*/,
+               float *stats /*[2c]*/, void *workspace, size_t workspace_bytes,
+               vnStream stream);
+
+/* Backward of the above (train mode).  d_out (K,T,2c) and/or d_voxelwise (K,2c)
+ * are the upstream gradients (either may be NULL).  Produces d_weight, d_bias,
+ * d_gamma, d_beta (overwritten) and, if d_x != NULL, d_x (K,T,cin). */
+int vn_vfe_bwd(const float *x0, const float *x, int64_t K, int32_t T, int32_t cin,
+               int32_t c, const float *weight, const float *bias, const float *gamma,
+               const float *beta, const float *stats, const float *d_out,
+               const float *d_voxelwise, float *d_x, float *d_weight, float *d_bias,
+               float *d_gamma, float *d_beta, void *workspace, size_t workspace_bytes,
+               vnStream stream);
+
+/* ------------------------------------------------------------------------
+ * Sparse -> dense scatter — model.py:102-106 (sparse COO .to_dense()).
+ * dense[b,z,y,x,:] = voxelwise[k,:]; zero elsewhere.  Coordinates unique.
+ * Backward = row gather.  Deterministic.
+ * ---------------------------------------------------------------------- */
+int vn_scatter_dense_fwd(const float *voxelwise /*[K,C]*/, const int64_t *coord /*[K,4]*/,
+                         int64_t K, int32_t C, int32_t B, int32_t D, int32_t H, int32_t W,
+                         void *dense, vnDtype dense_dtype, int32_t dense_channels,
+                         int32_t split3, vnStream stream);
+int vn_scatter_dense_bwd(const void *d_dense, vnDtype dtype, const int64_t *coord,
+                         int64_t K, int32_t C, int32_t B, int32_t D, int32_t H, int32_t W,
+                         float *d_voxelwise /*[K,C]*/, vnStream stream);
+
+/* ------------------------------------------------------------------------
+ * Convolutions — model.py:111-199 (ConvMD: Conv2d/Conv3d; DeConv2d:
+ * ConvTranspose2d) as ONE gather-GEMM on the matrix cores.
+ *
+ *   out[m, n] = bias[n] + sum_{tap, k} in[site(m, tap), k] * w[tap][n][k]
+ *
+ * m runs over the "row" sites (B, Dr, Hr, Wr); site(m, tap) is the source site
+ *   src = m * stride_dir + tap * tap_step - pad        (per axis; see vnConv)
+ * and contributes zero when out of range or (for transposed gathers) not
+ * divisible.  Forward conv, data-gradient of a strided conv, ConvTranspose2d
+ * forward and its data-gradient are all instances (host code picks the
+ * geometry and the packed weight orientation).
+ * Operands are bf16 (VN_BF16) with fp32 accumulation; `out` is fp32 or bf16.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int32_t B;
+    int32_t Ds, Hs, Ws;   /* source (gathered) tensor sites */
+    int32_t Dr, Hr, Wr;   /* row (produced) tensor sites */
+    int32_t Cs;           /* source channels = GEMM K per tap (multiple of 32) */
+    int32_t Cr;           /* row channels = GEMM N (multiple of 16) */
+    int32_t kD, kH, kW;   /* taps */
+    /* src = (row * mul + tap * tmul - pad) / div, valid iff divisible & in range */
+    int32_t mulD, mulH, mulW;
+    int32_t tmulD, tmulH, tmulW;
+    int32_t padD, padH, padW;
+    int32_t divD, divH, divW;
+    int32_t src_stride;   /* elements between consecutive source sites (>= Cs) */
+    int32_t out_stride;   /* elements between consecutive row sites (>= Cr) */
+} vnConv;
+
+int vn_conv_gather_gemm(const void *src /*bf16*/, const void *w_packed /*bf16 [taps][Cr][Cs]*/,
+                        const float *bias /*[Cr] or NULL*/, void *out, vnDtype out_dtype,
+                        const vnConv *geom, int32_t accumulate, vnStream stream);
+
+/* Weight-gradient: dw[tap][n][k] (+)= sum_m src[site(m,tap), k] * rows[m, n]
+ * (fp32 output in the packed [taps][Cr][Cs] orientation; split over m with
+ * fp32 atomics — caller zeroes dw first unless accumulating). */
+int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16 [M,Cr]*/,
+                  float *dw_packed, const vnConv *geom, int32_t rows_stride,
+                  vnStream stream);
+
+/* Packing between torch parameter layouts and the kernels' [taps][N][K] bf16.
+ * mode 0: Conv weight (Cout,Cin,k...) -> forward operand   [tap][Cout][Cin]
+ * mode 1: Conv weight                 -> data-grad operand [tap][Cin][Cout] (taps as stored)
+ * mode 2: ConvTranspose weight (Cin,Cout,kh,kw) -> forward operand [tap][Cout][Cin]
+ * mode 3: ConvTranspose weight        -> data-grad operand [tap][Cin][Cout]
+ * `split3`: emit the bf16x3 expansion (hi|lo|hi resp. hi;hi;lo along K) used by
+ * the fp32-accurate mode. */
+int vn_pack_weight(const float *w, int32_t n_out, int32_t n_in, int32_t taps,
+                   int32_t mode, int32_t split3, void *packed, vnStream stream);
+/* inverse for gradients: packed fp32 [tap][N][K] -> torch layout, mode as above */
+int vn_unpack_wgrad(const float *dw_packed, int32_t n_out, int32_t n_in, int32_t taps,
+                    int32_t mode, int32_t fold3, float *dw, vnStream stream);
+
+/* ------------------------------------------------------------------------
+ * BatchNorm(+ReLU) over channels-last rows — nn.BatchNorm{1,2,3}d defaults
+ * (momentum 0.1, eps 1e-5) as used at model.py:72,142,153,193.
+ * ---------------------------------------------------------------------- */
+/* per-channel sum / sum of squares over M rows -> stats[2C] (fp32; zeroed here) */
+int vn_bn_stats(const void *y, vnDtype dtype, int64_t M, int32_t C, int32_t stride,
+                float *sums /*[2C]*/, vnStream stream);
+/* sums -> (mean, invstd) in place; updates running stats (unbiased var) */
+int vn_bn_finalize(float *sums_to_stats /*[2C]*/, int64_t M, int32_t C, float eps,
+                   float momentum, float *running_mean, float *running_var,
+                   vnStream stream);
+/* a = relu?(gamma*(y-mean)*invstd+beta) -> bf16 (optionally hi|lo|hi split) or f32 */
+int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t M, int32_t C, int32_t y_stride,
+                const float *stats, const float *gamma, const float *beta, int32_t relu,
+                void *a, vnDtype a_dtype, int32_t a_stride, int32_t split3,
+                vnStream stream);
+/* backward, step 1: dz = da * (relu ? a>0 : 1); sums[0:C] = sum dz, sums[C:2C] = sum dz*xhat */
+int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int32_t da_stride, const void *y,
+                     vnDtype y_dtype, int32_t y_stride, int64_t M, int32_t C,
+                     const float *stats, const float *gamma, const float *beta,
+                     int32_t relu, float *sums /*[2C]*/, vnStream stream);
+/* step 2: dy = gamma*invstd*(dz - sum_dz/M - xhat*sum_dzxhat/M); d_gamma = sums[C:], d_beta = sums[:C] */
+int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int32_t da_stride, const void *y,
+                    vnDtype y_dtype, int32_t y_stride, int64_t M, int32_t C,
+                    const float *stats, const float *gamma, const float *beta,
+                    int32_t relu, const float *sums, void *dy, vnDtype dy_dtype,
+                    int32_t dy_stride, int32_t split3, vnStream stream);
+
+/* ------------------------------------------------------------------------
+ * Layout / dtype helpers at the nn.Module boundary (the reference's modules
+ * speak NCDHW fp32; model.py:259,262,281).
+ * ---------------------------------------------------------------------- */
+/* (B,C,S) fp32 <-> (B,S,C) bf16/fp32, S = product of spatial dims */
+int vn_nchw_to_nhwc(const float *src, int32_t B, int32_t C, int64_t S, void *dst,
+                    vnDtype dst_dtype, int32_t dst_stride, int32_t split3, vnStream stream);
+int vn_nhwc_to_nchw(const void *src, vnDtype src_dtype, int32_t src_stride, int32_t B,
+                    int32_t C, int64_t S, float *dst, int32_t sigmoid_first_n,
+                    vnStream stream);
+/* elementwise cast/copy of M rows of C channels between strided buffers */
+int vn_cast_rows(const void *src, vnDtype src_dtype, int32_t src_stride, int64_t M,
+                 int32_t C, void *dst, vnDtype dst_dtype, int32_t dst_stride,
+                 int32_t split3, vnStream stream);
+/* per-channel column sums of M rows (bias gradients): out[C] = sum_m rows[m,:] */
+int vn_col_sums(const void *rows, vnDtype dtype, int32_t stride, int64_t M, int32_t C,
+                float *out, vnStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOXELNET_HIP_H */

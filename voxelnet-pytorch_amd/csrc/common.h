@@ -1,0 +1,48 @@
+// Shared helpers for the gfx950 kernels.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/voxelnet_hip.h"
+
+#define VN_WAVE 64
+
+#define VN_CHECK_ARG(cond) do { if (!(cond)) return VN_EINVAL; } while (0)
+#define VN_LAUNCH_STATUS() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
+#define VN_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
+
+static inline hipStream_t vn_stream(vnStream s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int64_t vn_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t vn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// fp32 -> bf16 round-to-nearest-even via the hardware cast (keeps NaN a NaN)
+__device__ __forceinline__ bf16_t vn_f2bf(float x) { return (bf16_t)x; }
+__device__ __forceinline__ float vn_bf2f(bf16_t x) { return (float)x; }
+
+// bf16x3 split: x ~= hi + lo with hi = bf16(x), lo = bf16(x - hi)
+__device__ __forceinline__ void vn_split_bf16(float x, bf16_t &hi, bf16_t &lo) {
+    hi = (bf16_t)x;
+    lo = (bf16_t)(x - (float)hi);
+}
+
+__device__ __forceinline__ float vn_wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float vn_wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ int vn_wave_min_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,113 @@
+"""ctypes binding of libvoxelnet_hip.so (C ABI: include/voxelnet_hip.h).
+
+There is NO fallback: if the library is missing, or a call returns a non-zero
+status, this raises.  PyTorch is used above this layer only for device memory,
+streams and autograd bookkeeping.
+"""
+import ctypes
+import os
+
+# torch must be imported BEFORE the library is dlopen'ed: both need
+# libamdhip64.so.7 and must share ONE HIP runtime instance (the one bundled with
+# torch).  Loaded in the other order the process ends up with two runtimes and
+# our launches fail with hipErrorNoDevice.
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvoxelnet_hip.so")
+
+c_i32, c_i64, c_f32, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+VN_F32, VN_BF16 = 0, 1
+
+
+class VnGrid(ctypes.Structure):
+    _fields_ = [("D", c_i32), ("H", c_i32), ("W", c_i32),
+                ("vz", c_f32), ("vy", c_f32), ("vx", c_f32),
+                ("ox", c_f32), ("oy", c_f32), ("oz", c_f32), ("T", c_i32)]
+
+
+class VnConv(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in (
+        "B", "Ds", "Hs", "Ws", "Dr", "Hr", "Wr", "Cs", "Cr", "kD", "kH", "kW",
+        "mulD", "mulH", "mulW", "tmulD", "tmulH", "tmulW", "padD", "padH", "padW",
+        "divD", "divH", "divW", "src_stride", "out_stride")]
+
+
+# name -> (restype, argtypes); mirrors include/voxelnet_hip.h one to one
+_P = ctypes.POINTER
+SIGNATURES = {
+    "vn_abi_version": (c_i32, []),
+    "vn_build_info": (ctypes.c_char_p, []),
+    "vn_voxelize_workspace_bytes": (c_sz, [c_i64, _P(VnGrid)]),
+    "vn_voxelize_index": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_vp, c_vp]),
+    "vn_voxelize_gather": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "vn_vfe_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32, c_i32]),
+    "vn_vfe_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
+                           c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "vn_vfe_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "vn_scatter_dense_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,
+                                     c_i32, c_vp]),
+    "vn_scatter_dense_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vn_conv_gather_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_i32, c_vp]),
+    "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp]),
+    "vn_pack_weight": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vn_unpack_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vn_bn_stats": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
+    "vn_bn_finalize": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp]),
+    "vn_bn_apply": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32,
+                            c_vp]),
+    "vn_bn_bwd_reduce": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32,
+                                 c_vp, c_vp]),
+    "vn_bn_bwd_apply": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32,
+                                c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vn_nchw_to_nhwc": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vn_nhwc_to_nchw": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i32, c_vp]),
+    "vn_cast_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vn_col_sums": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+class VoxelnetHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library; loud failure if it was not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise VoxelnetHipError(
+                f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C voxelnet-pytorch_amd/csrc).  There is no CPU fallback.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name, None)
+            if fn is not None:
+                fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def missing_symbols():
+    """Symbols declared in include/voxelnet_hip.h that the built library lacks
+    (must be empty; __graft_entry__.build() and tests/test_abi.py assert it)."""
+    lib = load()
+    return [n for n in SIGNATURES if not hasattr(lib, n)]
+
+
+def check(status, what):
+    if status != 0:
+        kind = {-1: "invalid argument", -2: "unsupported shape", -3: "workspace too small"}.get(
+            status, f"hipError_t {status}" if status > 0 else "error")
+        raise VoxelnetHipError(f"{what} failed: {kind} (status {status})")
+
+
+def call(name, *args):
+    fn = getattr(load(), name, None)
+    if fn is None:
+        raise VoxelnetHipError(f"{name} is not exported by {LIB_PATH}; rebuild the HIP library")
+    check(fn(*args), name)

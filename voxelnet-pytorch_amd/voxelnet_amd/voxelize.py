@@ -1,0 +1,105 @@
+"""Host-side mirror of the reference's voxelization interface, backed by the HIP
+voxelizer (csrc/voxelize.hip) through the C ABI.
+
+  pcl_to_voxels   /root/reference/voxelnet/utils.py:10-100
+  prepare_voxel   /root/reference/voxelnet/dataset.py:101-119
+  collate_fn      /root/reference/voxelnet/dataset.py:70-97
+
+Same names, argument meaning, return formats and side effects (pcl_to_voxels
+shuffles its argument in place, utils.py:35).  `voxelize_device` is the
+device-resident variant the train loop uses to skip the numpy round trip.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import grid_config
+
+
+def _grid_struct(g):
+    return _lib.VnGrid(g.D, g.H, g.W, g.vz, g.vy, g.vx, g.ox, g.oy, g.oz, g.T)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def voxelize_device(points, grid, batch_index=0, coord_cols=4):
+    """points: (N,4) float32 CUDA tensor in processing order.
+    Returns (feature (K,T,7) f32, coord (K,coord_cols) i64, number (K,) i64) on device.
+    One 4-byte D2H read of K sizes the outputs (K is part of the reference's format)."""
+    if not (points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 4):
+        raise ValueError("points must be a CUDA float32 (N,4) tensor")
+    points = points.contiguous()
+    n = points.shape[0]
+    dev = points.device
+    gs = _grid_struct(grid)
+    lib = _lib.load()
+    ws_bytes = lib.vn_voxelize_workspace_bytes(n, ctypes.byref(gs))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    k_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        st = _stream()
+        _lib.call("vn_voxelize_index", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes,
+                  k_dev.data_ptr(), st)
+        K = int(k_dev.item())
+        feature = torch.empty((K, grid.T, 7), dtype=torch.float32, device=dev)
+        coord = torch.empty((K, coord_cols), dtype=torch.int64, device=dev)
+        number = torch.empty((K,), dtype=torch.int64, device=dev)
+        _lib.call("vn_voxelize_gather", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes, K,
+                  int(batch_index), coord_cols, feature.data_ptr(), coord.data_ptr(), number.data_ptr(), st)
+    return feature, coord, number
+
+
+def pcl_to_voxels(pcl, target, verbose=False, device="cuda:0"):
+    """Drop-in for utils.pcl_to_voxels (utils.py:10-100): numpy in, dict of numpy out."""
+    grid = grid_config("Car" if target == "Car" else "Pedestrian")   # utils.py:24-33: 'Car' else ped/cyc
+    np.random.shuffle(pcl)                                           # utils.py:35, in place
+    pts = torch.from_numpy(np.ascontiguousarray(pcl[:, :4], dtype=np.float32)).to(device)
+    feature, coord, number = voxelize_device(pts, grid, 0, coord_cols=3)
+    voxel_dict = {
+        "feature_buffer": feature.cpu().numpy(),
+        "coordinate_buffer": coord.cpu().numpy(),
+        "number_buffer": number.cpu().numpy(),
+    }
+    if verbose:
+        print(f"Coordinate buffer shape: {voxel_dict['coordinate_buffer'].shape}")
+        print(f"Feature buffer shape: {voxel_dict['feature_buffer'].shape}")
+        print(f"Number buffer shape: {voxel_dict['number_buffer'].shape}")
+    return voxel_dict
+
+
+def prepare_voxel(voxels):
+    """dataset.py:101-119: list of voxel dicts -> (features, numbers, coordinates (K,4))."""
+    features, numbers, coordinates = [], [], []
+    for i, voxel in enumerate(voxels):
+        features.append(voxel["feature_buffer"])
+        numbers.append(voxel["number_buffer"])
+        c = voxel["coordinate_buffer"]
+        out = np.empty((c.shape[0], 4), dtype=c.dtype)
+        out[:, 0] = i
+        out[:, 1:] = c
+        coordinates.append(out)
+    return features, numbers, coordinates
+
+
+def collate_fn(parts):
+    """dataset.py:70-97: batch 5-tuples (tag, rgb, raw_lidar, label, voxel dict) into the
+    reference's 7-tuple."""
+    tag = [p[0] for p in parts]
+    rgb = [p[1] for p in parts]
+    raw_lidar = [p[2] for p in parts]
+    label = [p[3] for p in parts]
+    voxel = [p[4] for p in parts]
+    voxel_features, voxel_numbers, voxel_coordinates = prepare_voxel(voxel)
+    return (
+        tag,
+        np.array(label, dtype=object),
+        [torch.from_numpy(f) for f in voxel_features],
+        np.array(voxel_numbers, dtype=object),
+        [torch.from_numpy(c) for c in voxel_coordinates],
+        np.array(rgb, dtype=object),
+        np.array(raw_lidar, dtype=object),
+    )
