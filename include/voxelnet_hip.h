@@ -107,12 +107,13 @@ int vn_vfe_bwd(const float *x0, const float *x, int64_t K, int32_t T, int32_t ci
 /* ------------------------------------------------------------------------
  * Sparse -> dense scatter — model.py:102-106 (sparse COO .to_dense()).
  * dense[b,z,y,x,:] = voxelwise[k,:]; zero elsewhere.  Coordinates unique.
+ * dense is f32 (B,D,H,W,C), bf16, or (split != 0) bf16 [hi|lo] with dense_channels = 2C.
  * Backward = row gather.  Deterministic.
  * ---------------------------------------------------------------------- */
 int vn_scatter_dense_fwd(const float *voxelwise /*[K,C]*/, const int64_t *coord /*[K,4]*/,
                          int64_t K, int32_t C, int32_t B, int32_t D, int32_t H, int32_t W,
                          void *dense, vnDtype dense_dtype, int32_t dense_channels,
-                         int32_t split3, vnStream stream);
+                         int32_t split, vnStream stream);
 int vn_scatter_dense_bwd(const void *d_dense, vnDtype dtype, const int64_t *coord,
                          int64_t K, int32_t C, int32_t B, int32_t D, int32_t H, int32_t W,
                          float *d_voxelwise /*[K,C]*/, vnStream stream);
@@ -121,101 +122,134 @@ int vn_scatter_dense_bwd(const void *d_dense, vnDtype dtype, const int64_t *coor
  * Convolutions — model.py:111-199 (ConvMD: Conv2d/Conv3d; DeConv2d:
  * ConvTranspose2d) as ONE gather-GEMM on the matrix cores.
  *
- *   out[m, n] = bias[n] + sum_{tap, k} in[site(m, tap), k] * w[tap][n][k]
+ *   out[m, n] = bias[n] + sum_{tap, k} src[site(m, tap), k] * w[tap][n][k]
  *
- * m runs over the "row" sites (B, Dr, Hr, Wr); site(m, tap) is the source site
- *   src = m * stride_dir + tap * tap_step - pad        (per axis; see vnConv)
- * and contributes zero when out of range or (for transposed gathers) not
- * divisible.  Forward conv, data-gradient of a strided conv, ConvTranspose2d
- * forward and its data-gradient are all instances (host code picks the
- * geometry and the packed weight orientation).
- * Operands are bf16 (VN_BF16) with fp32 accumulation; `out` is fp32 or bf16.
+ * m runs over the "row" sites (B, Dr, Hr, Wr); site(m, tap) is, per axis,
+ *   s = (row * mul + tap * tmul - pad) / div   (valid iff divisible, 0 <= s < S)
+ * and an invalid site contributes zero.  Forward conv (mul = stride, tmul = 1,
+ * div = 1), the data-gradient of a strided conv and ConvTranspose2d forward
+ * (mul = 1, tmul = -1, pad = -p, div = stride), and the data-gradient of a
+ * ConvTranspose2d are all instances; the host code picks the geometry and the
+ * packed weight orientation.  div > 1 is executed as div^3 (div^2) residue
+ * classes of a stride-1 gather, all inside one launch.
+ *
+ * Operands are bf16 with fp32 accumulation on v_mfma_f32_16x16x32_bf16.
+ * "split" (fp32-accurate, bf16x3) mode: activations are stored as 2C-wide rows
+ * [hi | lo] (hi = bf16(x), lo = bf16(x - hi)), weights are packed 3C-wide along
+ * K as [hi ; hi ; lo], Cs = 3C and src_wrap = 2C: K index k reads source column
+ * k (k < 2C) or k - 2C, i.e. a_hi*w_hi + a_lo*w_hi + a_hi*w_lo.
+ * Addresses are explicit strides in ELEMENTS, so channel slices of a wider
+ * buffer (the 768-channel concat, model.py:271-273) and the BEV fold
+ * (model.py:262) are views, not copies.
  * ---------------------------------------------------------------------- */
 typedef struct {
     int32_t B;
     int32_t Ds, Hs, Ws;   /* source (gathered) tensor sites */
     int32_t Dr, Hr, Wr;   /* row (produced) tensor sites */
-    int32_t Cs;           /* source channels = GEMM K per tap (multiple of 32) */
-    int32_t Cr;           /* row channels = GEMM N (multiple of 16) */
+    int32_t Cs;           /* GEMM K per tap (multiple of 64; 3C in split mode) */
+    int32_t src_wrap;     /* 0, or 2C in split mode (see above) */
+    int32_t Cr;           /* GEMM N = row channels (multiple of 4) */
     int32_t kD, kH, kW;   /* taps */
-    /* src = (row * mul + tap * tmul - pad) / div, valid iff divisible & in range */
     int32_t mulD, mulH, mulW;
     int32_t tmulD, tmulH, tmulW;
     int32_t padD, padH, padW;
     int32_t divD, divH, divW;
-    int32_t src_stride;   /* elements between consecutive source sites (>= Cs) */
-    int32_t out_stride;   /* elements between consecutive row sites (>= Cr) */
+    int64_t src_sB, src_sD, src_sH, src_sW; /* source strides, elements */
+    int64_t out_sB, out_sD, out_sH, out_sW; /* row/output strides, elements */
 } vnConv;
 
+/* stats_sums: NULL, or double[2*Cr] receiving per-channel sum / sum of squares of
+ * (out - bias) over the valid rows, accumulated with atomics (caller zeroes) —
+ * the train-mode BatchNorm reduction fused into the epilogue. */
 int vn_conv_gather_gemm(const void *src /*bf16*/, const void *w_packed /*bf16 [taps][Cr][Cs]*/,
                         const float *bias /*[Cr] or NULL*/, void *out, vnDtype out_dtype,
-                        const vnConv *geom, int32_t accumulate, vnStream stream);
+                        const vnConv *geom, int32_t accumulate, double *stats_sums,
+                        vnStream stream);
 
-/* Weight-gradient: dw[tap][n][k] (+)= sum_m src[site(m,tap), k] * rows[m, n]
- * (fp32 output in the packed [taps][Cr][Cs] orientation; split over m with
- * fp32 atomics — caller zeroes dw first unless accumulating). */
-int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16 [M,Cr]*/,
-                  float *dw_packed, const vnConv *geom, int32_t rows_stride,
-                  vnStream stream);
+/* Weight-gradient: dw[tap][n][k] += sum_m src[site(m,tap), k] * rows[m, n]
+ * fp32, packed [taps][Cr][C] orientation, C = real source channels; split over m
+ * with fp32 atomics — the caller zeroes dw first.  rows_* strides address the
+ * (B,Dr,Hr,Wr,Cr) gradient.  split != 0: src rows are [hi|lo] 2C wide and rows
+ * are [hi|lo] 2Cr wide; the three bf16x3 products are accumulated.
+ * geom->Cs is the real C here and geom->src_wrap is ignored. */
+int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16*/, float *dw_packed,
+                  const vnConv *geom, int32_t split, vnStream stream);
 
 /* Packing between torch parameter layouts and the kernels' [taps][N][K] bf16.
  * mode 0: Conv weight (Cout,Cin,k...) -> forward operand   [tap][Cout][Cin]
- * mode 1: Conv weight                 -> data-grad operand [tap][Cin][Cout] (taps as stored)
+ * mode 1: Conv weight                 -> data-grad operand [tap][Cin][Cout]
  * mode 2: ConvTranspose weight (Cin,Cout,kh,kw) -> forward operand [tap][Cout][Cin]
  * mode 3: ConvTranspose weight        -> data-grad operand [tap][Cin][Cout]
- * `split3`: emit the bf16x3 expansion (hi|lo|hi resp. hi;hi;lo along K) used by
- * the fp32-accurate mode. */
-int vn_pack_weight(const float *w, int32_t n_out, int32_t n_in, int32_t taps,
-                   int32_t mode, int32_t split3, void *packed, vnStream stream);
-/* inverse for gradients: packed fp32 [tap][N][K] -> torch layout, mode as above */
-int vn_unpack_wgrad(const float *dw_packed, int32_t n_out, int32_t n_in, int32_t taps,
-                    int32_t mode, int32_t fold3, float *dw, vnStream stream);
+ * split3: emit the bf16x3 expansion [hi;hi;lo] along K (3x wide rows).
+ * cin_fold f: the packed Cin index p stands for torch channel (p % (Cin/f))*f + p/(Cin/f)
+ * (f = 2 implements the BEV reshape of model.py:262, channel = c*2 + d; else 1). */
+int vn_pack_weight(const float *w, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode,
+                   int32_t split3, int32_t cin_fold, void *packed, vnStream stream);
+/* inverse for gradients: packed fp32 [tap][N][K] (mode 0 or 2 orientation) -> torch layout */
+int vn_unpack_wgrad(const float *dw_packed, int32_t c_out, int32_t c_in, int32_t taps,
+                    int32_t mode, int32_t cin_fold, float *dw, vnStream stream);
 
 /* ------------------------------------------------------------------------
  * BatchNorm(+ReLU) over channels-last rows — nn.BatchNorm{1,2,3}d defaults
  * (momentum 0.1, eps 1e-5) as used at model.py:72,142,153,193.
+ * Rows are M x C with `stride` elements between rows.  `fold` (1 or 2): the C
+ * columns are `fold` copies of C/fold real channels (BEV view of the last
+ * Conv3d, model.py:262); parameter vectors have C/fold entries, the sums /
+ * stats / coef work vectors are C wide.
  * ---------------------------------------------------------------------- */
-/* per-channel sum / sum of squares over M rows -> stats[2C] (fp32; zeroed here) */
-int vn_bn_stats(const void *y, vnDtype dtype, int64_t M, int32_t C, int32_t stride,
-                float *sums /*[2C]*/, vnStream stream);
-/* sums -> (mean, invstd) in place; updates running stats (unbiased var) */
-int vn_bn_finalize(float *sums_to_stats /*[2C]*/, int64_t M, int32_t C, float eps,
-                   float momentum, float *running_mean, float *running_var,
-                   vnStream stream);
-/* a = relu?(gamma*(y-mean)*invstd+beta) -> bf16 (optionally hi|lo|hi split) or f32 */
-int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t M, int32_t C, int32_t y_stride,
-                const float *stats, const float *gamma, const float *beta, int32_t relu,
-                void *a, vnDtype a_dtype, int32_t a_stride, int32_t split3,
-                vnStream stream);
-/* backward, step 1: dz = da * (relu ? a>0 : 1); sums[0:C] = sum dz, sums[C:2C] = sum dz*xhat */
-int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int32_t da_stride, const void *y,
-                     vnDtype y_dtype, int32_t y_stride, int64_t M, int32_t C,
-                     const float *stats, const float *gamma, const float *beta,
-                     int32_t relu, float *sums /*[2C]*/, vnStream stream);
-/* step 2: dy = gamma*invstd*(dz - sum_dz/M - xhat*sum_dzxhat/M); d_gamma = sums[C:], d_beta = sums[:C] */
-int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int32_t da_stride, const void *y,
-                    vnDtype y_dtype, int32_t y_stride, int64_t M, int32_t C,
-                    const float *stats, const float *gamma, const float *beta,
-                    int32_t relu, const float *sums, void *dy, vnDtype dy_dtype,
-                    int32_t dy_stride, int32_t split3, vnStream stream);
+/* sums[0:C] += sum_m (y - shift), sums[C:2C] += sum_m (y - shift)^2   (double; caller zeroes)
+ * shift: float[C/fold] or NULL (conditioning only; finalize takes the same shift) */
+int vn_bn_stats(const void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stride, int32_t fold,
+                const float *shift, double *sums, vnStream stream);
+/* sums -> stats[4C] = mean | invstd | S = gamma*invstd | beta  with a = S*(y-mean) + beta;
+ * training: batch statistics (biased var) + running-stat update (unbiased var);
+ * eval (training == 0): running statistics, sums ignored. */
+int vn_bn_finalize(const double *sums, int64_t M, int32_t C, int32_t fold, const float *shift,
+                   const float *gamma, const float *beta, float *running_mean, float *running_var,
+                   int32_t training, float momentum, float eps, float *stats, vnStream stream);
+/* a = relu?(S*(y-mean) + beta) -> f32 or bf16 rows.  lo_off != 0 (split mode): the
+ * bf16 residual lo = bf16(a - hi) is also written, lo_off elements after hi. */
+int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C,
+                const float *stats, int32_t relu, void *a, vnDtype a_dtype, int64_t a_stride,
+                int64_t lo_off, vnStream stream);
+/* backward step 1: dz = da * (relu ? S*y+T > 0 : 1);
+ * sums[0:C] += sum dz, sums[C:2C] += sum dz*xhat   (double; caller zeroes) */
+int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y,
+                     vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                     int32_t relu, double *sums, vnStream stream);
+/* step 2: folds the sums; coef[3C] with dy = c0*dz + c1*(y-mean) + c2;
+ * d_gamma[C/fold] = sum dz*xhat, d_beta[C/fold] = sum dz */
+int vn_bn_bwd_finalize(const double *sums, int64_t M, int32_t C, int32_t fold, const float *gamma,
+                       const float *stats, float *coef, float *d_gamma, float *d_beta,
+                       vnStream stream);
+/* step 3: dy = c0*dz + c1*(y-mean) + c2 -> f32 or bf16 (+ residual at lo_off, as vn_bn_apply) */
+int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y,
+                    vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                    const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
+                    int64_t lo_off, vnStream stream);
 
 /* ------------------------------------------------------------------------
  * Layout / dtype helpers at the nn.Module boundary (the reference's modules
- * speak NCDHW fp32; model.py:259,262,281).
+ * speak NC(D)HW fp32; model.py:259,262,281).
  * ---------------------------------------------------------------------- */
-/* (B,C,S) fp32 <-> (B,S,C) bf16/fp32, S = product of spatial dims */
-int vn_nchw_to_nhwc(const float *src, int32_t B, int32_t C, int64_t S, void *dst,
-                    vnDtype dst_dtype, int32_t dst_stride, int32_t split3, vnStream stream);
-int vn_nhwc_to_nchw(const void *src, vnDtype src_dtype, int32_t src_stride, int32_t B,
-                    int32_t C, int64_t S, float *dst, int32_t sigmoid_first_n,
-                    vnStream stream);
-/* elementwise cast/copy of M rows of C channels between strided buffers */
-int vn_cast_rows(const void *src, vnDtype src_dtype, int32_t src_stride, int64_t M,
-                 int32_t C, void *dst, vnDtype dst_dtype, int32_t dst_stride,
-                 int32_t split3, vnStream stream);
-/* per-channel column sums of M rows (bias gradients): out[C] = sum_m rows[m,:] */
-int vn_col_sums(const void *rows, vnDtype dtype, int32_t stride, int64_t M, int32_t C,
+/* (B,C,S) fp32 -> (B,S,C) rows (f32 / bf16 [+ residual at lo_off]); S = prod(spatial) */
+int vn_nchw_to_rows(const float *src, int32_t B, int32_t C, int64_t S, void *dst,
+                    vnDtype dst_dtype, int64_t dst_stride, int64_t lo_off, vnStream stream);
+/* (B,S,C) rows -> (B,C,S) fp32; sigmoid applied to the first `sigmoid_first_n` channels */
+int vn_rows_to_nchw(const void *src, vnDtype src_dtype, int64_t src_stride, int32_t B, int32_t C,
+                    int64_t S, float *dst, int32_t sigmoid_first_n, vnStream stream);
+/* row-wise cast/copy of M rows of C channels between strided buffers (+ residual at lo_off) */
+int vn_cast_rows(const void *src, vnDtype src_dtype, int64_t src_stride, int64_t M, int32_t C,
+                 void *dst, vnDtype dst_dtype, int64_t dst_stride, int64_t lo_off, vnStream stream);
+/* per-channel column sums of M rows (bias gradients): out[C] += sum_m rows[m,:] (float; caller zeroes) */
+int vn_col_sums(const void *rows, vnDtype dtype, int64_t stride, int64_t M, int32_t C,
                 float *out, vnStream stream);
+/* heads epilogue (model.py:281): rows (M,16) = [2 prob logits | 14 reg] ->
+ * NCHW prob = sigmoid (B,2,S), reg (B,14,S); and its backward:
+ * d_rows = [d_prob * p * (1-p) | d_reg] as bf16 or split rows */
+int vn_heads_bwd(const float *d_prob /*(B,2,S)*/, const float *d_reg /*(B,14,S)*/,
+                 const float *prob /*(B,2,S)*/, int32_t B, int64_t S, void *d_rows,
+                 int64_t d_stride, int32_t split, vnStream stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,297 @@
+// Train-/eval-mode BatchNorm (+ReLU) over channels-last rows — the batch_norm /
+// relu calls at model.py:72,76 (BatchNorm1d), 142,153,165-166 (ConvMD) and 193,198
+// (DeConv2d), forward and backward.  HBM-bound streaming kernels: 8 channels per
+// lane (16-B bf16 / 2x16-B fp32 accesses), rows distributed over the workgroup,
+// per-lane fp32 partials over a bounded number of rows, then double precision for
+// the cross-lane / cross-workgroup part (the variance is a difference of large
+// numbers when |mean| >> std, which is the case for the first Conv3d: 99 % of its
+// output sites equal the bias).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ void load8(const void *base, int dtype, int64_t off, float v[8]) {
+    if (dtype == VN_F32) {
+        const float4 a = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off);
+        const float4 b = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const bf16x8_t t = *reinterpret_cast<const bf16x8_t *>(static_cast<const bf16_t *>(base) + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)t[j];
+    }
+}
+
+__device__ __forceinline__ void store8(void *base, int dtype, int64_t lo_off, int64_t off, const float v[8]) {
+    if (dtype == VN_F32) {
+        float *d = static_cast<float *>(base) + off;
+        *reinterpret_cast<float4 *>(d) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4 *>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    } else {
+        bf16x8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bf16_t h, l; vn_split_bf16(v[j], h, l); hi[j] = h; lo[j] = l; }
+        bf16_t *d = static_cast<bf16_t *>(base) + off;
+        *reinterpret_cast<bf16x8_t *>(d) = hi;
+        if (lo_off) *reinterpret_cast<bf16x8_t *>(d + lo_off) = lo;
+    }
+}
+
+// block-level column reduction of 2 x 8 floats per thread -> double atomics
+__device__ __forceinline__ void block_reduce_atomic(const float s1[8], const float s2[8], int groups, int rpb, int C,
+                                                    double *sums) {
+    __shared__ float red[256 * 16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x * 16 + j] = s1[j];
+        red[threadIdx.x * 16 + 8 + j] = s2[j];
+    }
+    __syncthreads();
+    // thread t < groups*16 sums one (group, slot) column over the rpb row-slices
+    for (int t = threadIdx.x; t < groups * 16; t += 256) {
+        const int g = t >> 4, slot = t & 15;
+        double acc = 0.0;
+        for (int r = 0; r < rpb; ++r) acc += (double)red[(r * groups + g) * 16 + slot];
+        const int c = g * 8 + (slot & 7);
+        atomicAdd(sums + (slot >= 8 ? C : 0) + c, acc);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bn_stats(const void *__restrict__ y, int dtype, int64_t M, int C,
+                                                  int64_t stride, int fold, const float *__restrict__ shift,
+                                                  double *__restrict__ sums) {
+    const int groups = C >> 3, rpb = 256 / groups;
+    const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
+    const int creal = C / fold;
+    float sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[j] = shift ? shift[(g * 8 + j) % creal] : 0.f;
+    float s1[8] = {0}, s2[8] = {0};
+    if (rr < rpb) {
+        for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
+            float v[8];
+            load8(y, dtype, m * stride + g * 8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d = v[j] - sh[j];
+                s1[j] += d;
+                s2[j] += d * d;
+            }
+        }
+    }
+    block_reduce_atomic(s1, s2, groups, rpb, C, sums);
+}
+
+__global__ void __launch_bounds__(256) k_bn_finalize(const double *__restrict__ sums, int64_t M, int C, int fold,
+                                                     const float *__restrict__ shift, const float *__restrict__ gamma,
+                                                     const float *__restrict__ beta, float *running_mean,
+                                                     float *running_var, int training, float momentum, float eps,
+                                                     float *__restrict__ stats) {
+    const int creal = C / fold;
+    for (int c = threadIdx.x; c < creal; c += blockDim.x) {
+        double mean, var;
+        if (training) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int f = 0; f < fold; ++f) { s1 += sums[c + f * creal]; s2 += sums[C + c + f * creal]; }
+            const double n = (double)M * fold;
+            const double ms = s1 / n;
+            var = s2 / n - ms * ms;
+            if (var < 0.0) var = 0.0;
+            mean = ms + (shift ? (double)shift[c] : 0.0);
+            if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            if (running_var) {
+                const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            }
+        } else {
+            mean = running_mean[c];
+            var = running_var[c];
+        }
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float S = gamma[c] * invstd;
+        for (int f = 0; f < fold; ++f) {
+            const int ce = c + f * creal;
+            stats[ce] = (float)mean;
+            stats[C + ce] = invstd;
+            stats[2 * C + ce] = S;
+            stats[3 * C + ce] = beta[c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, int ydt, int64_t ystride, int64_t M, int C,
+                                                  const float *__restrict__ stats, int relu, void *__restrict__ a,
+                                                  int adt, int64_t astride, int64_t lo_off) {
+    const int groups = C >> 3;
+    const int64_t total = M * groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / groups;
+        const int c = (int)(i - m * groups) << 3;
+        float v[8];
+        load8(y, ydt, m * ystride + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float z = fmaf(stats[2 * C + c + j], v[j] - stats[c + j], stats[3 * C + c + j]);
+            v[j] = relu ? fmaxf(z, 0.f) : z;
+        }
+        store8(a, adt, lo_off, m * astride + c, v);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ da, int dadt, int64_t dastride,
+                                                       const void *__restrict__ y, int ydt, int64_t ystride, int64_t M,
+                                                       int C, const float *__restrict__ stats, int relu,
+                                                       double *__restrict__ sums) {
+    const int groups = C >> 3, rpb = 256 / groups;
+    const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
+    float mean[8], invstd[8], S[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = g * 8 + j;
+        mean[j] = stats[c]; invstd[j] = stats[C + c]; S[j] = stats[2 * C + c]; be[j] = stats[3 * C + c];
+    }
+    float s1[8] = {0}, s2[8] = {0};
+    if (rr < rpb) {
+        for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
+            float yv[8], dv[8];
+            load8(y, ydt, m * ystride + g * 8, yv);
+            load8(da, dadt, m * dastride + g * 8, dv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d0 = yv[j] - mean[j];
+                const float z = fmaf(S[j], d0, be[j]);
+                const float dz = (!relu || z > 0.f) ? dv[j] : 0.f;
+                s1[j] += dz;
+                s2[j] += dz * (d0 * invstd[j]);
+            }
+        }
+    }
+    block_reduce_atomic(s1, s2, groups, rpb, C, sums);
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_finalize(const double *__restrict__ sums, int64_t M, int C, int fold,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ stats, float *__restrict__ coef,
+                                                         float *__restrict__ d_gamma, float *__restrict__ d_beta) {
+    const int creal = C / fold;
+    for (int c = threadIdx.x; c < creal; c += blockDim.x) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int f = 0; f < fold; ++f) { s1 += sums[c + f * creal]; s2 += sums[C + c + f * creal]; }
+        const double n = (double)M * fold;
+        const float invstd = stats[C + c];
+        const float S = gamma[c] * invstd;
+        const float m1 = (float)(s1 / n), m2 = (float)(s2 / n);
+        if (d_gamma) d_gamma[c] = (float)s2;
+        if (d_beta) d_beta[c] = (float)s1;
+        for (int f = 0; f < fold; ++f) {
+            const int ce = c + f * creal;
+            coef[ce] = S;
+            coef[C + ce] = -S * invstd * m2;
+            coef[2 * C + ce] = -S * m1;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(const void *__restrict__ da, int dadt, int64_t dastride,
+                                                      const void *__restrict__ y, int ydt, int64_t ystride, int64_t M,
+                                                      int C, const float *__restrict__ stats,
+                                                      const float *__restrict__ coef, int relu, void *__restrict__ dy,
+                                                      int dydt, int64_t dystride, int64_t lo_off) {
+    const int groups = C >> 3;
+    const int64_t total = M * groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / groups;
+        const int c = (int)(i - m * groups) << 3;
+        float yv[8], dv[8], o[8];
+        load8(y, ydt, m * ystride + c, yv);
+        load8(da, dadt, m * dastride + c, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d0 = yv[j] - stats[c + j];
+            const float z = fmaf(stats[2 * C + c + j], d0, stats[3 * C + c + j]);
+            const float dz = (!relu || z > 0.f) ? dv[j] : 0.f;
+            o[j] = fmaf(coef[c + j], dz, fmaf(coef[C + c + j], d0, coef[2 * C + c + j]));
+        }
+        store8(dy, dydt, lo_off, m * dystride + c, o);
+    }
+}
+
+inline unsigned gs_blocks(int64_t total, int per_block, int cap) {
+    int64_t b = vn_ceil_div(total, per_block);
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+inline bool rows_ok(int C, int64_t stride) { return C >= 8 && (C & 7) == 0 && C <= 2048 && (stride & 7) == 0; }
+
+}  // namespace
+
+extern "C" int vn_bn_stats(const void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stride, int32_t fold,
+                           const float *shift, double *sums, vnStream stream) {
+    VN_CHECK_ARG(sums && M >= 0 && fold >= 1 && rows_ok(C, stride) && C % fold == 0);
+    if (M == 0) return VN_OK;
+    VN_CHECK_ARG(y);
+    const int rpb = 256 / (C >> 3);
+    k_bn_stats<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(y, (int)dtype, M, C, stride, fold, shift, sums);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_finalize(const double *sums, int64_t M, int32_t C, int32_t fold, const float *shift,
+                              const float *gamma, const float *beta, float *running_mean, float *running_var,
+                              int32_t training, float momentum, float eps, float *stats, vnStream stream) {
+    VN_CHECK_ARG(gamma && beta && stats && C > 0 && fold >= 1 && C % fold == 0);
+    VN_CHECK_ARG(training ? (sums != nullptr && M > 0) : (running_mean && running_var));
+    k_bn_finalize<<<1, 256, 0, vn_stream(stream)>>>(sums, M, C, fold, shift, gamma, beta, running_mean, running_var,
+                                                    training, momentum, eps, stats);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                           int32_t relu, void *a, vnDtype a_dtype, int64_t a_stride, int64_t lo_off, vnStream stream) {
+    VN_CHECK_ARG(M >= 0 && rows_ok(C, y_stride) && (a_stride & 7) == 0 && (lo_off & 7) == 0 && lo_off >= 0 && (!lo_off || a_dtype == VN_BF16));
+    if (M == 0) return VN_OK;
+    VN_CHECK_ARG(y && a && stats);
+    k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
+                                                                                   relu, a, (int)a_dtype, a_stride, lo_off);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y, vnDtype y_dtype,
+                                int64_t y_stride, int64_t M, int32_t C, const float *stats, int32_t relu, double *sums,
+                                vnStream stream) {
+    VN_CHECK_ARG(sums && M >= 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0);
+    if (M == 0) return VN_OK;
+    VN_CHECK_ARG(da && y && stats);
+    const int rpb = 256 / (C >> 3);
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+                                                                                 (int)y_dtype, y_stride, M, C, stats,
+                                                                                 relu, sums);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_bwd_finalize(const double *sums, int64_t M, int32_t C, int32_t fold, const float *gamma,
+                                  const float *stats, float *coef, float *d_gamma, float *d_beta, vnStream stream) {
+    VN_CHECK_ARG(sums && gamma && stats && coef && M > 0 && C > 0 && fold >= 1 && C % fold == 0);
+    k_bn_bwd_finalize<<<1, 256, 0, vn_stream(stream)>>>(sums, M, C, fold, gamma, stats, coef, d_gamma, d_beta);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y, vnDtype y_dtype,
+                               int64_t y_stride, int64_t M, int32_t C, const float *stats, const float *coef,
+                               int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride, int64_t lo_off,
+                               vnStream stream) {
+    VN_CHECK_ARG(M >= 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0 && (dy_stride & 7) == 0);
+    VN_CHECK_ARG(lo_off >= 0 && (lo_off & 7) == 0 && (!lo_off || dy_dtype == VN_BF16));
+    if (M == 0) return VN_OK;
+    VN_CHECK_ARG(da && y && stats && coef && dy);
+    k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(
+        da, (int)da_dtype, da_stride, y, (int)y_dtype, y_stride, M, C, stats, coef, relu, dy, (int)dy_dtype, dy_stride,
+        lo_off);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}

@@ -1,0 +1,445 @@
+// Gather-GEMM convolution on the gfx950 matrix cores — replaces the ATen conv /
+// conv_transpose calls behind model.py:111-199 (ConvMD, DeConv2d), forward and
+// data-gradient.
+//
+//   out[m, n] = bias[n] + sum_{tap, k} src[site(m, tap), k] * w[tap][n][k]
+//
+// Design (CDNA4-first):
+//   * One workgroup = 4 waves = a (64*WM) x (64*WN) output tile; every wave owns a
+//     64x64 sub-tile as 4x4 v_mfma_f32_16x16x32_bf16 accumulators (64 VGPRs).
+//   * K loop = taps x (Cs/64).  Each step stages a [rows][64] bf16 slab of the
+//     gathered source rows and of the packed weights in LDS by LDS-DMA
+//     (buffer_load_dwordx4 ... lds): every lane supplies its own source address,
+//     so the im2col gather costs no registers and no ds_write.  Invalid taps
+//     (padding, out-of-range, residue mismatch) point past the buffer
+//     descriptor's num_records and the hardware returns zeros.
+//   * LDS rows are 128 B; the 16-B chunk c of row r sits at slot c ^ ((r>>1)&7)
+//     so the ds_read_b128 fragment reads are bank-conflict free.  LDS-DMA writes
+//     linearly, so the swizzle is applied to the per-lane SOURCE address.
+//   * Two LDS stages: the loads of step s+1 fly while step s is on the MFMAs.
+//   * Weight rows are staged permuted so that a lane's four accumulator tiles
+//     hold four CONSECUTIVE output channels: the epilogue stores 8 B (bf16) or
+//     16 B (fp32) per lane, 128/256 B contiguous per row.
+//   * Strided transposed gathers (ConvTranspose2d forward, data-gradient of a
+//     strided conv) run as residue classes (blockIdx.y) of stride-1 gathers.
+//   * Optional fused BatchNorm reduction: per-channel sum / sum of squares of
+//     the fp32 accumulators (before the bias is added) -> double atomics.
+#include "common.h"
+
+namespace {
+
+constexpr int GG_MAX_TAPS = 32;
+constexpr int GG_MAX_CLASSES = 16;
+constexpr uint32_t GG_OOB = 0xFFFFF000u;   // voffset of an invalid gather row
+constexpr uint32_t GG_MAX_WINDOW = 0xFFFFE000u;
+
+struct GGClass {
+    int32_t tap_begin, ntaps;
+    int32_t qD, qH, qW;            // row grid of this class
+    int32_t ooffD, ooffH, ooffW;   // out coord = q * omul + ooff
+    int32_t offD[4], offH[4], offW[4];   // src coord = q * mul + off[axis index]
+};
+struct GGTap {
+    int32_t id, ih, iw, widx;
+};
+struct GGParams {
+    const char *src;
+    const char *w;
+    const float *bias;
+    char *out;
+    double *stats;
+    int64_t sB, sD, sH, sW;   // elements
+    int64_t oB, oD, oH, oW;
+    int32_t B, Ds, Hs, Ws, Do, Ho, Wo;
+    int32_t mulD, mulH, mulW, omulD, omulH, omulW;
+    int32_t Cs, src_wrap, N, out_f32, accumulate, nclasses, src_row_elems;
+    uint32_t w_bytes;
+    int64_t src_batch_extent;   // elements spanned by one batch item (for num_records)
+    GGClass cls[GG_MAX_CLASSES];
+    GGTap taps[GG_MAX_TAPS];
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds_wave_base, uint32_t voffset,
+                                          uint32_t soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
+template <int WM, int WN>
+__global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int RA = BM / 32, RB = BN / 32;     // LDS-DMA instructions per wave per step
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // ---- tile of this workgroup (XCD-aware: neighbouring tiles share an L2) ----
+    const GGClass &cl = p.cls[blockIdx.y];
+    const int ntn = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+    const int qD = cl.qD, qH = cl.qH, qW = cl.qW;
+    const int64_t Mq = (int64_t)p.B * qD * qH * qW;
+    const int64_t m0 = (int64_t)tile_m * BM;
+    if (m0 >= Mq) return;   // block-uniform
+    const int n0 = tile_n * BN;
+    const int rows_per_b = qD * qH * qW;
+    const int b0 = (int)(m0 / rows_per_b);
+
+    // ---- per-lane loader state ----
+    // A rows: instruction i of this wave covers LDS rows ((i*4+wave)*8 .. +7); lane -> row +(lane>>3), slot lane&7
+    const int a_chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);   // source chunk for this lane's slot
+    uint32_t a_row[RA];
+    uint32_t a_bits[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const int r = (i * 4 + wave) * 8 + (lane >> 3);
+        const int64_t m = m0 + r;
+        a_row[i] = GG_OOB;
+        a_bits[i] = 0;
+        if (m < Mq) {
+            int t = (int)(m - (int64_t)b0 * rows_per_b);   // row index relative to batch b0 (may span batches)
+            const int db = t / rows_per_b;
+            t -= db * rows_per_b;
+            const int qw = t % qW;
+            t /= qW;
+            const int qh = t % qH;
+            const int qd = t / qH;
+            const int sd = qd * p.mulD, sh = qh * p.mulH, sw = qw * p.mulW;
+            const int64_t e = (int64_t)db * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW;
+            a_row[i] = (uint32_t)(e * 2) + (uint32_t)a_chunk * 16u;
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bits |= ((uint32_t)(sd + cl.offD[j]) < (uint32_t)p.Ds ? 1u : 0u) << j;
+                bits |= ((uint32_t)(sh + cl.offH[j]) < (uint32_t)p.Hs ? 1u : 0u) << (4 + j);
+                bits |= ((uint32_t)(sw + cl.offW[j]) < (uint32_t)p.Ws ? 1u : 0u) << (8 + j);
+            }
+            a_bits[i] = bits;
+        }
+    }
+    // B rows: LDS row rho of the tile holds weight row n0 + (rho/64)*64 + (rho%16)*4 + (rho%64)/16
+    uint32_t b_row[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int rho = (i * 4 + wave) * 8 + (lane >> 3);
+        const int rl = rho & 63;
+        const int n = n0 + (rho & ~63) + (rl & 15) * 4 + (rl >> 4);
+        const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
+        b_row[i] = n < p.N ? (uint32_t)(((int64_t)n * p.Cs + chunk * 8) * 2) : GG_OOB;
+    }
+
+    // buffer descriptors (wave-uniform by construction: kernel args and blockIdx only)
+    const char *src_base = p.src + (int64_t)b0 * p.sB * 2;
+    int64_t src_bytes = ((int64_t)(p.B - b0 - 1) * p.sB + p.src_batch_extent) * 2;
+    if (src_bytes > (int64_t)GG_MAX_WINDOW) src_bytes = GG_MAX_WINDOW;
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc((void *)src_base, 0, (int)(uint32_t)src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b =
+        __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_bytes, 0x00020000);
+
+    const int nk = p.Cs >> 6;
+    const int nsteps = cl.ntaps * nk;
+
+    auto stage = [&](int s, int buf) {
+        const int tap = s / nk, kc = s - tap * nk;
+        const GGTap tp = p.taps[cl.tap_begin + tap];
+        const uint32_t tapbits = (1u << tp.id) | (16u << tp.ih) | (256u << tp.iw);
+        const int64_t de = (int64_t)cl.offD[tp.id] * p.sD + (int64_t)cl.offH[tp.ih] * p.sH +
+                           (int64_t)cl.offW[tp.iw] * p.sW;
+        const uint32_t delta = (uint32_t)(int32_t)(de * 2);
+        int kb = kc << 6;
+        if (p.src_wrap > 0 && kb >= p.src_wrap) kb -= p.src_wrap;
+        const uint32_t a_soff = (uint32_t)kb * 2u;
+        const uint32_t b_soff = (uint32_t)(((int64_t)tp.widx * p.N * p.Cs + ((int64_t)kc << 6)) * 2);
+        char *la = smem + buf * STAGE + wave * 1024;
+        char *lb = smem + buf * STAGE + A_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const bool ok = (a_bits[i] & tapbits) == tapbits;
+            const uint32_t v = ok ? a_row[i] + delta : GG_OOB;
+            lds_dma16(rs_a, la + i * 4096, v, a_soff);
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) lds_dma16(rs_b, lb + i * 4096, b_row[i], b_soff);
+    };
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row (lane&15), chunk (ks*4 + lane>>4) ^ ((lane&15)>>1)
+    const int fr = lane & 15, fq = lane >> 4;
+    const int frag_off0 = fr * 128 + (((0 + fq) ^ (fr >> 1)) << 4);
+    const int frag_off1 = fr * 128 + (((4 + fq) ^ (fr >> 1)) << 4);
+
+    stage(0, 0);
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nsteps) stage(s + 1, buf ^ 1);
+        const char *la = smem + buf * STAGE + wm * (64 * 128);
+        const char *lb = smem + buf * STAGE + A_BYTES + wn * (64 * 128);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int fo = ks ? frag_off1 : frag_off0;
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t *>(la + i * 2048 + fo);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t *>(lb + j * 2048 + fo);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ----
+    // per-row output element offsets into LDS (stage memory is free now)
+    __syncthreads();
+    int32_t *otab = reinterpret_cast<int32_t *>(smem);
+    for (int r = threadIdx.x; r < BM; r += 256) {
+        const int64_t m = m0 + r;
+        int32_t off = -1;
+        if (m < Mq) {
+            int t = (int)(m % rows_per_b);
+            const int b = (int)(m / rows_per_b);
+            const int qw = t % qW;
+            t /= qW;
+            const int qh = t % qH;
+            const int qd = t / qH;
+            const int od = qd * p.omulD + cl.ooffD, oh = qh * p.omulH + cl.ooffH, ow = qw * p.omulW + cl.ooffW;
+            if (od < p.Do && oh < p.Ho && ow < p.Wo)
+                off = (int32_t)((int64_t)b * p.oB + (int64_t)od * p.oD + (int64_t)oh * p.oH + (int64_t)ow * p.oW);
+        }
+        otab[r] = off;
+    }
+    __syncthreads();
+
+    const int ncol = n0 + wn * 64 + fr * 4;   // this lane's 4 consecutive output channels
+    const bool col_ok = ncol < p.N;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && col_ok) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + ncol);
+        bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int4 offs = *reinterpret_cast<const int4 *>(otab + wm * 64 + i * 16 + fq * 4);
+        const int32_t o4[4] = {offs.x, offs.y, offs.z, offs.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (o4[e] < 0 || !col_ok) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = acc[i][j][e];
+                s1[j] += a;
+                s2[j] += a * a;
+                v[j] = a + bias4[j];
+            }
+            if (p.out_f32) {
+                float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + (int64_t)o4[e] + ncol);
+                if (p.accumulate) {
+                    const float4 old = *dst;
+                    v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+                }
+                *dst = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16x4_t *dst = reinterpret_cast<bf16x4_t *>(reinterpret_cast<bf16_t *>(p.out) + (int64_t)o4[e] + ncol);
+                if (p.accumulate) {
+                    const bf16x4_t old = *dst;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
+                }
+                bf16x4_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+                *dst = o;
+            }
+        }
+    }
+    if (p.stats) {
+        // reduce over the 4 row groups (lane>>4) of the wave, then one double atomic per column per wave
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s1[j] += __shfl_xor(s1[j], 16, 64);
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 16, 64);
+            s2[j] += __shfl_xor(s2[j], 32, 64);
+        }
+        if (fq == 0 && col_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                atomicAdd(p.stats + ncol + j, (double)s1[j]);
+                atomicAdd(p.stats + p.N + ncol + j, (double)s2[j]);
+            }
+        }
+    }
+}
+
+inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+inline int posmod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
+
+struct AxisClass {
+    int r;          // residue (out offset)
+    int q;          // row-grid size along this axis
+    int n;          // taps in this class
+    int tap[4];     // kernel index
+    int off[4];     // source coordinate offset
+};
+
+// decompose one axis: s = (row*mul + t*tmul - pad)/div.  Returns number of classes.
+int axis_classes(int R, int k, int mul, int tmul, int pad, int div, AxisClass *out, int *mul_out, int *omul_out) {
+    if (div == 1) {
+        AxisClass c{};
+        c.r = 0; c.q = R; c.n = k;
+        for (int t = 0; t < k; ++t) { c.tap[t] = t; c.off[t] = t * tmul - pad; }
+        out[0] = c;
+        *mul_out = mul; *omul_out = 1;
+        return 1;
+    }
+    // mul must be 1: row = div*q + r
+    int nc = 0;
+    for (int r = 0; r < div && r < R; ++r) {
+        AxisClass c{};
+        c.r = r; c.q = (R - r + div - 1) / div; c.n = 0;
+        for (int t = 0; t < k; ++t) {
+            const int num = r + t * tmul - pad;
+            if (posmod(num, div) == 0) { c.tap[c.n] = t; c.off[c.n] = floordiv(num, div); ++c.n; }
+        }
+        out[nc++] = c;
+    }
+    *mul_out = 1; *omul_out = div;
+    return nc;
+}
+
+}  // namespace
+
+extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const float *bias, void *out,
+                                   vnDtype out_dtype, const vnConv *g, int32_t accumulate, double *stats_sums,
+                                   vnStream stream) {
+    VN_CHECK_ARG(src && w_packed && out && g);
+    VN_CHECK_ARG(g->B > 0 && g->Ds > 0 && g->Hs > 0 && g->Ws > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0);
+    VN_CHECK_ARG(g->kD >= 1 && g->kD <= 4 && g->kH >= 1 && g->kH <= 4 && g->kW >= 1 && g->kW <= 4);
+    VN_CHECK_ARG(g->kD * g->kH * g->kW <= GG_MAX_TAPS);
+    VN_CHECK_ARG(g->divD >= 1 && g->divH >= 1 && g->divW >= 1);
+    VN_CHECK_ARG(g->divD == 1 || g->mulD == 1);
+    VN_CHECK_ARG(g->divH == 1 || g->mulH == 1);
+    VN_CHECK_ARG(g->divW == 1 || g->mulW == 1);
+    VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
+    if (g->Cs <= 0 || (g->Cs & 63) || g->Cr <= 0 || (g->Cr & 3)) return VN_EUNSUPPORTED;
+    if (g->src_wrap < 0 || (g->src_wrap & 63) || (g->src_wrap > 0 && g->src_wrap >= g->Cs)) return VN_EUNSUPPORTED;
+    if (g->divD * g->divH * g->divW > GG_MAX_CLASSES) return VN_EUNSUPPORTED;
+    if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & 7) != 0) return VN_EUNSUPPORTED;      // 16-B source chunks
+    if (((g->out_sB | g->out_sD | g->out_sH | g->out_sW) & 3) != 0) return VN_EUNSUPPORTED;      // 8/16-B stores
+    if ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(w_packed) & 15) ||
+        (reinterpret_cast<uintptr_t>(out) & 15))
+        return VN_EUNSUPPORTED;
+
+    GGParams p{};
+    p.src = static_cast<const char *>(src);
+    p.w = static_cast<const char *>(w_packed);
+    p.bias = bias;
+    p.out = static_cast<char *>(out);
+    p.stats = stats_sums;
+    p.sB = g->src_sB; p.sD = g->src_sD; p.sH = g->src_sH; p.sW = g->src_sW;
+    p.oB = g->out_sB; p.oD = g->out_sD; p.oH = g->out_sH; p.oW = g->out_sW;
+    p.B = g->B; p.Ds = g->Ds; p.Hs = g->Hs; p.Ws = g->Ws;
+    p.Do = g->Dr; p.Ho = g->Hr; p.Wo = g->Wr;
+    p.Cs = g->Cs; p.src_wrap = g->src_wrap; p.N = g->Cr;
+    p.out_f32 = out_dtype == VN_F32;
+    p.accumulate = accumulate;
+    p.src_row_elems = g->src_wrap > 0 ? g->src_wrap : g->Cs;
+    const int taps_total = g->kD * g->kH * g->kW;
+    const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * 2;
+    if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;
+    p.w_bytes = (uint32_t)wb;
+    p.src_batch_extent = (int64_t)(g->Ds - 1) * g->src_sD + (int64_t)(g->Hs - 1) * g->src_sH +
+                         (int64_t)(g->Ws - 1) * g->src_sW + p.src_row_elems;
+    // output offsets are int32 elements
+    const int64_t out_extent = (int64_t)(g->B - 1) * g->out_sB + (int64_t)(g->Dr - 1) * g->out_sD +
+                               (int64_t)(g->Hr - 1) * g->out_sH + (int64_t)(g->Wr - 1) * g->out_sW + g->Cr;
+    if (out_extent >= (1ll << 31)) return VN_EUNSUPPORTED;
+
+    AxisClass ad[4], ah[4], aw[4];
+    const int ncd = axis_classes(g->Dr, g->kD, g->mulD, g->tmulD, g->padD, g->divD, ad, &p.mulD, &p.omulD);
+    const int nch = axis_classes(g->Hr, g->kH, g->mulH, g->tmulH, g->padH, g->divH, ah, &p.mulH, &p.omulH);
+    const int ncw = axis_classes(g->Wr, g->kW, g->mulW, g->tmulW, g->padW, g->divW, aw, &p.mulW, &p.omulW);
+    int ntap = 0, ncls = 0;
+    int64_t max_rows = 0;
+    for (int cd = 0; cd < ncd; ++cd)
+        for (int ch = 0; ch < nch; ++ch)
+            for (int cw = 0; cw < ncw; ++cw) {
+                const AxisClass &D = ad[cd], &H = ah[ch], &W = aw[cw];
+                GGClass &c = p.cls[ncls];
+                c.tap_begin = ntap;
+                c.qD = D.q; c.qH = H.q; c.qW = W.q;
+                c.ooffD = D.r; c.ooffH = H.r; c.ooffW = W.r;
+                for (int j = 0; j < 4; ++j) {
+                    c.offD[j] = j < D.n ? D.off[j] : (1 << 29);   // never valid
+                    c.offH[j] = j < H.n ? H.off[j] : (1 << 29);
+                    c.offW[j] = j < W.n ? W.off[j] : (1 << 29);
+                }
+                for (int i = 0; i < D.n; ++i)
+                    for (int j = 0; j < H.n; ++j)
+                        for (int k = 0; k < W.n; ++k) {
+                            if (ntap >= GG_MAX_TAPS) return VN_EUNSUPPORTED;
+                            p.taps[ntap++] = GGTap{i, j, k, (D.tap[i] * g->kH + H.tap[j]) * g->kW + W.tap[k]};
+                        }
+                c.ntaps = ntap - c.tap_begin;
+                const int64_t rows = (int64_t)g->B * D.q * H.q * W.q;
+                if (rows > max_rows) max_rows = rows;
+                ++ncls;
+            }
+    p.nclasses = ncls;
+
+    const bool wide = g->Cr > 64;   // 128x128 tile (2x2 waves) vs 256x64 (4x1)
+    const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+    // the gather window of one workgroup: rows of at most (BM / rows_per_batch + 2) batch items
+    {
+        int64_t min_rows_b = (int64_t)p.cls[0].qD * p.cls[0].qH * p.cls[0].qW;
+        for (int c = 1; c < ncls; ++c) {
+            const int64_t r = (int64_t)p.cls[c].qD * p.cls[c].qH * p.cls[c].qW;
+            if (r < min_rows_b) min_rows_b = r;
+        }
+        if (min_rows_b <= 0) min_rows_b = 1;
+        int64_t span_b = BM / min_rows_b + 2;
+        if (span_b > g->B) span_b = g->B;
+        const int64_t need = ((span_b - 1) * g->src_sB + p.src_batch_extent) * 2;
+        if (need > (int64_t)GG_MAX_WINDOW - 4096) return VN_EUNSUPPORTED;
+    }
+    const int64_t tiles_m = vn_ceil_div(max_rows, BM);
+    const int64_t tiles_n = vn_ceil_div(g->Cr, BN);
+    if (tiles_m * tiles_n > 0x7fffffffll) return VN_EUNSUPPORTED;
+    const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ncls);
+    const size_t lds = 2u * (size_t)(BM + BN) * 128u;
+    hipStream_t st = vn_stream(stream);
+    if (wide) {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather_gemm<2, 2>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+        if (attr != hipSuccess) return (int)attr;
+        k_gather_gemm<2, 2><<<grid, 256, lds, st>>>(p);
+    } else {
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather_gemm<4, 1>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
+        if (attr != hipSuccess) return (int)attr;
+        k_gather_gemm<4, 1><<<grid, 256, lds, st>>>(p);
+    }
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}

@@ -1,0 +1,280 @@
+// Weight packing and layout/dtype helpers at the nn.Module boundary.
+//   vn_pack_weight / vn_unpack_wgrad : torch parameter layouts (model.py:134-153,188-193)
+//                                      <-> the gather-GEMM's [tap][N][K] bf16 operand
+//   vn_nchw_to_rows / vn_rows_to_nchw: NC(D)HW fp32 <-> channels-last rows (model.py:259,281)
+//   vn_cast_rows, vn_col_sums, vn_heads_bwd
+// All HBM-bound elementwise/transposing kernels: 16-B accesses on the channels-last side,
+// LDS-tiled transposes so both sides stay coalesced.
+#include "common.h"
+
+namespace {
+
+// torch index of packed (tap, n, k) ; mode: 0/1 conv (Cout,Cin,taps), 2/3 convT (Cin,Cout,taps)
+__device__ __forceinline__ int64_t torch_index(int mode, int c_out, int c_in, int taps, int tap, int n, int k,
+                                               int cin_fold) {
+    // modes 0,2: n = cout, k = cin ; modes 1,3: n = cin, k = cout
+    int co = (mode == 0 || mode == 2) ? n : k;
+    int ci = (mode == 0 || mode == 2) ? k : n;
+    if (cin_fold > 1) {
+        const int per = c_in / cin_fold;
+        ci = (ci % per) * cin_fold + ci / per;
+    }
+    if (mode <= 1) return ((int64_t)co * c_in + ci) * taps + tap;
+    return ((int64_t)ci * c_out + co) * taps + tap;
+}
+
+__global__ void __launch_bounds__(256) k_pack_weight(const float *__restrict__ w, int c_out, int c_in, int taps,
+                                                     int mode, int split3, int cin_fold, bf16_t *__restrict__ packed) {
+    const int N = (mode == 0 || mode == 2) ? c_out : c_in;
+    const int K = (mode == 0 || mode == 2) ? c_in : c_out;
+    const int Ke = split3 ? 3 * K : K;
+    const int64_t total = (int64_t)taps * N * Ke;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int ke = (int)(i % Ke);
+        const int n = (int)((i / Ke) % N);
+        const int tap = (int)(i / ((int64_t)Ke * N));
+        const int k = ke % K, part = ke / K;   // part 0: hi, 1: hi, 2: lo
+        const float v = w[torch_index(mode, c_out, c_in, taps, tap, n, k, cin_fold)];
+        bf16_t hi, lo;
+        vn_split_bf16(v, hi, lo);
+        packed[i] = part == 2 ? lo : hi;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_unpack_wgrad(const float *__restrict__ dwp, int c_out, int c_in, int taps,
+                                                      int mode, int cin_fold, float *__restrict__ dw) {
+    // dwp is [tap][N = cout][K = cin] (forward orientation) for both conv (mode 0) and convT (mode 2)
+    const int64_t total = (int64_t)taps * c_out * c_in;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % c_in);
+        const int n = (int)((i / c_in) % c_out);
+        const int tap = (int)(i / ((int64_t)c_in * c_out));
+        dw[torch_index(mode, c_out, c_in, taps, tap, n, k, cin_fold)] = dwp[i];
+    }
+}
+
+__device__ __forceinline__ void store_elem(void *dst, int dtype, int64_t lo_off, int64_t row_off, int c, float v) {
+    if (dtype == VN_F32) {
+        static_cast<float *>(dst)[row_off + c] = v;
+    } else {
+        bf16_t hi, lo;
+        vn_split_bf16(v, hi, lo);
+        static_cast<bf16_t *>(dst)[row_off + c] = hi;
+        if (lo_off) static_cast<bf16_t *>(dst)[row_off + lo_off + c] = lo;
+    }
+}
+
+// (B,C,S) fp32 -> rows (B*S, C): 32x32 LDS-tiled transpose
+__global__ void __launch_bounds__(256) k_nchw_to_rows(const float *__restrict__ src, int C, int64_t S, void *dst,
+                                                      int dtype, int64_t dst_stride, int64_t lo_off) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int64_t s0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const int64_t s = s0 + tx;
+        tile[j][tx] = (c < C && s < S) ? src[((int64_t)b * C + c) * S + s] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t s = s0 + j;
+        const int c = c0 + tx;
+        if (c < C && s < S) store_elem(dst, dtype, lo_off, ((int64_t)b * S + s) * dst_stride, c, tile[tx][j]);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_rows_to_nchw(const void *__restrict__ src, int dtype, int64_t src_stride,
+                                                      int C, int64_t S, float *__restrict__ dst, int sigmoid_first_n) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int64_t s0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int64_t s = s0 + j;
+        const int c = c0 + tx;
+        float v = 0.f;
+        if (c < C && s < S) {
+            const int64_t o = ((int64_t)b * S + s) * src_stride + c;
+            v = dtype == VN_F32 ? static_cast<const float *>(src)[o] : (float)static_cast<const bf16_t *>(src)[o];
+            if (c < sigmoid_first_n) v = 1.0f / (1.0f + expf(-v));
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j;
+        const int64_t s = s0 + tx;
+        if (c < C && s < S) dst[((int64_t)b * C + c) * S + s] = tile[tx][j];
+    }
+}
+
+// 4 channels per thread
+__global__ void __launch_bounds__(256) k_cast_rows(const void *__restrict__ src, int sdt, int64_t sstride, int64_t M,
+                                                   int C, void *__restrict__ dst, int ddt, int64_t dstride, int64_t lo_off) {
+    const int groups = C >> 2;
+    const int64_t total = M * groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / groups;
+        const int c = (int)(i - m * groups) << 2;
+        float v[4];
+        if (sdt == VN_F32) {
+            const float4 t = *reinterpret_cast<const float4 *>(static_cast<const float *>(src) + m * sstride + c);
+            v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+        } else {
+            const bf16x4_t t = *reinterpret_cast<const bf16x4_t *>(static_cast<const bf16_t *>(src) + m * sstride + c);
+            v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+        }
+        if (ddt == VN_F32) {
+            *reinterpret_cast<float4 *>(static_cast<float *>(dst) + m * dstride + c) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            bf16x4_t hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { bf16_t h, l; vn_split_bf16(v[j], h, l); hi[j] = h; lo[j] = l; }
+            bf16_t *d = static_cast<bf16_t *>(dst) + m * dstride + c;
+            *reinterpret_cast<bf16x4_t *>(d) = hi;
+            if (lo_off) *reinterpret_cast<bf16x4_t *>(d + lo_off) = lo;
+        }
+    }
+}
+
+// column sums: thread (cg = tid % groups) walks rows; LDS reduce; float atomics
+__global__ void __launch_bounds__(256) k_col_sums(const void *__restrict__ rows, int dtype, int64_t stride, int64_t M,
+                                                  int C, float *__restrict__ out) {
+    __shared__ float red[256 * 4];
+    const int groups = C >> 2;            // <= 256
+    const int rpb = 256 / groups;         // rows per block iteration
+    const int cg = threadIdx.x % groups, rr = threadIdx.x / groups;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rr < rpb) {
+        for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
+            if (dtype == VN_F32) {
+                const float4 t = *reinterpret_cast<const float4 *>(static_cast<const float *>(rows) + m * stride + cg * 4);
+                s[0] += t.x; s[1] += t.y; s[2] += t.z; s[3] += t.w;
+            } else {
+                const bf16x4_t t = *reinterpret_cast<const bf16x4_t *>(static_cast<const bf16_t *>(rows) + m * stride + cg * 4);
+                s[0] += (float)t[0]; s[1] += (float)t[1]; s[2] += (float)t[2]; s[3] += (float)t[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[threadIdx.x * 4 + j] = s[j];
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rpb; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] += red[(r * groups + threadIdx.x) * 4 + j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(out + threadIdx.x * 4 + j, t[j]);
+    }
+}
+
+// heads backward: NCHW d_prob (B,2,S), d_reg (B,14,S), prob -> rows (B*S, 16)
+__global__ void __launch_bounds__(256) k_heads_bwd(const float *__restrict__ dprob, const float *__restrict__ dreg,
+                                                   const float *__restrict__ prob, int B, int64_t S, void *drows,
+                                                   int64_t stride, int split) {
+    const int64_t total = (int64_t)B * S;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / S, s = i - b * S;
+        bf16_t *d = static_cast<bf16_t *>(drows) + i * stride;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            float v;
+            if (c < 2) {
+                const float pr = prob[(b * 2 + c) * S + s];
+                v = dprob[(b * 2 + c) * S + s] * pr * (1.0f - pr);
+            } else {
+                v = dreg[(b * 14 + (c - 2)) * S + s];
+            }
+            bf16_t h, l;
+            vn_split_bf16(v, h, l);
+            d[c] = h;
+            if (split) d[16 + c] = l;
+        }
+    }
+}
+
+inline unsigned gs_blocks(int64_t total, int per_block = 256, int cap = 8192) {
+    int64_t b = vn_ceil_div(total, per_block);
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" int vn_pack_weight(const float *w, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode, int32_t split3,
+                              int32_t cin_fold, void *packed, vnStream stream) {
+    VN_CHECK_ARG(w && packed && c_out > 0 && c_in > 0 && taps > 0 && mode >= 0 && mode <= 3);
+    VN_CHECK_ARG(cin_fold >= 1 && c_in % cin_fold == 0);
+    const int64_t total = (int64_t)taps * c_out * c_in * (split3 ? 3 : 1);
+    k_pack_weight<<<gs_blocks(total), 256, 0, vn_stream(stream)>>>(w, c_out, c_in, taps, mode, split3, cin_fold,
+                                                                   static_cast<bf16_t *>(packed));
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_unpack_wgrad(const float *dw_packed, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode,
+                               int32_t cin_fold, float *dw, vnStream stream) {
+    VN_CHECK_ARG(dw_packed && dw && c_out > 0 && c_in > 0 && taps > 0 && (mode == 0 || mode == 2));
+    VN_CHECK_ARG(cin_fold >= 1 && c_in % cin_fold == 0);
+    const int64_t total = (int64_t)taps * c_out * c_in;
+    k_unpack_wgrad<<<gs_blocks(total), 256, 0, vn_stream(stream)>>>(dw_packed, c_out, c_in, taps, mode, cin_fold, dw);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_nchw_to_rows(const float *src, int32_t B, int32_t C, int64_t S, void *dst, vnDtype dst_dtype,
+                               int64_t dst_stride, int64_t lo_off, vnStream stream) {
+    VN_CHECK_ARG(src && dst && B > 0 && C > 0 && S > 0 && B <= 65535);
+    VN_CHECK_ARG(lo_off >= 0 && (!lo_off || dst_dtype == VN_BF16));
+    VN_CHECK_ARG(dst_stride >= C);
+    const dim3 grid((unsigned)vn_ceil_div(S, 32), (unsigned)vn_ceil_div(C, 32), (unsigned)B);
+    k_nchw_to_rows<<<grid, 256, 0, vn_stream(stream)>>>(src, C, S, dst, (int)dst_dtype, dst_stride, lo_off);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_rows_to_nchw(const void *src, vnDtype src_dtype, int64_t src_stride, int32_t B, int32_t C, int64_t S,
+                               float *dst, int32_t sigmoid_first_n, vnStream stream) {
+    VN_CHECK_ARG(src && dst && B > 0 && C > 0 && S > 0 && B <= 65535 && src_stride >= C);
+    const dim3 grid((unsigned)vn_ceil_div(S, 32), (unsigned)vn_ceil_div(C, 32), (unsigned)B);
+    k_rows_to_nchw<<<grid, 256, 0, vn_stream(stream)>>>(src, (int)src_dtype, src_stride, C, S, dst, sigmoid_first_n);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_cast_rows(const void *src, vnDtype src_dtype, int64_t src_stride, int64_t M, int32_t C, void *dst,
+                            vnDtype dst_dtype, int64_t dst_stride, int64_t lo_off, vnStream stream) {
+    VN_CHECK_ARG(M >= 0 && C > 0 && (C & 3) == 0 && (src_stride & 3) == 0 && (dst_stride & 3) == 0);
+    VN_CHECK_ARG(lo_off >= 0 && (lo_off & 3) == 0);
+    if (M == 0) return VN_OK;
+    VN_CHECK_ARG(src && dst && (!lo_off || dst_dtype == VN_BF16));
+    k_cast_rows<<<gs_blocks(M * (C >> 2)), 256, 0, vn_stream(stream)>>>(src, (int)src_dtype, src_stride, M, C, dst,
+                                                                        (int)dst_dtype, dst_stride, lo_off);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_col_sums(const void *rows, vnDtype dtype, int64_t stride, int64_t M, int32_t C, float *out,
+                           vnStream stream) {
+    VN_CHECK_ARG(out && M >= 0 && C > 0 && (C & 3) == 0 && C <= 1024 && (stride & 3) == 0);
+    if (M == 0) return VN_OK;
+    VN_CHECK_ARG(rows);
+    const int rpb = 256 / (C >> 2);
+    k_col_sums<<<gs_blocks(M, rpb * 16, 1024), 256, 0, vn_stream(stream)>>>(rows, (int)dtype, stride, M, C, out);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_heads_bwd(const float *d_prob, const float *d_reg, const float *prob, int32_t B, int64_t S,
+                            void *d_rows, int64_t d_stride, int32_t split, vnStream stream) {
+    VN_CHECK_ARG(d_prob && d_reg && prob && d_rows && B > 0 && S > 0 && d_stride >= (split ? 32 : 16));
+    k_heads_bwd<<<gs_blocks((int64_t)B * S), 256, 0, vn_stream(stream)>>>(d_prob, d_reg, prob, B, S, d_rows, d_stride,
+                                                                          split);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}

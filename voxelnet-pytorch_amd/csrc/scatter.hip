@@ -23,7 +23,7 @@ __global__ void __launch_bounds__(256) k_zero(uint4 *__restrict__ p, int64_t n16
 }
 
 // one thread per (row, 4-channel group)
-template <int MODE>  // 0: f32, 1: bf16, 2: bf16 split3 (hi|lo|hi)
+template <int MODE>  // 0: f32, 1: bf16, 2: bf16 split (hi|lo)
 __global__ void __launch_bounds__(256) k_scatter(const float *__restrict__ vw, const int64_t *__restrict__ coord,
                                                  int64_t K, int C, int B, int D, int H, int W, void *__restrict__ dense,
                                                  int dense_channels) {
@@ -46,10 +46,7 @@ __global__ void __launch_bounds__(256) k_scatter(const float *__restrict__ vw, c
         vn_split_bf16(v.z, h, l); hi[2] = h; lo[2] = l;
         vn_split_bf16(v.w, h, l); hi[3] = h; lo[3] = l;
         *reinterpret_cast<bf16x4_t *>(o) = hi;
-        if (MODE == 2) {
-            *reinterpret_cast<bf16x4_t *>(o + C) = lo;
-            *reinterpret_cast<bf16x4_t *>(o + 2 * C) = hi;
-        }
+        if (MODE == 2) *reinterpret_cast<bf16x4_t *>(o + C) = lo;
     }
 }
 
@@ -79,11 +76,11 @@ __global__ void __launch_bounds__(256) k_gather_rows(const void *__restrict__ dd
 
 extern "C" int vn_scatter_dense_fwd(const float *voxelwise, const int64_t *coord, int64_t K, int32_t C, int32_t B,
                                     int32_t D, int32_t H, int32_t W, void *dense, vnDtype dense_dtype,
-                                    int32_t dense_channels, int32_t split3, vnStream stream) {
+                                    int32_t dense_channels, int32_t split, vnStream stream) {
     VN_CHECK_ARG(dense && K >= 0 && C > 0 && (C & 3) == 0 && B > 0 && D > 0 && H > 0 && W > 0);
     VN_CHECK_ARG(K == 0 || (voxelwise && coord));
-    VN_CHECK_ARG(dense_channels == (split3 ? 3 * C : C));
-    VN_CHECK_ARG(!split3 || dense_dtype == VN_BF16);
+    VN_CHECK_ARG(dense_channels == (split ? 2 * C : C));
+    VN_CHECK_ARG(!split || dense_dtype == VN_BF16);
     hipStream_t st = vn_stream(stream);
     const int64_t sites = (int64_t)B * D * H * W;
     const int64_t bytes = sites * dense_channels * (dense_dtype == VN_BF16 ? 2 : 4);
@@ -94,7 +91,7 @@ extern "C" int vn_scatter_dense_fwd(const float *voxelwise, const int64_t *coord
     const unsigned blocks = (unsigned)vn_ceil_div(K * (C >> 2), 256);
     if (dense_dtype == VN_F32)
         k_scatter<0><<<blocks, 256, 0, st>>>(voxelwise, coord, K, C, B, D, H, W, dense, dense_channels);
-    else if (!split3)
+    else if (!split)
         k_scatter<1><<<blocks, 256, 0, st>>>(voxelwise, coord, K, C, B, D, H, W, dense, dense_channels);
     else
         k_scatter<2><<<blocks, 256, 0, st>>>(voxelwise, coord, K, C, B, D, H, W, dense, dense_channels);

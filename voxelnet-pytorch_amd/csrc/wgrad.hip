@@ -1,0 +1,288 @@
+// Weight gradient of the gather-GEMM convolution (autograd of model.py:134-153,
+// 188-193: Conv2d/Conv3d/ConvTranspose2d .weight.grad):
+//
+//   dw[tap][n][k] += sum_m rows[m][n] * src[site(m, tap)][k]
+//
+// The reduction runs over the sites m, which is the SLOW dimension of both
+// operands in memory (channels-last rows), so both MFMA operands need a
+// transposed read.  gfx950 has one: ds_read_b64_tr_b16.  Slabs of 64 sites x
+// {DN, DK} channels are staged row-major in LDS by LDS-DMA (per-lane gathered
+// source rows; invalid rows read zeros through the buffer descriptor's bounds
+// check), and each wave builds its v_mfma_f32_16x16x32_bf16 fragments with two
+// transposed reads per operand tile.
+// Grid: (row chunk, tap, (n,k) tile).  Every workgroup owns a DN x DK fp32 tile
+// of one tap's dw, accumulated over its chunk of sites in registers, and adds it
+// to HBM with fp32 atomics once (atomic bytes ~ dw size x chunks: negligible).
+// A 64-entry row table (site -> source/row byte offsets) is maintained
+// incrementally by wave 0 one stage ahead, so the loaders do no index math.
+#include "common.h"
+
+namespace {
+
+constexpr uint32_t WG_OOB = 0xFFFFF000u;
+constexpr uint32_t WG_MAX_WINDOW = 0xFFFFE000u;
+
+struct WGParams {
+    const char *src;
+    const char *rows;
+    float *dw;
+    int64_t sB, sD, sH, sW;   // src strides, elements
+    int64_t rB, rD, rH, rW;   // rows strides, elements
+    int32_t B, Ds, Hs, Ws, Dr, Hr, Wr;
+    int32_t mulD, mulH, mulW, tmulD, tmulH, tmulW, padD, padH, padW;
+    int32_t kD, kH, kW;
+    int32_t C, N;             // real source / row channels
+    int32_t split;
+    int32_t rows_per_chunk;   // multiple of 64
+    int32_t tiles_k;          // number of DK tiles
+    uint32_t src_bytes, rows_bytes;
+};
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds_wave_base, uint32_t voffset,
+                                          uint32_t soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
+// swizzle of the 16-B chunk index inside a row, as a function of the row, so that the
+// transposed 8-B reads of a 32-lane half hit 32 distinct bank pairs.
+template <int ROW_BYTES>
+__device__ __forceinline__ int chunk_swz(int row) {
+    if (ROW_BYTES == 128) return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
+    return ((row & 3) << 1) | (((row >> 3) & 1) << 3);   // 256-B rows
+}
+
+template <int TN, int TK>   // wave tile in units of 16 channels; 2x2 waves
+__global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
+    constexpr int DN = 32 * TN, DK = 32 * TK;
+    constexpr int RBN = DN * 2, RBK = DK * 2;               // LDS row bytes
+    constexpr int TILE_N = 64 * RBN, TILE_K = 64 * RBK;     // bytes per stage
+    constexpr int STAGE = TILE_N + TILE_K;
+    constexpr int IN = TILE_N / 4096, IK = TILE_K / 4096;   // DMA instructions per wave per stage
+    constexpr int LPR_N = RBN / 16, LPR_K = RBK / 16;       // lanes per row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + 2 * STAGE);   // [2][64][2]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int tile = blockIdx.z;
+    const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+    const int n0 = tn * DN, k0 = tk * DK;
+    const int tap = blockIdx.y;
+    const int td = tap / (p.kH * p.kW), th = (tap / p.kW) % p.kH, tw = tap % p.kW;
+    const int64_t M = (int64_t)p.B * p.Dr * p.Hr * p.Wr;
+    const int64_t rbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
+    if (rbeg >= M) return;
+    int64_t rend = rbeg + p.rows_per_chunk;
+    if (rend > M) rend = M;
+    const int nsteps = (int)((rend - rbeg + 63) >> 6);
+    const int nv = p.split ? 3 : 1;
+    const int nstages = nsteps * nv;
+
+    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)p.src, 0, (int)p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)p.rows, 0, (int)p.rows_bytes, 0x00020000);
+
+    // ---- row table producer state (wave 0: lane <-> row of the current 64-row slab) ----
+    int cb = 0, cd = 0, ch = 0, cw = 0;
+    int64_t cm = rbeg + lane;   // the site this lane tracks
+    int tstep = 0;              // slab index its coordinates stand for
+    if (wave == 0) {
+        int64_t t = cm;
+        cw = (int)(t % p.Wr); t /= p.Wr;
+        ch = (int)(t % p.Hr); t /= p.Hr;
+        cd = (int)(t % p.Dr);
+        cb = (int)(t / p.Dr);
+    }
+    auto table_write = [&](int stage_idx) {
+        // wave 0 only: entry for slab (stage_idx / nv) into tbl[stage_idx & 1]
+        const int step = stage_idx / nv;
+        while (tstep < step) {   // advance by 64 sites
+            cm += 64;
+            cw += 64;
+            while (cw >= p.Wr) {
+                cw -= p.Wr;
+                if (++ch >= p.Hr) { ch = 0; if (++cd >= p.Dr) { cd = 0; ++cb; } }
+            }
+            ++tstep;
+        }
+        uint32_t so = WG_OOB, ro = WG_OOB;
+        if (cm < rend) {
+            const int sd = cd * p.mulD + td * p.tmulD - p.padD;
+            const int sh = ch * p.mulH + th * p.tmulH - p.padH;
+            const int sw = cw * p.mulW + tw * p.tmulW - p.padW;
+            ro = (uint32_t)(((int64_t)cb * p.rB + (int64_t)cd * p.rD + (int64_t)ch * p.rH + (int64_t)cw * p.rW) * 2);
+            if ((unsigned)sd < (unsigned)p.Ds && (unsigned)sh < (unsigned)p.Hs && (unsigned)sw < (unsigned)p.Ws)
+                so = (uint32_t)(((int64_t)cb * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW) * 2);
+        }
+        uint32_t *e = tbl + ((stage_idx & 1) * 64 + lane) * 2;
+        e[0] = so;
+        e[1] = ro;
+    };
+
+    // per-lane DMA geometry: instruction i of this wave covers LDS bytes ((i*4+wave)*1024 .. +1023) of a tile
+    auto stage = [&](int sidx, int buf) {
+        const int v = sidx % nv;   // bf16x3 variant: 0 hi*hi, 1 lo(src)*hi(rows), 2 hi(src)*lo(rows)
+        const uint32_t s_col = (uint32_t)((k0 + (v == 1 ? p.C : 0)) * 2);
+        const uint32_t r_col = (uint32_t)((n0 + (v == 2 ? p.N : 0)) * 2);
+        const uint32_t *t = tbl + (sidx & 1) * 128;
+        char *ln = smem + buf * STAGE + wave * 1024;
+        char *lk = smem + buf * STAGE + TILE_N + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < IN; ++i) {
+            const int r = ((i * 4 + wave) * 1024) / RBN + lane / LPR_N;
+            const int c = (lane % LPR_N) ^ chunk_swz<RBN>(r);
+            const uint32_t ro = t[r * 2 + 1];
+            const bool ok = ro != WG_OOB && (n0 + c * 8) < p.N;
+            lds_dma16(rs_r, ln + i * 4096, ok ? ro + (uint32_t)c * 16u : WG_OOB, r_col);
+        }
+#pragma unroll
+        for (int i = 0; i < IK; ++i) {
+            const int r = ((i * 4 + wave) * 1024) / RBK + lane / LPR_K;
+            const int c = (lane % LPR_K) ^ chunk_swz<RBK>(r);
+            const uint32_t so = t[r * 2];
+            const bool ok = so != WG_OOB && (k0 + c * 8) < p.C;
+            lds_dma16(rs_s, lk + i * 4096, ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
+        }
+    };
+
+    f32x4_t acc[TN][TK];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read lane geometry: lane = 16g + 4q + pp -> row (8g + q [+4]), 8-B piece pp of a 16-column tile
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+
+    if (wave == 0) table_write(0);
+    __syncthreads();
+    stage(0, 0);
+    if (wave == 0 && nstages > 1) table_write(1);
+    for (int s = 0; s < nstages; ++s) {
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nstages) stage(s + 1, buf ^ 1);
+        if (wave == 0 && s + 2 < nstages) table_write(s + 2);
+        const char *ln = smem + buf * STAGE;
+        const char *lk = smem + buf * STAGE + TILE_N;
+        typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int r0 = ks * 32 + g * 8 + q, r1 = r0 + 4;
+            bf16x8_t a[TN], b[TK];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int col = (wn * TN + i) * 16 + pp * 4;          // element column inside the tile
+                const int c16 = col >> 3, half = (col >> 2) & 1;      // 16-B chunk, 8-B half
+                const char *p0 = ln + r0 * RBN + ((c16 ^ chunk_swz<RBN>(r0)) << 4) + half * 8;
+                const char *p1 = ln + r1 * RBN + ((c16 ^ chunk_swz<RBN>(r1)) << 4) + half * 8;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
+                const s16x8_t t8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                a[i] = __builtin_bit_cast(bf16x8_t, t8);
+            }
+#pragma unroll
+            for (int j = 0; j < TK; ++j) {
+                const int col = (wk * TK + j) * 16 + pp * 4;
+                const int c16 = col >> 3, half = (col >> 2) & 1;
+                const char *p0 = lk + r0 * RBK + ((c16 ^ chunk_swz<RBK>(r0)) << 4) + half * 8;
+                const char *p1 = lk + r1 * RBK + ((c16 ^ chunk_swz<RBK>(r1)) << 4) + half * 8;
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
+                const s16x8_t t8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                b[j] = __builtin_bit_cast(bf16x8_t, t8);
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TK; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // D[n][k]: n = (lane>>4)*4 + e, k = lane&15
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+            const int k = k0 + (wk * TK + j) * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + (wn * TN + i) * 16 + (lane >> 4) * 4 + e;
+                if (n < p.N && k < p.C) atomicAdd(p.dw + ((int64_t)tap * p.N + n) * p.C + k, acc[i][j][e]);
+            }
+        }
+}
+
+template <int TN, int TK>
+int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
+    constexpr int DN = 32 * TN, DK = 32 * TK;
+    constexpr size_t lds = 2u * 64u * (DN + DK) * 2u + 2u * 64u * 2u * 4u;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return (int)attr;
+    k_wgrad<TN, TK><<<grid, 256, lds, st>>>(p);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+}  // namespace
+
+extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
+                             vnStream stream) {
+    VN_CHECK_ARG(src && rows && dw_packed && g);
+    VN_CHECK_ARG(g->B > 0 && g->Ds > 0 && g->Hs > 0 && g->Ws > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0);
+    VN_CHECK_ARG(g->kD >= 1 && g->kH >= 1 && g->kW >= 1 && g->kD * g->kH * g->kW <= 65535);
+    if (g->divD != 1 || g->divH != 1 || g->divW != 1) return VN_EUNSUPPORTED;
+    if (g->Cs <= 0 || (g->Cs & 7) || g->Cr <= 0 || (g->Cr & 7)) return VN_EUNSUPPORTED;
+    if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & 7) != 0) return VN_EUNSUPPORTED;
+    if (((g->out_sB | g->out_sD | g->out_sH | g->out_sW) & 7) != 0) return VN_EUNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(rows) & 15)) return VN_EUNSUPPORTED;
+
+    WGParams p{};
+    p.src = static_cast<const char *>(src);
+    p.rows = static_cast<const char *>(rows);
+    p.dw = dw_packed;
+    p.sB = g->src_sB; p.sD = g->src_sD; p.sH = g->src_sH; p.sW = g->src_sW;
+    p.rB = g->out_sB; p.rD = g->out_sD; p.rH = g->out_sH; p.rW = g->out_sW;
+    p.B = g->B; p.Ds = g->Ds; p.Hs = g->Hs; p.Ws = g->Ws; p.Dr = g->Dr; p.Hr = g->Hr; p.Wr = g->Wr;
+    p.mulD = g->mulD; p.mulH = g->mulH; p.mulW = g->mulW;
+    p.tmulD = g->tmulD; p.tmulH = g->tmulH; p.tmulW = g->tmulW;
+    p.padD = g->padD; p.padH = g->padH; p.padW = g->padW;
+    p.kD = g->kD; p.kH = g->kH; p.kW = g->kW;
+    p.C = g->Cs; p.N = g->Cr; p.split = split ? 1 : 0;
+    const int wmul = split ? 2 : 1;
+    const int64_t sbytes = ((int64_t)(g->B - 1) * g->src_sB + (int64_t)(g->Ds - 1) * g->src_sD +
+                            (int64_t)(g->Hs - 1) * g->src_sH + (int64_t)(g->Ws - 1) * g->src_sW + wmul * g->Cs) * 2;
+    const int64_t rbytes = ((int64_t)(g->B - 1) * g->out_sB + (int64_t)(g->Dr - 1) * g->out_sD +
+                            (int64_t)(g->Hr - 1) * g->out_sH + (int64_t)(g->Wr - 1) * g->out_sW + wmul * g->Cr) * 2;
+    if (sbytes > (int64_t)WG_MAX_WINDOW || rbytes > (int64_t)WG_MAX_WINDOW) return VN_EUNSUPPORTED;
+    p.src_bytes = (uint32_t)sbytes;
+    p.rows_bytes = (uint32_t)rbytes;
+
+    const int taps = g->kD * g->kH * g->kW;
+    const bool n128 = g->Cr > 64, k128 = g->Cs > 64;
+    const int DN = n128 ? 128 : 64, DK = k128 ? 128 : 64;
+    const int tiles_n = (int)vn_ceil_div(g->Cr, DN), tiles_k = (int)vn_ceil_div(g->Cs, DK);
+    p.tiles_k = tiles_k;
+    const int64_t M = (int64_t)g->B * g->Dr * g->Hr * g->Wr;
+    // ~2048 workgroups in flight, at least 64 sites each
+    int64_t chunks = 2048 / ((int64_t)taps * tiles_n * tiles_k);
+    if (chunks < 1) chunks = 1;
+    int64_t rpc = vn_ceil_div(vn_ceil_div(M, chunks), 64) * 64;
+    if (rpc < 64) rpc = 64;
+    if (rpc > (1 << 30)) return VN_EUNSUPPORTED;
+    p.rows_per_chunk = (int32_t)rpc;
+    chunks = vn_ceil_div(M, rpc);
+    const dim3 grid((unsigned)chunks, (unsigned)taps, (unsigned)(tiles_n * tiles_k));
+    hipStream_t st = vn_stream(stream);
+    if (n128 && k128) return launch_wgrad<4, 4>(p, grid, st);
+    if (n128) return launch_wgrad<4, 2>(p, grid, st);
+    if (k128) return launch_wgrad<2, 4>(p, grid, st);
+    return launch_wgrad<2, 2>(p, grid, st);
+}

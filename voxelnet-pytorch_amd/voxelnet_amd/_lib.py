@@ -29,9 +29,10 @@ class VnGrid(ctypes.Structure):
 
 class VnConv(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in (
-        "B", "Ds", "Hs", "Ws", "Dr", "Hr", "Wr", "Cs", "Cr", "kD", "kH", "kW",
+        "B", "Ds", "Hs", "Ws", "Dr", "Hr", "Wr", "Cs", "src_wrap", "Cr", "kD", "kH", "kW",
         "mulD", "mulH", "mulW", "tmulD", "tmulH", "tmulW", "padD", "padH", "padW",
-        "divD", "divH", "divW", "src_stride", "out_stride")]
+        "divD", "divH", "divW")] + [(n, c_i64) for n in (
+        "src_sB", "src_sD", "src_sH", "src_sW", "out_sB", "out_sD", "out_sH", "out_sW")]
 
 
 # name -> (restype, argtypes); mirrors include/voxelnet_hip.h one to one
@@ -42,30 +43,29 @@ SIGNATURES = {
     "vn_voxelize_workspace_bytes": (c_sz, [c_i64, _P(VnGrid)]),
     "vn_voxelize_index": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_vp, c_vp]),
     "vn_voxelize_gather": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
-    "vn_vfe_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32, c_i32]),
-    "vn_vfe_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32,
-                           c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "vn_vfe_bwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
-                           c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "vn_vfe_workspace_bytes": (c_sz, [c_i64, c_i32]),
+    "vn_vfe_fwd": (c_i32, [c_vp, c_i64, c_i32, _P(c_vp), c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "vn_vfe_bwd": (c_i32, [c_vp, c_i64, c_i32, _P(c_vp), c_vp, c_vp, _P(c_vp), c_vp, c_sz, c_vp]),
     "vn_scatter_dense_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,
                                      c_i32, c_vp]),
     "vn_scatter_dense_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "vn_conv_gather_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_i32, c_vp]),
+    "vn_conv_gather_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_i32, c_vp, c_vp]),
     "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp]),
-    "vn_pack_weight": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vn_pack_weight": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vn_unpack_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "vn_bn_stats": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp]),
-    "vn_bn_finalize": (c_i32, [c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp]),
-    "vn_bn_apply": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_i32, c_i32,
-                            c_vp]),
-    "vn_bn_bwd_reduce": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32,
-                                 c_vp, c_vp]),
-    "vn_bn_bwd_apply": (c_i32, [c_vp, c_i32, c_i32, c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32,
-                                c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    "vn_nchw_to_nhwc": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    "vn_nhwc_to_nchw": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i64, c_vp, c_i32, c_vp]),
-    "vn_cast_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_i32, c_i32, c_i32, c_vp]),
-    "vn_col_sums": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    "vn_bn_stats": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "vn_bn_finalize": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_vp,
+                               c_vp]),
+    "vn_bn_apply": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
+    "vn_bn_bwd_reduce": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "vn_bn_bwd_finalize": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vn_bn_bwd_apply": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp,
+                                c_i32, c_i64, c_i64, c_vp]),
+    "vn_nchw_to_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_vp]),
+    "vn_rows_to_nchw": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp, c_i32, c_vp]),
+    "vn_cast_rows": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
+    "vn_col_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp]),
+    "vn_heads_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_i32, c_vp]),
 }
 
 _lib = None

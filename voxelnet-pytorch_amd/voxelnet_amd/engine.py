@@ -1,0 +1,321 @@
+"""Layer engine: drives the C-ABI kernels (include/voxelnet_hip.h) for one
+ConvMD / DeConv2d layer, forward and backward, on channels-last rows.
+
+PyTorch supplies device memory (torch.empty), the current HIP stream and nothing
+else; every arithmetic step is a libvoxelnet_hip.so call.  Reference semantics:
+  ConvMD    /root/reference/voxelnet/model.py:111-167  (conv -> BatchNorm -> ReLU)
+  DeConv2d  /root/reference/voxelnet/model.py:170-199  (ConvTranspose2d -> BatchNorm2d -> ReLU)
+
+Precision modes
+  "bf16"  : activations/gradients stored bf16, bf16 MFMA with fp32 accumulation
+            (BASELINE.json configs[1]: "bf16 fwd+bwd").
+  "exact" : bf16x3 — every activation/gradient is stored as [hi|lo] bf16 pairs and
+            every product is a_hi*w_hi + a_lo*w_hi + a_hi*w_lo on the same kernels
+            (fp32-accurate; used for the <=1e-3 parity bar against the fp32 oracle).
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import VN_BF16, VN_F32, VnConv
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dt(t):
+    return VN_F32 if t.dtype == torch.float32 else VN_BF16
+
+
+@dataclass(frozen=True)
+class LayerSpec:
+    """One conv-like layer (model.py:206-254)."""
+    name: str
+    dim: int            # 2 or 3
+    cin: int
+    cout: int
+    k: tuple            # (kD,kH,kW)
+    stride: tuple
+    pad: tuple
+    transposed: bool = False
+    bn: bool = True
+    relu: bool = True
+    cin_fold: int = 1   # 2 for block1.0 (BEV reshape, model.py:262)
+
+    @property
+    def taps(self):
+        return self.k[0] * self.k[1] * self.k[2]
+
+    def out_dims(self, dims):
+        if self.transposed:
+            return tuple((d - 1) * s - 2 * p + k for d, s, p, k in zip(dims, self.stride, self.pad, self.k))
+        return tuple((d + 2 * p - k) // s + 1 for d, s, p, k in zip(dims, self.stride, self.pad, self.k))
+
+
+def spec3(name, cin, cout, k, s, p):
+    return LayerSpec(name, 3, cin, cout, (k, k, k), tuple(s), tuple(p))
+
+
+def spec2(name, cin, cout, k, s, p, **kw):
+    return LayerSpec(name, 2, cin, cout, (1, k, k), (1,) + tuple(s), (0,) + tuple(p), **kw)
+
+
+class Rows:
+    """A channels-last activation or gradient: tensor (B, D, H, W, width), last dim
+    contiguous, other dims arbitrary strides.  `C` real channels; in split layout the
+    bf16 residual sits `lo_off` elements after the hi part (lo_off == 0: plain)."""
+
+    def __init__(self, t, C, lo_off=0):
+        assert t.dim() == 5 and t.stride(4) == 1
+        self.t, self.C, self.lo_off = t, C, lo_off
+
+    @property
+    def dims(self):
+        return tuple(self.t.shape[1:4])
+
+    @property
+    def B(self):
+        return self.t.shape[0]
+
+    @property
+    def strides(self):
+        return tuple(self.t.stride()[:4])
+
+    @property
+    def M(self):
+        s = self.t.shape
+        return s[0] * s[1] * s[2] * s[3]
+
+    def ptr(self):
+        return self.t.data_ptr()
+
+    def row_stride(self):
+        """rows as an (M, width) matrix: only valid when the 4 site dims are jointly contiguous-strided"""
+        st, sh = self.t.stride(), self.t.shape
+        assert st[2] == sh[3] * st[3] and st[1] == sh[2] * st[2] and st[0] == sh[1] * st[1], "not a row matrix"
+        return st[3]
+
+
+def new_rows(B, dims, C, dtype, split, device):
+    width = 2 * C if split else C
+    t = torch.empty((B,) + tuple(dims) + (width,), dtype=dtype, device=device)
+    return Rows(t, C, C if split else 0)
+
+
+def _geom(B, src, row_dims, Cs_eff, src_wrap, Cr, k, mul, tmul, pad, div, out_strides):
+    g = VnConv()
+    g.B = B
+    g.Ds, g.Hs, g.Ws = src.dims
+    g.Dr, g.Hr, g.Wr = row_dims
+    g.Cs, g.src_wrap, g.Cr = Cs_eff, src_wrap, Cr
+    g.kD, g.kH, g.kW = k
+    g.mulD, g.mulH, g.mulW = mul
+    g.tmulD, g.tmulH, g.tmulW = tmul
+    g.padD, g.padH, g.padW = pad
+    g.divD, g.divH, g.divW = div
+    g.src_sB, g.src_sD, g.src_sH, g.src_sW = src.strides
+    g.out_sB, g.out_sD, g.out_sH, g.out_sW = out_strides
+    return g
+
+
+def pack_weight(w, spec, mode, split):
+    """torch parameter -> bf16 [taps][N][K(*3)] operand (vn_pack_weight)."""
+    c_out, c_in = spec.cout, spec.cin
+    N, K = (c_out, c_in) if mode in (0, 2) else (c_in, c_out)
+    packed = torch.empty((spec.taps, N, K * (3 if split else 1)), dtype=torch.bfloat16, device=w.device)
+    _lib.call("vn_pack_weight", w.data_ptr(), c_out, c_in, spec.taps, mode, int(split), spec.cin_fold,
+              packed.data_ptr(), stream())
+    return packed
+
+
+def gather_gemm(src, wp, bias, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dims, accumulate=False, stats=None):
+    """out rows <- gather-GEMM of src rows (vn_conv_gather_gemm)."""
+    split = src.lo_off != 0
+    if split:
+        assert src.lo_off == src.C, "gather source must be [hi|lo] contiguous"
+    g = _geom(src.B, src, row_dims, Cs * (3 if split else 1), 2 * Cs if split else 0, Cr, spec_k, mul, tmul, pad,
+              div, out.strides)
+    _lib.call("vn_conv_gather_gemm", src.ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+              out.ptr(), _dt(out.t), ctypes.byref(g), int(accumulate),
+              stats.data_ptr() if stats is not None else None, stream())
+
+
+class LayerState:
+    """What a layer's backward needs (saved by layer_forward)."""
+    __slots__ = ("spec", "x", "y", "stats", "a", "in_dims", "out_dims")
+
+
+def _bev_slices(B, D):
+    return [(b, d) for b in range(B) for d in range(D)]
+
+
+def layer_forward(spec, x, params, buffers, training, split, out=None, act_dtype=torch.bfloat16, y_dtype=None,
+                  bev_out=False):
+    """x: Rows (input activation).  params: dict weight,bias[,gamma,beta]; buffers: dict
+    running_mean, running_var (updated in place when training).  Returns (a: Rows, state).
+    `out`: optional pre-made Rows for the activation (e.g. a channel slice of the concat)."""
+    dev = x.t.device
+    B = x.B
+    odims = spec.out_dims(x.dims)
+    w, bias = params["weight"], params["bias"]
+    wp = pack_weight(w, spec, 2 if spec.transposed else 0, split)
+    if y_dtype is None:
+        y_dtype = torch.float32 if split else torch.bfloat16
+    y = Rows(torch.empty((B,) + odims + (spec.cout,), dtype=y_dtype, device=dev), spec.cout)
+    fuse_stats = spec.bn and training
+    sums = torch.zeros(2 * spec.cout, dtype=torch.float64, device=dev) if fuse_stats else None
+    if spec.transposed:
+        mul, tmul, pad, div = (1, 1, 1), (-1, -1, -1), tuple(-p for p in spec.pad), spec.stride
+    else:
+        mul, tmul, pad, div = spec.stride, (1, 1, 1), spec.pad, (1, 1, 1)
+    gather_gemm(x, wp, bias, y, spec.k, spec.cin, spec.cout, mul, tmul, pad, div, odims, stats=sums)
+    st = LayerState()
+    st.spec, st.x, st.y, st.in_dims, st.out_dims = spec, x, y, x.dims, odims
+    st.stats, st.a = None, None
+    if not spec.bn:
+        return y, st
+    M = y.M
+    stats = torch.empty(4 * spec.cout, dtype=torch.float32, device=dev)
+    _lib.call("vn_bn_finalize", sums.data_ptr() if sums is not None else None, M, spec.cout, 1, bias.data_ptr(),
+              params["gamma"].data_ptr(), params["beta"].data_ptr(), buffers["running_mean"].data_ptr(),
+              buffers["running_var"].data_ptr(), int(training), BN_MOMENTUM, BN_EPS, stats.data_ptr(), stream())
+    if bev_out:
+        # model.py:262: (B,C,D,H,W).reshape(B,-1,H,W), channel = c*D + d.  Stored here as channel d*C + c
+        # (block1.0's packed weights are permuted to match, LayerSpec.cin_fold).
+        D, H, W = odims
+        Cb = spec.cout * D
+        a = Rows(torch.empty((B, 1, H, W, Cb * (2 if split else 1)), dtype=act_dtype, device=dev), Cb,
+                 Cb if split else 0)
+        for b, d in _bev_slices(B, D):
+            _lib.call("vn_bn_apply", y.t[b, d].data_ptr(), _dt(y.t), spec.cout, H * W, spec.cout, stats.data_ptr(),
+                      int(spec.relu), a.t[b, 0, :, :, d * spec.cout:].data_ptr(), _dt(a.t), a.t.stride(3), a.lo_off,
+                      stream())
+    else:
+        a = out if out is not None else new_rows(B, odims, spec.cout, act_dtype, split, dev)
+        _lib.call("vn_bn_apply", y.ptr(), _dt(y.t), y.row_stride(), M, spec.cout, stats.data_ptr(), int(spec.relu),
+                  a.ptr(), _dt(a.t), a.row_stride(), a.lo_off, stream())
+    st.stats, st.a = stats, a
+    return a, st
+
+
+def layer_backward(st, da, params, split, need_dx=True, dx=None, dx_accumulate=False, bev_da=False):
+    """da: Rows-like gradient w.r.t. the layer output activation (plain rows, f32 or bf16,
+    any row stride) — or, for a layer without BN, w.r.t. the conv output as [hi|lo] Rows.
+    Returns (grads dict, dx Rows or None)."""
+    spec, x, y = st.spec, st.x, st.y
+    dev = y.t.device
+    B, M, C = y.B, y.M, spec.cout
+    grads = {}
+    if spec.bn:
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+        D, H, W = st.out_dims
+        if bev_da:
+            for b, d in _bev_slices(B, D):
+                _lib.call("vn_bn_bwd_reduce", da.t[b, 0, :, :, d * C:].data_ptr(), _dt(da.t), da.t.stride(3),
+                          y.t[b, d].data_ptr(), _dt(y.t), C, H * W, C, st.stats.data_ptr(), int(spec.relu),
+                          sums.data_ptr(), stream())
+        else:
+            _lib.call("vn_bn_bwd_reduce", da.ptr(), _dt(da.t), da.row_stride(), y.ptr(), _dt(y.t), y.row_stride(), M,
+                      C, st.stats.data_ptr(), int(spec.relu), sums.data_ptr(), stream())
+        coef = torch.empty(3 * C, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+        _lib.call("vn_bn_bwd_finalize", sums.data_ptr(), M, C, 1, params["gamma"].data_ptr(), st.stats.data_ptr(),
+                  coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream())
+        dy = new_rows(B, st.out_dims, C, torch.bfloat16, split, dev)
+        if bev_da:
+            for b, d in _bev_slices(B, D):
+                _lib.call("vn_bn_bwd_apply", da.t[b, 0, :, :, d * C:].data_ptr(), _dt(da.t), da.t.stride(3),
+                          y.t[b, d].data_ptr(), _dt(y.t), C, H * W, C, st.stats.data_ptr(), coef.data_ptr(),
+                          int(spec.relu), dy.t[b, d].data_ptr(), VN_BF16, dy.t.stride(3), dy.lo_off, stream())
+        else:
+            _lib.call("vn_bn_bwd_apply", da.ptr(), _dt(da.t), da.row_stride(), y.ptr(), _dt(y.t), y.row_stride(), M,
+                      C, st.stats.data_ptr(), coef.data_ptr(), int(spec.relu), dy.ptr(), VN_BF16, dy.row_stride(),
+                      dy.lo_off, stream())
+        grads["gamma"], grads["beta"] = dgamma, dbeta
+    else:
+        dy = da
+    # bias gradient = column sums of dy (hi + lo parts)
+    width = dy.t.shape[-1]
+    cs = torch.zeros(width, dtype=torch.float32, device=dev)
+    _lib.call("vn_col_sums", dy.ptr(), VN_BF16, dy.row_stride(), M, width, cs.data_ptr(), stream())
+    grads["bias"] = cs[:C] + cs[C:2 * C] if width == 2 * C else cs
+    # weight gradient
+    taps = spec.taps
+    if spec.transposed:
+        # dW[ci][co][k] = sum_i x[i][ci] * dy[i*s - p + k][co]: rows = x sites, gathered = dy
+        dwp = torch.zeros((taps, spec.cin, spec.cout), dtype=torch.float32, device=dev)
+        g = _geom(B, dy, st.in_dims, spec.cout, 0, spec.cin, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1),
+                  x.strides)
+        _lib.call("vn_conv_wgrad", dy.ptr(), x.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), stream())
+        dw = torch.empty_like(params["weight"])
+        _lib.call("vn_unpack_wgrad", dwp.data_ptr(), spec.cin, spec.cout, taps, 0, 1, dw.data_ptr(), stream())
+    else:
+        dwp = torch.zeros((taps, spec.cout, spec.cin), dtype=torch.float32, device=dev)
+        g = _geom(B, x, st.out_dims, spec.cin, 0, spec.cout, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1),
+                  dy.strides)
+        _lib.call("vn_conv_wgrad", x.ptr(), dy.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), stream())
+        dw = torch.empty_like(params["weight"])
+        _lib.call("vn_unpack_wgrad", dwp.data_ptr(), spec.cout, spec.cin, taps, 0, spec.cin_fold, dw.data_ptr(),
+                  stream())
+    grads["weight"] = dw
+    if not need_dx:
+        return grads, None
+    # data gradient: rows = input sites, gathered = dy
+    if dx is None:
+        dx = Rows(torch.empty((B,) + tuple(st.in_dims) + (spec.cin,),
+                              dtype=torch.float32 if split else torch.bfloat16, device=dev), spec.cin)
+    wp = pack_weight(params["weight"], spec, 3 if spec.transposed else 1, split)
+    if spec.transposed:
+        mul, tmul, pad, div = spec.stride, (1, 1, 1), spec.pad, (1, 1, 1)
+    else:
+        mul, tmul, pad, div = (1, 1, 1), (-1, -1, -1), tuple(-p for p in spec.pad), spec.stride
+    gather_gemm(dy, wp, None, dx, spec.k, spec.cout, spec.cin, mul, tmul, pad, div, st.in_dims,
+                accumulate=dx_accumulate)
+    return grads, dx
+
+
+# ---- NC(D)HW fp32 <-> rows (module boundary) -------------------------------------------------
+
+def nchw_to_rows(x, split):
+    """(B,C,*spatial) fp32 -> Rows bf16 ([hi|lo] when split)."""
+    x = x.contiguous().float()
+    B, C = x.shape[:2]
+    sp = tuple(x.shape[2:])
+    dims = (1,) + sp if len(sp) == 2 else sp
+    S = 1
+    for d in sp:
+        S *= d
+    r = new_rows(B, dims, C, torch.bfloat16, split, x.device)
+    _lib.call("vn_nchw_to_rows", x.data_ptr(), B, C, S, r.ptr(), VN_BF16, r.row_stride(), r.lo_off, stream())
+    return r
+
+
+def nchw_to_plain_rows(x, dtype):
+    """(B,C,*spatial) fp32 -> plain Rows of `dtype` (gradients entering layer_backward)."""
+    x = x.contiguous().float()
+    B, C = x.shape[:2]
+    sp = tuple(x.shape[2:])
+    dims = (1,) + sp if len(sp) == 2 else sp
+    S = 1
+    for d in sp:
+        S *= d
+    r = Rows(torch.empty((B,) + dims + (C,), dtype=dtype, device=x.device), C)
+    _lib.call("vn_nchw_to_rows", x.data_ptr(), B, C, S, r.ptr(), _dt(r.t), r.row_stride(), 0, stream())
+    return r
+
+
+def rows_to_nchw(r, dim, sigmoid_first_n=0):
+    B, C = r.B, r.C
+    D, H, W = r.dims
+    out_shape = (B, C, D, H, W) if dim == 3 else (B, C, H, W)
+    out = torch.empty(out_shape, dtype=torch.float32, device=r.t.device)
+    _lib.call("vn_rows_to_nchw", r.ptr(), _dt(r.t), r.row_stride(), B, C, D * H * W, out.data_ptr(),
+              sigmoid_first_n, stream())
+    return out
