@@ -75,34 +75,34 @@ int vn_voxelize_gather(const float *points, int64_t n_points, const vnGrid *grid
                        int64_t *number /*[K]*/, vnStream stream);
 
 /* ------------------------------------------------------------------------
- * VFE layer — model.py:60-82 (VFELayer.forward), train- or eval-mode BN.
- *   p   = BN1d(ReLU(x W^T + b))        stats over all K*T rows (padded too)
- *   out = cat[p, max_T p] * mask       mask = max_c(x0) != 0 (model.py:95-96)
- * `x0` is the raw (K,T,7) feature buffer the mask derives from; `x` is this
- * layer's input (K,T,cin) (x == x0 for vfe_1).  cin in {7,32}, cout/2 in {16,64}.
- * stats: [mean(c), invstd(c)] saved for backward.  If voxelwise != NULL the
- * max over T of `out` (model.py:100) is also written, (K, 2c).
- * `out` may be NULL when only voxelwise is wanted.
+ * Voxel feature encoder — FeatureLearningNet.forward up to the scatter
+ * (model.py:93-100) incl. both VFELayer.forward calls (model.py:74-82):
+ *   mask = max_c(x) != 0 ; h1 = relu(x W1^T + b1) ; p1 = BN1d(h1) over all K*T rows
+ *   out1 = [p1, max_T p1] * mask ; h2 = relu(out1 W2^T + b2) ; p2 = BN1d(h2)
+ *   out2 = [p2, max_T p2] * mask ; voxelwise = max_T out2            (K,128)
+ * Shapes are the reference's: W1 (16,7), W2 (64,32), T <= 64.
+ * Train mode uses batch statistics (biased variance) and updates the running
+ * statistics (momentum, unbiased variance) exactly like nn.BatchNorm1d.
+ * stats (320 floats: [mean|invstd|gamma*invstd|beta] of BN1 then BN2) is saved
+ * for the backward.  Deterministic (fixed-order slab reductions, no float atomics).
  * ---------------------------------------------------------------------- */
-size_t vn_vfe_workspace_bytes(int64_t K, int32_t T, int32_t cin, int32_t c);
+typedef struct {
+    const float *w1, *b1, *g1, *be1; float *rm1, *rv1;   /* vfe_1: fcn.0.weight/bias, bn.weight/bias, running stats */
+    const float *w2, *b2, *g2, *be2; float *rm2, *rv2;   /* vfe_2 */
+} vnVfeWeights;
+typedef struct {
+    float *dw1, *db1, *dg1, *dbe1, *dw2, *db2, *dg2, *dbe2;   /* overwritten */
+} vnVfeGrads;
 
-int vn_vfe_fwd(const float *x0, const float *x, int64_t K, int32_t T, int32_t cin,
-               int32_t c, const float *weight /*[c,cin]*/, const float *bias,
-               const float *gamma, const float *beta, float *running_mean,
-               float *running_var, int32_t training, float momentum, float eps,
-               float *out /*[K,T,2c] or NULL*/, float *voxelwise /*[K,2c] or NULL*/,
-               float *stats /*[2c]*/, void *workspace, size_t workspace_bytes,
-               vnStream stream);
-
-/* Backward of the above (train mode).  d_out (K,T,2c) and/or d_voxelwise (K,2c)
- * are the upstream gradients (either may be NULL).  Produces d_weight, d_bias,
- * d_gamma, d_beta (overwritten) and, if d_x != NULL, d_x (K,T,cin). */
-int vn_vfe_bwd(const float *x0, const float *x, int64_t K, int32_t T, int32_t cin,
-               int32_t c, const float *weight, const float *bias, const float *gamma,
-               const float *beta, const float *stats, const float *d_out,
-               const float *d_voxelwise, float *d_x, float *d_weight, float *d_bias,
-               float *d_gamma, float *d_beta, void *workspace, size_t workspace_bytes,
-               vnStream stream);
+size_t vn_vfe_workspace_bytes(int64_t K, int32_t T);
+int vn_vfe_fwd(const float *feature /*[K,T,7]*/, int64_t K, int32_t T, const vnVfeWeights *w,
+               int32_t training, float momentum, float eps, float *voxelwise /*[K,128]*/,
+               float *stats /*[320]*/, void *workspace, size_t workspace_bytes, vnStream stream);
+/* gradients of all eight parameter tensors for upstream d_voxelwise (K,128); the input
+ * features are leaf data (no d_feature).  `workspace` need not be the forward's. */
+int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, const float *stats,
+               const float *d_voxelwise, const vnVfeGrads *g, void *workspace,
+               size_t workspace_bytes, vnStream stream);
 
 /* ------------------------------------------------------------------------
  * Sparse -> dense scatter — model.py:102-106 (sparse COO .to_dense()).

@@ -35,6 +35,14 @@ class VnConv(ctypes.Structure):
         "src_sB", "src_sD", "src_sH", "src_sW", "out_sB", "out_sD", "out_sH", "out_sW")]
 
 
+class VnVfeWeights(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("w1", "b1", "g1", "be1", "rm1", "rv1", "w2", "b2", "g2", "be2", "rm2", "rv2")]
+
+
+class VnVfeGrads(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("dw1", "db1", "dg1", "dbe1", "dw2", "db2", "dg2", "dbe2")]
+
+
 # name -> (restype, argtypes); mirrors include/voxelnet_hip.h one to one
 _P = ctypes.POINTER
 SIGNATURES = {
@@ -44,8 +52,8 @@ SIGNATURES = {
     "vn_voxelize_index": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_vp, c_vp]),
     "vn_voxelize_gather": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "vn_vfe_workspace_bytes": (c_sz, [c_i64, c_i32]),
-    "vn_vfe_fwd": (c_i32, [c_vp, c_i64, c_i32, _P(c_vp), c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "vn_vfe_bwd": (c_i32, [c_vp, c_i64, c_i32, _P(c_vp), c_vp, c_vp, _P(c_vp), c_vp, c_sz, c_vp]),
+    "vn_vfe_fwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "vn_vfe_bwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_vp, c_vp, _P(VnVfeGrads), c_vp, c_sz, c_vp]),
     "vn_scatter_dense_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,
                                      c_i32, c_vp]),
     "vn_scatter_dense_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

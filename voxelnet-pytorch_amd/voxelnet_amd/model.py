@@ -1,0 +1,485 @@
+"""nn.Module surface of the reference's hot path, backed by libvoxelnet_hip.so.
+
+Same class names, constructor arguments, attribute names (=> state_dict keys) and
+forward signatures as /root/reference/voxelnet/model.py:
+  VFELayer            model.py:60-82     (parameter container; see note)
+  FeatureLearningNet  model.py:85-108
+  ConvMD              model.py:111-167
+  DeConv2d            model.py:170-199
+  MiddleConvNet       model.py:202-281
+  RPN3D               model.py:284-362   (forward + loss; predict/NMS are out of scope)
+so `model(data, device); loss.backward(); clip_grad_norm_; SGD.step()` (train.py:148-155)
+runs unchanged.  The nn.Linear / nn.Conv* / nn.BatchNorm* sub-modules only HOLD the
+parameters and buffers (identical init and state_dict keys); their ATen forwards are
+never called — every forward/backward goes through the C ABI via the
+torch.autograd.Functions below.  There is no CPU path: CPU tensors raise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from . import engine as E
+from . import net as N
+from .config import ALPHA, BETA, SIGMA, grid_config
+from .engine import Rows
+
+_PRECISION = {"mode": "bf16"}
+
+
+def set_precision(mode):
+    """'bf16' (bf16 storage + MFMA, BASELINE configs[1]) or 'exact' (bf16x3, fp32-accurate)."""
+    if mode not in ("bf16", "exact"):
+        raise ValueError(mode)
+    _PRECISION["mode"] = mode
+
+
+def get_precision():
+    return _PRECISION["mode"]
+
+
+def _split():
+    return _PRECISION["mode"] == "exact"
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.VoxelnetHipError("voxelnet_amd modules need CUDA(HIP) tensors; there is no CPU path")
+
+
+def _act_to_nchw(a, dim):
+    out = E.rows_to_nchw(Rows(a.t[..., :a.C], a.C), dim)
+    if a.lo_off:
+        out = out + E.rows_to_nchw(Rows(a.t[..., a.lo_off:a.lo_off + a.C], a.C), dim)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# single layers (ConvMD / DeConv2d)
+# ---------------------------------------------------------------------------------------------
+class _LayerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, spec, bn_mod, training):
+        _need_cuda(x, weight)
+        split = _split()
+        with torch.cuda.device(x.device):
+            xr = E.nchw_to_rows(x, split)
+            P = {"weight": weight.detach(), "bias": bias.detach(),
+                 "gamma": gamma.detach() if gamma is not None else None,
+                 "beta": beta.detach() if beta is not None else None}
+            Bf = None
+            if spec.bn:
+                Bf = {"running_mean": bn_mod.running_mean, "running_var": bn_mod.running_var}
+            a, st = E.layer_forward(spec, xr, P, Bf, training, split, y_dtype=None if spec.bn else torch.float32)
+            out = _act_to_nchw(a, spec.dim) if spec.bn else E.rows_to_nchw(a, spec.dim)
+        ctx.st, ctx.P, ctx.split, ctx.spec = st, P, split, spec
+        ctx.need_dx = x.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        spec, split = ctx.spec, ctx.split
+        with torch.cuda.device(dout.device):
+            if spec.bn:
+                da = E.nchw_to_plain_rows(dout, torch.float32 if split else torch.bfloat16)
+            else:
+                da = E.nchw_to_rows(dout, split)
+            grads, dx = E.layer_backward(ctx.st, da, ctx.P, split, need_dx=ctx.need_dx)
+            dxn = E.rows_to_nchw(dx, spec.dim) if dx is not None else None
+        return dxn, grads["weight"], grads["bias"], grads.get("gamma"), grads.get("beta"), None, None, None
+
+
+def _tup(v, n):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v,) * n
+
+
+class ConvMD(nn.Module):
+    """model.py:111-167."""
+
+    def __init__(self, input_dim, cin, cout, kernel_size, stride, padding, bn=True, activation=True):
+        super().__init__()
+        self.input_dim, self.cin, self.cout = input_dim, cin, cout
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.bn, self.activation = bn, activation
+        if input_dim == 2:
+            self.conv = nn.Conv2d(cin, cout, kernel_size, stride, padding)
+            if bn:
+                self.batch_norm = nn.BatchNorm2d(cout)
+        elif input_dim == 3:
+            self.conv = nn.Conv3d(cin, cout, kernel_size, stride, padding)
+            if bn:
+                self.batch_norm = nn.BatchNorm3d(cout)
+        else:
+            raise ValueError("Choose between 2D and 3D input.")    # model.py:156
+        if bn != activation:
+            raise _lib.VoxelnetHipError("ConvMD: only bn==activation variants exist in the reference network")
+        k, s, p = _tup(kernel_size, input_dim), _tup(stride, input_dim), _tup(padding, input_dim)
+        if input_dim == 2:
+            k, s, p = (1,) + k, (1,) + s, (0,) + p
+        self._spec = E.LayerSpec("ConvMD", input_dim, cin, cout, k, s, p, bn=bn, relu=activation)
+
+    def forward(self, x):
+        bnm = self.batch_norm if self.bn else None
+        out = _LayerFn.apply(x, self.conv.weight, self.conv.bias, bnm.weight if bnm is not None else None,
+                             bnm.bias if bnm is not None else None, self._spec, bnm, self.training)
+        if bnm is not None and self.training:
+            bnm.num_batches_tracked += 1
+        return out
+
+
+class DeConv2d(nn.Module):
+    """model.py:170-199."""
+
+    def __init__(self, cin, cout, kernel_size, stride, padding, bn=True):
+        super().__init__()
+        self.cin, self.cout, self.kernel_size, self.stride, self.padding, self.bn = \
+            cin, cout, kernel_size, stride, padding, bn
+        self.deconv = nn.ConvTranspose2d(cin, cout, kernel_size, stride, padding)
+        if bn:
+            self.batch_norm = nn.BatchNorm2d(cout)
+        else:
+            raise _lib.VoxelnetHipError("DeConv2d without BatchNorm does not occur in the reference network")
+        k, s, p = _tup(kernel_size, 2), _tup(stride, 2), _tup(padding, 2)
+        self._spec = E.LayerSpec("DeConv2d", 2, cin, cout, (1,) + k, (1,) + s, (0,) + p, transposed=True)
+
+    def forward(self, x):
+        out = _LayerFn.apply(x, self.deconv.weight, self.deconv.bias, self.batch_norm.weight, self.batch_norm.bias,
+                             self._spec, self.batch_norm, self.training)
+        if self.training:
+            self.batch_norm.num_batches_tracked += 1
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# feature net (VFE x2 + voxel-wise max + sparse->dense)
+# ---------------------------------------------------------------------------------------------
+class VFELayer(nn.Module):
+    """model.py:60-82.  Holds fcn (Linear+ReLU) and bn exactly like the reference; the
+    arithmetic of both VFE layers runs fused inside FeatureLearningNet (csrc/vfe.hip)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.in_channels, self.out_channels, self.local_agg_features = cin, cout, cout // 2
+        self.fcn = nn.Sequential(nn.Linear(cin, cout // 2), nn.ReLU())
+        self.bn = nn.BatchNorm1d(cout // 2)
+
+    def forward(self, inputs, mask):
+        raise _lib.VoxelnetHipError(
+            "VFELayer runs fused inside FeatureLearningNet.forward on the HIP path (no standalone kernel)")
+
+
+def _vfe_weights(fn):
+    v1, v2 = fn.vfe_1, fn.vfe_2
+    return [v1.fcn[0].weight, v1.fcn[0].bias, v1.bn.weight, v1.bn.bias,
+            v2.fcn[0].weight, v2.fcn[0].bias, v2.bn.weight, v2.bn.bias]
+
+
+def featnet_forward(feature, params, bufs, training):
+    """feature (K,T,7) f32 cuda; params = [w1,b1,g1,be1,w2,b2,g2,be2]; bufs = [rm1,rv1,rm2,rv2].
+    -> voxelwise (K,128) f32, stats, saved handle."""
+    K, T = feature.shape[0], feature.shape[1]
+    dev = feature.device
+    w = _lib.VnVfeWeights(params[0].data_ptr(), params[1].data_ptr(), params[2].data_ptr(), params[3].data_ptr(),
+                          bufs[0].data_ptr(), bufs[1].data_ptr(), params[4].data_ptr(), params[5].data_ptr(),
+                          params[6].data_ptr(), params[7].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr())
+    ws_bytes = _lib.load().vn_vfe_workspace_bytes(K, T)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    vw = torch.empty((K, 128), dtype=torch.float32, device=dev)
+    stats = torch.empty(320, dtype=torch.float32, device=dev)
+    _lib.call("vn_vfe_fwd", feature.data_ptr(), K, T, ctypes.byref(w), int(training), E.BN_MOMENTUM, E.BN_EPS,
+              vw.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws_bytes, E.stream())
+    return vw, stats, (w, ws, ws_bytes)
+
+
+def featnet_backward(feature, wstruct, stats, d_vw, params):
+    w, ws, ws_bytes = wstruct
+    K, T = feature.shape[0], feature.shape[1]
+    grads = [torch.empty_like(p) for p in params]
+    g = _lib.VnVfeGrads(*[t.data_ptr() for t in grads])
+    d_vw = d_vw.contiguous()
+    _lib.call("vn_vfe_bwd", feature.data_ptr(), K, T, ctypes.byref(w), stats.data_ptr(), d_vw.data_ptr(),
+              ctypes.byref(g), ws.data_ptr(), ws_bytes, E.stream())
+    return grads
+
+
+def scatter_rows(vw, coord, B, dims, split):
+    """model.py:102-106 -> dense Rows (bf16, [hi|lo] when split)"""
+    D, H, W = dims
+    K, C = vw.shape
+    ch = 2 * C if split else C
+    dense = torch.empty((B, D, H, W, ch), dtype=torch.bfloat16, device=vw.device)
+    _lib.call("vn_scatter_dense_fwd", vw.data_ptr(), coord.data_ptr(), K, C, B, D, H, W, dense.data_ptr(),
+              _lib.VN_BF16, ch, int(split), E.stream())
+    return Rows(dense, C, C if split else 0)
+
+
+def gather_rows(d_dense, coord, K, C):
+    """backward of the scatter: rows of d_dense (plain f32/bf16 Rows) at coord -> (K,C) f32"""
+    B = d_dense.B
+    D, H, W = d_dense.dims
+    out = torch.empty((K, C), dtype=torch.float32, device=coord.device)
+    _lib.call("vn_scatter_dense_bwd", d_dense.ptr(), E._dt(d_dense.t), coord.data_ptr(), K, C, B, D, H, W,
+              out.data_ptr(), E.stream())
+    return out
+
+
+class _FeatureNetFn(torch.autograd.Function):
+    """FeatureLearningNet.forward with the fp32 dense output of the reference (module boundary)."""
+
+    @staticmethod
+    def forward(ctx, feature, coord, B, dims, training, bufs, *params):
+        _need_cuda(feature, coord)
+        params = [p.detach() for p in params]
+        with torch.cuda.device(feature.device):
+            vw, stats, wst = featnet_forward(feature, params, bufs, training)
+            D, H, W = dims
+            dense = torch.empty((B, D, H, W, 128), dtype=torch.float32, device=feature.device)
+            _lib.call("vn_scatter_dense_fwd", vw.data_ptr(), coord.data_ptr(), vw.shape[0], 128, B, D, H, W,
+                      dense.data_ptr(), _lib.VN_F32, 128, 0, E.stream())
+        ctx.saved = (feature, coord, stats, wst, params)
+        return dense
+
+    @staticmethod
+    def backward(ctx, d_dense):
+        feature, coord, stats, wst, params = ctx.saved
+        with torch.cuda.device(d_dense.device):
+            d_vw = gather_rows(Rows(d_dense.contiguous(), 128), coord, feature.shape[0], 128)
+            grads = featnet_backward(feature, wst, stats, d_vw, params)
+        return (None, None, None, None, None, None) + tuple(grads)
+
+
+class FeatureLearningNet(nn.Module):
+    """model.py:85-108.  forward(feature: list[(K_i,T,7)], coordinate: list[(K_i,4)]) -> (B,D,H,W,128)."""
+
+    def __init__(self, cls_name="Car"):
+        super().__init__()
+        self.vfe_1 = VFELayer(7, 32)
+        self.vfe_2 = VFELayer(32, 128)
+        self._grid = grid_config(cls_name)
+
+    def _bufs(self):
+        return [self.vfe_1.bn.running_mean, self.vfe_1.bn.running_var, self.vfe_2.bn.running_mean,
+                self.vfe_2.bn.running_var]
+
+    def _tick(self):
+        if self.training:
+            self.vfe_1.bn.num_batches_tracked += 1
+            self.vfe_2.bn.num_batches_tracked += 1
+
+    def forward(self, feature, coordinate):
+        bs = len(feature)
+        feature = torch.cat(list(feature), dim=0).contiguous().float()
+        coordinate = torch.cat(list(coordinate), dim=0).contiguous().long()
+        out = _FeatureNetFn.apply(feature, coordinate, bs, self._grid.dims, self.training, self._bufs(),
+                                  *_vfe_weights(self))
+        self._tick()
+        return out
+
+
+# ---------------------------------------------------------------------------------------------
+# middle layers + RPN
+# ---------------------------------------------------------------------------------------------
+def _collect_middle(mod):
+    """-> (names, P, Bf, flat parameter list) in net.layer_table order, + heads"""
+    names, P, Bf, flat = [], {}, {}, []
+    for name, spec in N.layer_table(mod._block1_stride):
+        blk, _, idx = name.partition(".")
+        m = getattr(mod, blk)
+        if idx:
+            m = m[int(idx)]
+        conv = m.deconv if spec.transposed else m.conv
+        bn = m.batch_norm
+        P[name] = {"weight": conv.weight, "bias": conv.bias, "gamma": bn.weight, "beta": bn.bias}
+        Bf[name] = {"running_mean": bn.running_mean, "running_var": bn.running_var}
+        names.append(name)
+        flat += [conv.weight, conv.bias, bn.weight, bn.bias]
+    flat += [mod.prob_conv.conv.weight, mod.prob_conv.conv.bias, mod.reg_conv.conv.weight, mod.reg_conv.conv.bias]
+    return names, P, Bf, flat
+
+
+def _heads_params(flat):
+    pw, pb, rw, rb = flat[-4:]
+    return {"weight": torch.cat([pw, rw], 0).contiguous(), "bias": torch.cat([pb, rb], 0).contiguous()}
+
+
+def _middle_grads_flat(names, G):
+    out = []
+    for n in names:
+        g = G[n]
+        out += [g["weight"], g["bias"], g["gamma"], g["beta"]]
+    hw, hb = G["heads"]["weight"], G["heads"]["bias"]
+    out += [hw[:2].contiguous(), hb[:2].contiguous(), hw[2:].contiguous(), hb[2:].contiguous()]
+    return out
+
+
+def _detached(P):
+    return {k: {kk: vv.detach() for kk, vv in v.items()} for k, v in P.items()}
+
+
+class _MiddleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, training, *flat):
+        _need_cuda(x)
+        split = _split()
+        names, P, Bf, _ = _collect_middle(mod)
+        P = _detached(P)
+        P["heads"] = _heads_params([f.detach() for f in flat])
+        with torch.cuda.device(x.device):
+            B, D, H, W, C = x.shape
+            dense = E.new_rows(B, (D, H, W), 128, torch.bfloat16, split, x.device)
+            xc = x.contiguous().float()
+            _lib.call("vn_cast_rows", xc.data_ptr(), _lib.VN_F32, 128, B * D * H * W, 128, dense.ptr(), _lib.VN_BF16,
+                      dense.t.shape[-1], dense.lo_off, E.stream())
+            prob, reg, st = N.middle_forward(dense, P, Bf, mod._block1_stride, training, split)
+        ctx.st, ctx.P, ctx.names = st, P, names
+        ctx.need_dx = x.requires_grad
+        return prob, reg
+
+    @staticmethod
+    def backward(ctx, d_prob, d_reg):
+        with torch.cuda.device(d_prob.device):
+            G, d_dense = N.middle_backward(ctx.st, d_prob.float(), d_reg.float(), ctx.P, need_dx=ctx.need_dx)
+            dx = None
+            if d_dense is not None:
+                dx = d_dense.t if d_dense.t.dtype == torch.float32 else d_dense.t.float()
+        return (dx, None, None) + tuple(_middle_grads_flat(ctx.names, G))
+
+
+class MiddleConvNet(nn.Module):
+    """model.py:202-281.  forward(x (B,D,H,W,128)) -> (sigmoid(probs) (B,2,h,w), reg (B,14,h,w))."""
+
+    def __init__(self, cls_name="Car"):
+        super().__init__()
+        g = grid_config(cls_name)
+        self._block1_stride = g.block1_stride
+        self.middle_layer = nn.Sequential(
+            ConvMD(3, 128, 64, 3, (2, 1, 1), (1, 1, 1)),
+            ConvMD(3, 64, 64, 3, (1, 1, 1), (0, 1, 1)),
+            ConvMD(3, 64, 64, 3, (2, 1, 1), (1, 1, 1)))
+        s1 = (g.block1_stride, g.block1_stride)                    # model.py:212-227
+        self.block1 = nn.Sequential(ConvMD(2, 128, 128, 3, s1, (1, 1)),
+                                    *[ConvMD(2, 128, 128, 3, (1, 1), (1, 1)) for _ in range(4)])
+        self.deconv1 = DeConv2d(128, 256, 3, (1, 1), (1, 1))
+        self.block2 = nn.Sequential(ConvMD(2, 128, 128, 3, (2, 2), (1, 1)),
+                                    *[ConvMD(2, 128, 128, 3, (1, 1), (1, 1)) for _ in range(5)])
+        self.deconv2 = DeConv2d(128, 256, 2, (2, 2), (0, 0))
+        self.block3 = nn.Sequential(ConvMD(2, 128, 256, 3, (2, 2), (1, 1)),
+                                    *[ConvMD(2, 256, 256, 3, (1, 1), (1, 1)) for _ in range(5)])
+        self.deconv3 = DeConv2d(256, 256, 4, (4, 4), (0, 0))
+        self.prob_conv = ConvMD(2, 768, 2, 1, (1, 1), (0, 0), bn=False, activation=False)
+        self.reg_conv = ConvMD(2, 768, 14, 1, (1, 1), (0, 0), bn=False, activation=False)
+        # config.py FEATURE_HEIGHT/WIDTH: car 200x176; ped/cyc 100x120 (although the network emits 200x240,
+        # SURVEY.md §8a a8 — kept as the reference has it)
+        self.output_shape = [g.H // 2, g.W // 2]
+
+    def _tick(self):
+        if self.training:
+            for m in self.modules():
+                if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
+                    m.num_batches_tracked += 1
+
+    def forward(self, x):
+        _, _, _, flat = _collect_middle(self)
+        prob, reg = _MiddleFn.apply(x, self, self.training, *flat)
+        self._tick()
+        return prob, reg
+
+
+class _DetectorFn(torch.autograd.Function):
+    """feature_net + middle_rpn fused: the dense grid is written once, directly in the conv
+    kernels' bf16 / [hi|lo] row format, and never exists as an fp32 NDHWC tensor."""
+
+    @staticmethod
+    def forward(ctx, feature, coord, B, rpn, training, *flat):
+        _need_cuda(feature, coord)
+        split = _split()
+        fn, mid = rpn.feature_net, rpn.middle_rpn
+        nv = 8
+        vparams = [p.detach() for p in flat[:nv]]
+        names, P, Bf, _ = _collect_middle(mid)
+        P = _detached(P)
+        P["heads"] = _heads_params([f.detach() for f in flat[nv:]])
+        with torch.cuda.device(feature.device):
+            vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
+            dense = scatter_rows(vw, coord, B, fn._grid.dims, split)
+            prob, reg, st = N.middle_forward(dense, P, Bf, mid._block1_stride, training, split)
+        ctx.saved = (feature, coord, stats, wst, vparams, st, P, names)
+        return prob, reg
+
+    @staticmethod
+    def backward(ctx, d_prob, d_reg):
+        feature, coord, stats, wst, vparams, st, P, names = ctx.saved
+        with torch.cuda.device(d_prob.device):
+            G, d_dense = N.middle_backward(st, d_prob.float(), d_reg.float(), P, need_dx=True)
+            d_vw = gather_rows(d_dense, coord, feature.shape[0], 128)
+            vg = featnet_backward(feature, wst, stats, d_vw, vparams)
+        return (None, None, None, None, None) + tuple(vg) + tuple(_middle_grads_flat(names, G))
+
+
+def smooth_L1_loss(deltas, targets, sigma=3.0):
+    """loss.py:3-13, quirk included (option1 * option2, loss.py:9)."""
+    sigma2 = sigma * sigma
+    diffs = deltas - targets
+    smooth_l1_signs = torch.lt(torch.abs(diffs), 1.0 / sigma2).float()
+    option1 = torch.mul(diffs, diffs) * 0.5 * sigma2
+    option2 = torch.abs(diffs) - 0.5 / sigma2
+    return torch.mul(option1, option2) + torch.mul(option2, 1 - smooth_l1_signs)
+
+
+class RPN3D(nn.Module):
+    """model.py:284-362.  forward(x: 7-tuple batch, device) -> 7-tuple like the reference.
+    Targets: pass `targets=(pos_equal_one, neg_equal_one, targets)` (channels-last arrays as
+    utils.generate_targets returns them, model.py:309) or set `target_fn`; CPU target
+    generation itself is outside this path."""
+
+    def __init__(self, cls_name="Car", alpha=ALPHA, beta=BETA, sigma=SIGMA):
+        super().__init__()
+        self.cls_name, self.alpha, self.beta, self.sigma = cls_name, alpha, beta, sigma
+        self.feature_net = FeatureLearningNet(cls_name)
+        self.middle_rpn = MiddleConvNet(cls_name)
+        self.rpn_output_shape = self.middle_rpn.output_shape
+        self.target_fn = None    # callable(label, rpn_output_shape) -> (pos, neg, targets)
+
+    def detect(self, voxel_features, voxel_coordinates):
+        """feature_net + middle_rpn (model.py:305-306), fused."""
+        bs = len(voxel_features)
+        feature = torch.cat(list(voxel_features), dim=0).contiguous().float()
+        coord = torch.cat(list(voxel_coordinates), dim=0).contiguous().long()
+        flat = _vfe_weights(self.feature_net) + _collect_middle(self.middle_rpn)[3]
+        prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, *flat)
+        self.feature_net._tick()
+        self.middle_rpn._tick()
+        return prob, reg
+
+    def loss(self, prob_out, delta_out, pos_equal_one, neg_equal_one, targets):
+        """model.py:310-352 on device (elementwise + reductions through PyTorch-ROCm ops)."""
+        dev = prob_out.device
+
+        def f32(a):
+            return (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev).float()
+        pos, neg, tgt = f32(pos_equal_one), f32(neg_equal_one), f32(targets)
+        pos_reg = torch.cat([pos[..., [0]].expand(-1, -1, -1, 7), pos[..., [1]].expand(-1, -1, -1, 7)], -1)
+        pos_sum = pos.sum(dim=(1, 2, 3)).reshape(-1, 1, 1, 1).clamp(min=1)
+        neg_sum = neg.sum(dim=(1, 2, 3)).reshape(-1, 1, 1, 1).clamp(min=1)
+        pos_c, neg_c = pos.permute(0, 3, 1, 2), neg.permute(0, 3, 1, 2)
+        tgt_c, posr_c = tgt.permute(0, 3, 1, 2), pos_reg.permute(0, 3, 1, 2)
+        cls_pos_loss = (-pos_c * torch.log(prob_out + 1e-6)) / pos_sum
+        cls_neg_loss = (-neg_c * torch.log(1 - prob_out + 1e-6)) / neg_sum
+        cls_loss = torch.sum(self.alpha * cls_pos_loss + self.beta * cls_neg_loss)
+        reg_loss = torch.sum(smooth_L1_loss(delta_out * posr_c, tgt_c * posr_c, self.sigma) / pos_sum)
+        return cls_loss + reg_loss, cls_loss, reg_loss, torch.sum(cls_pos_loss), torch.sum(cls_neg_loss)
+
+    def forward(self, x, device, targets=None):
+        label, voxel_features, voxel_coordinates = x[1], x[2], x[4]
+        voxel_features = [f.to(device) for f in voxel_features]          # model.py:302-303
+        voxel_coordinates = [c.to(device) for c in voxel_coordinates]
+        prob_out, delta_out = self.detect(voxel_features, voxel_coordinates)
+        if targets is None:
+            if self.target_fn is None:
+                raise _lib.VoxelnetHipError("RPN3D.forward needs targets=(pos,neg,targets) or a target_fn")
+            targets = self.target_fn(label, self.rpn_output_shape)
+        loss, cls_loss, reg_loss, cpos, cneg = self.loss(prob_out, delta_out, *targets)
+        return prob_out, delta_out, loss, cls_loss, reg_loss, cpos, cneg
