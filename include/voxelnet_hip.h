@@ -143,10 +143,12 @@ int vn_scatter_dense_bwd(const void *d_dense, vnDtype dtype, const int64_t *coor
  * (model.py:262) are views, not copies.
  * ---------------------------------------------------------------------- */
 typedef struct {
+    int32_t dtype;        /* operand type of src / w_packed (/ rows in wgrad): VN_BF16, or VN_F32 =
+                             exact fp32 products on v_mfma_f32_16x16x4_f32 (1/16 of the bf16 rate) */
     int32_t B;
     int32_t Ds, Hs, Ws;   /* source (gathered) tensor sites */
     int32_t Dr, Hr, Wr;   /* row (produced) tensor sites */
-    int32_t Cs;           /* GEMM K per tap (multiple of 64; 3C in split mode) */
+    int32_t Cs;           /* GEMM K per tap (multiple of 64 bf16 / 32 fp32; 3C in split mode) */
     int32_t src_wrap;     /* 0, or 2C in split mode (see above) */
     int32_t Cr;           /* GEMM N = row channels (multiple of 4) */
     int32_t kD, kH, kW;   /* taps */
@@ -184,7 +186,8 @@ int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16*/, float *dw
  * cin_fold f: the packed Cin index p stands for torch channel (p % (Cin/f))*f + p/(Cin/f)
  * (f = 2 implements the BEV reshape of model.py:262, channel = c*2 + d; else 1). */
 int vn_pack_weight(const float *w, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode,
-                   int32_t split3, int32_t cin_fold, void *packed, vnStream stream);
+                   int32_t split3, int32_t cin_fold, void *packed, vnDtype packed_dtype,
+                   vnStream stream);
 /* inverse for gradients: packed fp32 [tap][N][K] (mode 0 or 2 orientation) -> torch layout */
 int vn_unpack_wgrad(const float *dw_packed, int32_t c_out, int32_t c_in, int32_t taps,
                     int32_t mode, int32_t cin_fold, float *dw, vnStream stream);
@@ -246,9 +249,9 @@ int vn_col_sums(const void *rows, vnDtype dtype, int64_t stride, int64_t M, int3
                 float *out, vnStream stream);
 /* heads epilogue (model.py:281): rows (M,16) = [2 prob logits | 14 reg] ->
  * NCHW prob = sigmoid (B,2,S), reg (B,14,S); and its backward:
- * d_rows = [d_prob * p * (1-p) | d_reg] as bf16 or split rows */
+ * d_rows = [d_prob * p * (1-p) | d_reg] as f32, bf16 or split bf16 rows */
 int vn_heads_bwd(const float *d_prob /*(B,2,S)*/, const float *d_reg /*(B,14,S)*/,
-                 const float *prob /*(B,2,S)*/, int32_t B, int64_t S, void *d_rows,
+                 const float *prob /*(B,2,S)*/, int32_t B, int64_t S, void *d_rows, vnDtype d_dtype,
                  int64_t d_stride, int32_t split, vnStream stream);
 
 #ifdef __cplusplus

@@ -47,12 +47,27 @@ def rpn_layers(cls_name="Car"):
 
 
 def _fill(shape, tag, scale):
-    """Closed-form deterministic tensor: scale * sin(0.37*i + tag)."""
+    """Closed-form deterministic tensor, uniform in [-scale, scale): splitmix64 of the
+    flat index and `tag` (integer arithmetic, identical on every machine).  Random-like
+    on purpose: a smooth closed form (e.g. a sine of the index) gives nearly low-rank
+    weights, and the 23-layer Conv+BatchNorm+ReLU stack then amplifies fp32 rounding noise
+    to O(1) (fp32 and fp64 runs of the SAME torch ops disagree completely) — no
+    implementation could be compared against such fixtures."""
+    import numpy as np
     n = 1
     for s in shape:
         n *= s
-    i = torch.arange(n, dtype=torch.float64)
-    return (scale * torch.sin(0.37 * i + 1.7 * tag + 0.3)).to(torch.float32).reshape(shape)
+    mask = (1 << 64) - 1
+    seed = np.uint64((int(tag) * 0xBF58476D1CE4E5B9 + 0x632BE59BD9B4E019) & mask)
+    with np.errstate(over="ignore"):
+        x = np.arange(n, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + seed
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    u = (x >> np.uint64(11)).astype(np.float64) / float(1 << 53)
+    return torch.from_numpy(((2.0 * u - 1.0) * scale).astype(np.float32)).reshape(shape)
 
 
 def make_state_dict(cls_name="Car"):

@@ -53,6 +53,7 @@ struct GGParams {
     int32_t B, Ds, Hs, Ws, Do, Ho, Wo;
     int32_t mulD, mulH, mulW, omulD, omulH, omulW;
     int32_t Cs, src_wrap, N, out_f32, accumulate, nclasses, src_row_elems;
+    int32_t esz;                // operand element size: 2 (bf16) or 4 (fp32, exact v_mfma_f32_16x16x4_f32 path)
     uint32_t w_bytes;
     int64_t src_batch_extent;   // elements spanned by one batch item (for num_records)
     GGClass cls[GG_MAX_CLASSES];
@@ -66,8 +67,9 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-template <int WM, int WN>
+template <int WM, int WN, bool F32>
 __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
+    constexpr int ESZ = F32 ? 4 : 2;          // a K step is always 128 B of every row: 64 bf16 or 32 fp32
     constexpr int BM = 64 * WM, BN = 64 * WN;
     constexpr int RA = BM / 32, RB = BN / 32;     // LDS-DMA instructions per wave per step
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
             const int qd = t / qH;
             const int sd = qd * p.mulD, sh = qh * p.mulH, sw = qw * p.mulW;
             const int64_t e = (int64_t)db * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW;
-            a_row[i] = (uint32_t)(e * 2) + (uint32_t)a_chunk * 16u;
+            a_row[i] = (uint32_t)(e * ESZ) + (uint32_t)a_chunk * 16u;
             uint32_t bits = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -134,19 +136,20 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         const int rl = rho & 63;
         const int n = n0 + (rho & ~63) + (rl & 15) * 4 + (rl >> 4);
         const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
-        b_row[i] = n < p.N ? (uint32_t)(((int64_t)n * p.Cs + chunk * 8) * 2) : GG_OOB;
+        b_row[i] = n < p.N ? (uint32_t)((int64_t)n * p.Cs * ESZ + chunk * 16) : GG_OOB;
     }
 
     // buffer descriptors (wave-uniform by construction: kernel args and blockIdx only)
-    const char *src_base = p.src + (int64_t)b0 * p.sB * 2;
-    int64_t src_bytes = ((int64_t)(p.B - b0 - 1) * p.sB + p.src_batch_extent) * 2;
+    const char *src_base = p.src + (int64_t)b0 * p.sB * ESZ;
+    int64_t src_bytes = ((int64_t)(p.B - b0 - 1) * p.sB + p.src_batch_extent) * ESZ;
     if (src_bytes > (int64_t)GG_MAX_WINDOW) src_bytes = GG_MAX_WINDOW;
     const __amdgpu_buffer_rsrc_t rs_a =
         __builtin_amdgcn_make_buffer_rsrc((void *)src_base, 0, (int)(uint32_t)src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b =
         __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_bytes, 0x00020000);
 
-    const int nk = p.Cs >> 6;
+    constexpr int BKE = 128 / ESZ;            // elements per K step
+    const int nk = p.Cs / BKE;
     const int nsteps = cl.ntaps * nk;
 
     auto stage = [&](int s, int buf) {
@@ -155,11 +158,11 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         const uint32_t tapbits = (1u << tp.id) | (16u << tp.ih) | (256u << tp.iw);
         const int64_t de = (int64_t)cl.offD[tp.id] * p.sD + (int64_t)cl.offH[tp.ih] * p.sH +
                            (int64_t)cl.offW[tp.iw] * p.sW;
-        const uint32_t delta = (uint32_t)(int32_t)(de * 2);
-        int kb = kc << 6;
+        const uint32_t delta = (uint32_t)(int32_t)(de * ESZ);
+        int kb = kc * BKE;
         if (p.src_wrap > 0 && kb >= p.src_wrap) kb -= p.src_wrap;
-        const uint32_t a_soff = (uint32_t)kb * 2u;
-        const uint32_t b_soff = (uint32_t)(((int64_t)tp.widx * p.N * p.Cs + ((int64_t)kc << 6)) * 2);
+        const uint32_t a_soff = (uint32_t)kb * (uint32_t)ESZ;
+        const uint32_t b_soff = (uint32_t)(((int64_t)tp.widx * p.N * p.Cs + (int64_t)kc * BKE) * ESZ);
         char *la = smem + buf * STAGE + wave * 1024;
         char *lb = smem + buf * STAGE + A_BYTES + wave * 1024;
 #pragma unroll
@@ -194,16 +197,33 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int fo = ks ? frag_off1 : frag_off0;
-            bf16x8_t a[4], b[4];
+            if constexpr (F32) {
+                // 16 B per lane = 4 consecutive k of one row; MFMA step t consumes element t of every lane's
+                // vector (the k <-> (lane>>4, t) assignment is the same for A and B, which is all the sum needs)
+                f32x4_t a[4], b[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t *>(la + i * 2048 + fo);
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4_t *>(la + i * 2048 + fo);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t *>(lb + j * 2048 + fo);
+                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + fo);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+            } else {
+                bf16x8_t a[4], b[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t *>(la + i * 2048 + fo);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t *>(lb + j * 2048 + fo);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
         }
     }
 
@@ -342,10 +362,13 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     VN_CHECK_ARG(g->divH == 1 || g->mulH == 1);
     VN_CHECK_ARG(g->divW == 1 || g->mulW == 1);
     VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
-    if (g->Cs <= 0 || (g->Cs & 63) || g->Cr <= 0 || (g->Cr & 3)) return VN_EUNSUPPORTED;
-    if (g->src_wrap < 0 || (g->src_wrap & 63) || (g->src_wrap > 0 && g->src_wrap >= g->Cs)) return VN_EUNSUPPORTED;
+    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32);
+    const bool f32 = g->dtype == VN_F32;
+    const int esz = f32 ? 4 : 2, bke = 128 / esz, align_e = 16 / esz;
+    if (g->Cs <= 0 || (g->Cs % bke) || g->Cr <= 0 || (g->Cr & 3)) return VN_EUNSUPPORTED;
+    if (g->src_wrap < 0 || (g->src_wrap & 63) || (g->src_wrap > 0 && (g->src_wrap >= g->Cs || f32))) return VN_EUNSUPPORTED;
     if (g->divD * g->divH * g->divW > GG_MAX_CLASSES) return VN_EUNSUPPORTED;
-    if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & 7) != 0) return VN_EUNSUPPORTED;      // 16-B source chunks
+    if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & (align_e - 1)) != 0) return VN_EUNSUPPORTED;   // 16-B chunks
     if (((g->out_sB | g->out_sD | g->out_sH | g->out_sW) & 3) != 0) return VN_EUNSUPPORTED;      // 8/16-B stores
     if ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(w_packed) & 15) ||
         (reinterpret_cast<uintptr_t>(out) & 15))
@@ -365,8 +388,9 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     p.out_f32 = out_dtype == VN_F32;
     p.accumulate = accumulate;
     p.src_row_elems = g->src_wrap > 0 ? g->src_wrap : g->Cs;
+    p.esz = esz;
     const int taps_total = g->kD * g->kH * g->kW;
-    const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * 2;
+    const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * esz;
     if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;
     p.w_bytes = (uint32_t)wb;
     p.src_batch_extent = (int64_t)(g->Ds - 1) * g->src_sD + (int64_t)(g->Hs - 1) * g->src_sH +
@@ -420,7 +444,7 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
         if (min_rows_b <= 0) min_rows_b = 1;
         int64_t span_b = BM / min_rows_b + 2;
         if (span_b > g->B) span_b = g->B;
-        const int64_t need = ((span_b - 1) * g->src_sB + p.src_batch_extent) * 2;
+        const int64_t need = ((span_b - 1) * g->src_sB + p.src_batch_extent) * esz;
         if (need > (int64_t)GG_MAX_WINDOW - 4096) return VN_EUNSUPPORTED;
     }
     const int64_t tiles_m = vn_ceil_div(max_rows, BM);
@@ -429,17 +453,17 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ncls);
     const size_t lds = 2u * (size_t)(BM + BN) * 128u;
     hipStream_t st = vn_stream(stream);
-    if (wide) {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather_gemm<2, 2>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    auto launch = [&](auto kern, int max_lds) -> int {
+        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         if (attr != hipSuccess) return (int)attr;
-        k_gather_gemm<2, 2><<<grid, 256, lds, st>>>(p);
-    } else {
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather_gemm<4, 1>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 81920);
-        if (attr != hipSuccess) return (int)attr;
-        k_gather_gemm<4, 1><<<grid, 256, lds, st>>>(p);
-    }
+        kern<<<grid, 256, lds, st>>>(p);
+        return 0;
+    };
+    int rc;
+    if (wide) rc = f32 ? launch(&k_gather_gemm<2, 2, true>, 65536) : launch(&k_gather_gemm<2, 2, false>, 65536);
+    else rc = f32 ? launch(&k_gather_gemm<4, 1, true>, 81920) : launch(&k_gather_gemm<4, 1, false>, 81920);
+    if (rc) return rc;
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

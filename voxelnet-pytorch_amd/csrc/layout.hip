@@ -24,7 +24,7 @@ __device__ __forceinline__ int64_t torch_index(int mode, int c_out, int c_in, in
 }
 
 __global__ void __launch_bounds__(256) k_pack_weight(const float *__restrict__ w, int c_out, int c_in, int taps,
-                                                     int mode, int split3, int cin_fold, bf16_t *__restrict__ packed) {
+                                                     int mode, int split3, int cin_fold, void *__restrict__ packed, int f32) {
     const int N = (mode == 0 || mode == 2) ? c_out : c_in;
     const int K = (mode == 0 || mode == 2) ? c_in : c_out;
     const int Ke = split3 ? 3 * K : K;
@@ -35,9 +35,13 @@ __global__ void __launch_bounds__(256) k_pack_weight(const float *__restrict__ w
         const int tap = (int)(i / ((int64_t)Ke * N));
         const int k = ke % K, part = ke / K;   // part 0: hi, 1: hi, 2: lo
         const float v = w[torch_index(mode, c_out, c_in, taps, tap, n, k, cin_fold)];
-        bf16_t hi, lo;
-        vn_split_bf16(v, hi, lo);
-        packed[i] = part == 2 ? lo : hi;
+        if (f32) {
+            static_cast<float *>(packed)[i] = v;
+        } else {
+            bf16_t hi, lo;
+            vn_split_bf16(v, hi, lo);
+            static_cast<bf16_t *>(packed)[i] = part == 2 ? lo : hi;
+        }
     }
 }
 
@@ -175,11 +179,12 @@ __global__ void __launch_bounds__(256) k_col_sums(const void *__restrict__ rows,
 // heads backward: NCHW d_prob (B,2,S), d_reg (B,14,S), prob -> rows (B*S, 16)
 __global__ void __launch_bounds__(256) k_heads_bwd(const float *__restrict__ dprob, const float *__restrict__ dreg,
                                                    const float *__restrict__ prob, int B, int64_t S, void *drows,
-                                                   int64_t stride, int split) {
+                                                   int64_t stride, int split, int f32) {
     const int64_t total = (int64_t)B * S;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / S, s = i - b * S;
         bf16_t *d = static_cast<bf16_t *>(drows) + i * stride;
+        float *df = static_cast<float *>(drows) + i * stride;
 #pragma unroll
         for (int c = 0; c < 16; ++c) {
             float v;
@@ -189,10 +194,14 @@ __global__ void __launch_bounds__(256) k_heads_bwd(const float *__restrict__ dpr
             } else {
                 v = dreg[(b * 14 + (c - 2)) * S + s];
             }
-            bf16_t h, l;
-            vn_split_bf16(v, h, l);
-            d[c] = h;
-            if (split) d[16 + c] = l;
+            if (f32) {
+                df[c] = v;
+            } else {
+                bf16_t h, l;
+                vn_split_bf16(v, h, l);
+                d[c] = h;
+                if (split) d[16 + c] = l;
+            }
         }
     }
 }
@@ -207,12 +216,13 @@ inline unsigned gs_blocks(int64_t total, int per_block = 256, int cap = 8192) {
 }  // namespace
 
 extern "C" int vn_pack_weight(const float *w, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode, int32_t split3,
-                              int32_t cin_fold, void *packed, vnStream stream) {
+                              int32_t cin_fold, void *packed, vnDtype packed_dtype, vnStream stream) {
     VN_CHECK_ARG(w && packed && c_out > 0 && c_in > 0 && taps > 0 && mode >= 0 && mode <= 3);
+    VN_CHECK_ARG(packed_dtype == VN_BF16 || (packed_dtype == VN_F32 && !split3));
     VN_CHECK_ARG(cin_fold >= 1 && c_in % cin_fold == 0);
     const int64_t total = (int64_t)taps * c_out * c_in * (split3 ? 3 : 1);
-    k_pack_weight<<<gs_blocks(total), 256, 0, vn_stream(stream)>>>(w, c_out, c_in, taps, mode, split3, cin_fold,
-                                                                   static_cast<bf16_t *>(packed));
+    k_pack_weight<<<gs_blocks(total), 256, 0, vn_stream(stream)>>>(w, c_out, c_in, taps, mode, split3, cin_fold, packed,
+                                                                   packed_dtype == VN_F32);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -271,10 +281,11 @@ extern "C" int vn_col_sums(const void *rows, vnDtype dtype, int64_t stride, int6
 }
 
 extern "C" int vn_heads_bwd(const float *d_prob, const float *d_reg, const float *prob, int32_t B, int64_t S,
-                            void *d_rows, int64_t d_stride, int32_t split, vnStream stream) {
+                            void *d_rows, vnDtype d_dtype, int64_t d_stride, int32_t split, vnStream stream) {
     VN_CHECK_ARG(d_prob && d_reg && prob && d_rows && B > 0 && S > 0 && d_stride >= (split ? 32 : 16));
+    VN_CHECK_ARG(d_dtype == VN_BF16 || (d_dtype == VN_F32 && !split));
     k_heads_bwd<<<gs_blocks((int64_t)B * S), 256, 0, vn_stream(stream)>>>(d_prob, d_reg, prob, B, S, d_rows, d_stride,
-                                                                          split);
+                                                                          split, d_dtype == VN_F32);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -49,17 +49,20 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds
 
 // swizzle of the 16-B chunk index inside a row, as a function of the row, so that the
 // transposed 8-B reads of a 32-lane half hit 32 distinct bank pairs.
-template <int ROW_BYTES>
+template <int ROW_BYTES, bool F32>
 __device__ __forceinline__ int chunk_swz(int row) {
+    if (F32) return (row & 3) << 2;   // fp32 tiles (rows >= 256 B) are read with ds_read_b32: 64-B shifts by row&3
     if (ROW_BYTES == 128) return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
     return ((row & 3) << 1) | (((row >> 3) & 1) << 3);   // 256-B rows
 }
 
-template <int TN, int TK>   // wave tile in units of 16 channels; 2x2 waves
+template <int TN, int TK, bool F32>   // wave tile in units of 16 channels; 2x2 waves
 __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
+    constexpr int ESZ = F32 ? 4 : 2;
+    constexpr int ROWS = F32 ? 32 : 64;                     // sites per stage (same bytes either way)
     constexpr int DN = 32 * TN, DK = 32 * TK;
-    constexpr int RBN = DN * 2, RBK = DK * 2;               // LDS row bytes
-    constexpr int TILE_N = 64 * RBN, TILE_K = 64 * RBK;     // bytes per stage
+    constexpr int RBN = DN * ESZ, RBK = DK * ESZ;           // LDS row bytes
+    constexpr int TILE_N = ROWS * RBN, TILE_K = ROWS * RBK; // bytes per stage
     constexpr int STAGE = TILE_N + TILE_K;
     constexpr int IN = TILE_N / 4096, IK = TILE_K / 4096;   // DMA instructions per wave per stage
     constexpr int LPR_N = RBN / 16, LPR_K = RBK / 16;       // lanes per row
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     if (rbeg >= M) return;
     int64_t rend = rbeg + p.rows_per_chunk;
     if (rend > M) rend = M;
-    const int nsteps = (int)((rend - rbeg + 63) >> 6);
+    const int nsteps = (int)((rend - rbeg + ROWS - 1) / ROWS);
     const int nv = p.split ? 3 : 1;
     const int nstages = nsteps * nv;
 
@@ -100,9 +103,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     auto table_write = [&](int stage_idx) {
         // wave 0 only: entry for slab (stage_idx / nv) into tbl[stage_idx & 1]
         const int step = stage_idx / nv;
-        while (tstep < step) {   // advance by 64 sites
-            cm += 64;
-            cw += 64;
+        while (tstep < step) {   // advance by ROWS sites
+            cm += ROWS;
+            cw += ROWS;
             while (cw >= p.Wr) {
                 cw -= p.Wr;
                 if (++ch >= p.Hr) { ch = 0; if (++cd >= p.Dr) { cd = 0; ++cb; } }
@@ -114,9 +117,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
             const int sd = cd * p.mulD + td * p.tmulD - p.padD;
             const int sh = ch * p.mulH + th * p.tmulH - p.padH;
             const int sw = cw * p.mulW + tw * p.tmulW - p.padW;
-            ro = (uint32_t)(((int64_t)cb * p.rB + (int64_t)cd * p.rD + (int64_t)ch * p.rH + (int64_t)cw * p.rW) * 2);
+            ro = (uint32_t)(((int64_t)cb * p.rB + (int64_t)cd * p.rD + (int64_t)ch * p.rH + (int64_t)cw * p.rW) * ESZ);
             if ((unsigned)sd < (unsigned)p.Ds && (unsigned)sh < (unsigned)p.Hs && (unsigned)sw < (unsigned)p.Ws)
-                so = (uint32_t)(((int64_t)cb * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW) * 2);
+                so = (uint32_t)(((int64_t)cb * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW) * ESZ);
         }
         uint32_t *e = tbl + ((stage_idx & 1) * 64 + lane) * 2;
         e[0] = so;
@@ -126,25 +129,25 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     // per-lane DMA geometry: instruction i of this wave covers LDS bytes ((i*4+wave)*1024 .. +1023) of a tile
     auto stage = [&](int sidx, int buf) {
         const int v = sidx % nv;   // bf16x3 variant: 0 hi*hi, 1 lo(src)*hi(rows), 2 hi(src)*lo(rows)
-        const uint32_t s_col = (uint32_t)((k0 + (v == 1 ? p.C : 0)) * 2);
-        const uint32_t r_col = (uint32_t)((n0 + (v == 2 ? p.N : 0)) * 2);
+        const uint32_t s_col = (uint32_t)((k0 + (v == 1 ? p.C : 0)) * ESZ);
+        const uint32_t r_col = (uint32_t)((n0 + (v == 2 ? p.N : 0)) * ESZ);
         const uint32_t *t = tbl + (sidx & 1) * 128;
         char *ln = smem + buf * STAGE + wave * 1024;
         char *lk = smem + buf * STAGE + TILE_N + wave * 1024;
 #pragma unroll
         for (int i = 0; i < IN; ++i) {
             const int r = ((i * 4 + wave) * 1024) / RBN + lane / LPR_N;
-            const int c = (lane % LPR_N) ^ chunk_swz<RBN>(r);
+            const int c = (lane % LPR_N) ^ chunk_swz<RBN, F32>(r);
             const uint32_t ro = t[r * 2 + 1];
-            const bool ok = ro != WG_OOB && (n0 + c * 8) < p.N;
+            const bool ok = ro != WG_OOB && (n0 + c * (16 / ESZ)) < p.N;
             lds_dma16(rs_r, ln + i * 4096, ok ? ro + (uint32_t)c * 16u : WG_OOB, r_col);
         }
 #pragma unroll
         for (int i = 0; i < IK; ++i) {
             const int r = ((i * 4 + wave) * 1024) / RBK + lane / LPR_K;
-            const int c = (lane % LPR_K) ^ chunk_swz<RBK>(r);
+            const int c = (lane % LPR_K) ^ chunk_swz<RBK, F32>(r);
             const uint32_t so = t[r * 2];
-            const bool ok = so != WG_OOB && (k0 + c * 8) < p.C;
+            const bool ok = so != WG_OOB && (k0 + c * (16 / ESZ)) < p.C;
             lds_dma16(rs_s, lk + i * 4096, ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
         }
     };
@@ -170,6 +173,31 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
         if (wave == 0 && s + 2 < nstages) table_write(s + 2);
         const char *ln = smem + buf * STAGE;
         const char *lk = smem + buf * STAGE + TILE_N;
+        if constexpr (F32) {
+            // v_mfma_f32_16x16x4_f32: lane (c = lane&15, kq = lane>>4) supplies element [site 4s+kq][col c]
+            const int fc = lane & 15, kq = lane >> 4;
+#pragma unroll
+            for (int ss = 0; ss < ROWS / 4; ++ss) {
+                const int r = ss * 4 + kq;
+                const int sw = chunk_swz<RBN, true>(r);     // same function for both tiles (row & 3)
+                float a[TN], b[TK];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int col = (wn * TN + i) * 16 + fc;
+                    a[i] = *reinterpret_cast<const float *>(ln + r * RBN + ((((col >> 2) ^ sw)) << 4) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int j = 0; j < TK; ++j) {
+                    const int col = (wk * TK + j) * 16 + fc;
+                    b[j] = *reinterpret_cast<const float *>(lk + r * RBK + ((((col >> 2) ^ sw)) << 4) + (col & 3) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
         typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -179,8 +207,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
             for (int i = 0; i < TN; ++i) {
                 const int col = (wn * TN + i) * 16 + pp * 4;          // element column inside the tile
                 const int c16 = col >> 3, half = (col >> 2) & 1;      // 16-B chunk, 8-B half
-                const char *p0 = ln + r0 * RBN + ((c16 ^ chunk_swz<RBN>(r0)) << 4) + half * 8;
-                const char *p1 = ln + r1 * RBN + ((c16 ^ chunk_swz<RBN>(r1)) << 4) + half * 8;
+                const char *p0 = ln + r0 * RBN + ((c16 ^ chunk_swz<RBN, false>(r0)) << 4) + half * 8;
+                const char *p1 = ln + r1 * RBN + ((c16 ^ chunk_swz<RBN, false>(r1)) << 4) + half * 8;
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
                 const s16x8_t t8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -190,8 +218,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
             for (int j = 0; j < TK; ++j) {
                 const int col = (wk * TK + j) * 16 + pp * 4;
                 const int c16 = col >> 3, half = (col >> 2) & 1;
-                const char *p0 = lk + r0 * RBK + ((c16 ^ chunk_swz<RBK>(r0)) << 4) + half * 8;
-                const char *p1 = lk + r1 * RBK + ((c16 ^ chunk_swz<RBK>(r1)) << 4) + half * 8;
+                const char *p0 = lk + r0 * RBK + ((c16 ^ chunk_swz<RBK, false>(r0)) << 4) + half * 8;
+                const char *p1 = lk + r1 * RBK + ((c16 ^ chunk_swz<RBK, false>(r1)) << 4) + half * 8;
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
                 const s16x8_t t8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -202,6 +230,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
 #pragma unroll
                 for (int j = 0; j < TK; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
         }
     }
 
@@ -219,14 +248,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
         }
 }
 
-template <int TN, int TK>
+template <int TN, int TK, bool F32>
 int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
     constexpr int DN = 32 * TN, DK = 32 * TK;
-    constexpr size_t lds = 2u * 64u * (DN + DK) * 2u + 2u * 64u * 2u * 4u;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK>),
+    constexpr size_t lds = 2u * 64u * (DN + DK) * 2u + 2u * 64u * 2u * 4u;   // same bytes for bf16 (64 sites) and fp32 (32)
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK, F32>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    k_wgrad<TN, TK><<<grid, 256, lds, st>>>(p);
+    k_wgrad<TN, TK, F32><<<grid, 256, lds, st>>>(p);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -239,9 +268,12 @@ extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed
     VN_CHECK_ARG(g->B > 0 && g->Ds > 0 && g->Hs > 0 && g->Ws > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0);
     VN_CHECK_ARG(g->kD >= 1 && g->kH >= 1 && g->kW >= 1 && g->kD * g->kH * g->kW <= 65535);
     if (g->divD != 1 || g->divH != 1 || g->divW != 1) return VN_EUNSUPPORTED;
-    if (g->Cs <= 0 || (g->Cs & 7) || g->Cr <= 0 || (g->Cr & 7)) return VN_EUNSUPPORTED;
-    if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & 7) != 0) return VN_EUNSUPPORTED;
-    if (((g->out_sB | g->out_sD | g->out_sH | g->out_sW) & 7) != 0) return VN_EUNSUPPORTED;
+    VN_CHECK_ARG(g->dtype == VN_BF16 || (g->dtype == VN_F32 && !split));
+    const bool f32 = g->dtype == VN_F32;
+    const int esz = f32 ? 4 : 2, al = 16 / esz - 1;
+    if (g->Cs <= 0 || (g->Cs & al) || g->Cr <= 0 || (g->Cr & al)) return VN_EUNSUPPORTED;
+    if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & al) != 0) return VN_EUNSUPPORTED;
+    if (((g->out_sB | g->out_sD | g->out_sH | g->out_sW) & al) != 0) return VN_EUNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(src) & 15) || (reinterpret_cast<uintptr_t>(rows) & 15)) return VN_EUNSUPPORTED;
 
     WGParams p{};
@@ -258,9 +290,9 @@ extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed
     p.C = g->Cs; p.N = g->Cr; p.split = split ? 1 : 0;
     const int wmul = split ? 2 : 1;
     const int64_t sbytes = ((int64_t)(g->B - 1) * g->src_sB + (int64_t)(g->Ds - 1) * g->src_sD +
-                            (int64_t)(g->Hs - 1) * g->src_sH + (int64_t)(g->Ws - 1) * g->src_sW + wmul * g->Cs) * 2;
+                            (int64_t)(g->Hs - 1) * g->src_sH + (int64_t)(g->Ws - 1) * g->src_sW + wmul * g->Cs) * esz;
     const int64_t rbytes = ((int64_t)(g->B - 1) * g->out_sB + (int64_t)(g->Dr - 1) * g->out_sD +
-                            (int64_t)(g->Hr - 1) * g->out_sH + (int64_t)(g->Wr - 1) * g->out_sW + wmul * g->Cr) * 2;
+                            (int64_t)(g->Hr - 1) * g->out_sH + (int64_t)(g->Wr - 1) * g->out_sW + wmul * g->Cr) * esz;
     if (sbytes > (int64_t)WG_MAX_WINDOW || rbytes > (int64_t)WG_MAX_WINDOW) return VN_EUNSUPPORTED;
     p.src_bytes = (uint32_t)sbytes;
     p.rows_bytes = (uint32_t)rbytes;
@@ -281,8 +313,14 @@ extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed
     chunks = vn_ceil_div(M, rpc);
     const dim3 grid((unsigned)chunks, (unsigned)taps, (unsigned)(tiles_n * tiles_k));
     hipStream_t st = vn_stream(stream);
-    if (n128 && k128) return launch_wgrad<4, 4>(p, grid, st);
-    if (n128) return launch_wgrad<4, 2>(p, grid, st);
-    if (k128) return launch_wgrad<2, 4>(p, grid, st);
-    return launch_wgrad<2, 2>(p, grid, st);
+    if (f32) {
+        if (n128 && k128) return launch_wgrad<4, 4, true>(p, grid, st);
+        if (n128) return launch_wgrad<4, 2, true>(p, grid, st);
+        if (k128) return launch_wgrad<2, 4, true>(p, grid, st);
+        return launch_wgrad<2, 2, true>(p, grid, st);
+    }
+    if (n128 && k128) return launch_wgrad<4, 4, false>(p, grid, st);
+    if (n128) return launch_wgrad<4, 2, false>(p, grid, st);
+    if (k128) return launch_wgrad<2, 4, false>(p, grid, st);
+    return launch_wgrad<2, 2, false>(p, grid, st);
 }

@@ -29,7 +29,7 @@ class VnGrid(ctypes.Structure):
 
 class VnConv(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in (
-        "B", "Ds", "Hs", "Ws", "Dr", "Hr", "Wr", "Cs", "src_wrap", "Cr", "kD", "kH", "kW",
+        "dtype", "B", "Ds", "Hs", "Ws", "Dr", "Hr", "Wr", "Cs", "src_wrap", "Cr", "kD", "kH", "kW",
         "mulD", "mulH", "mulW", "tmulD", "tmulH", "tmulW", "padD", "padH", "padW",
         "divD", "divH", "divW")] + [(n, c_i64) for n in (
         "src_sB", "src_sD", "src_sH", "src_sW", "out_sB", "out_sD", "out_sH", "out_sW")]
@@ -59,7 +59,7 @@ SIGNATURES = {
     "vn_scatter_dense_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vn_conv_gather_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_i32, c_vp, c_vp]),
     "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp]),
-    "vn_pack_weight": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vn_pack_weight": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "vn_unpack_wgrad": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vn_bn_stats": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_i32, c_vp, c_vp, c_vp]),
     "vn_bn_finalize": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32, c_vp,
@@ -73,7 +73,7 @@ SIGNATURES = {
     "vn_rows_to_nchw": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp, c_i32, c_vp]),
     "vn_cast_rows": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
     "vn_col_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp]),
-    "vn_heads_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i64, c_i32, c_vp]),
+    "vn_heads_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp]),
 }
 
 _lib = None

@@ -30,8 +30,9 @@ _PRECISION = {"mode": "bf16"}
 
 
 def set_precision(mode):
-    """'bf16' (bf16 storage + MFMA, BASELINE configs[1]) or 'exact' (bf16x3, fp32-accurate)."""
-    if mode not in ("bf16", "exact"):
+    """'bf16' (bf16 storage + MFMA, BASELINE configs[1]), 'fp32' (exact fp32 MFMA, the parity
+    mode) or 'bf16x3' (see engine.py)."""
+    if mode not in E.MODES:
         raise ValueError(mode)
     _PRECISION["mode"] = mode
 
@@ -40,8 +41,8 @@ def get_precision():
     return _PRECISION["mode"]
 
 
-def _split():
-    return _PRECISION["mode"] == "exact"
+def _mode():
+    return _PRECISION["mode"]
 
 
 def _need_cuda(*ts):
@@ -64,30 +65,30 @@ class _LayerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, spec, bn_mod, training):
         _need_cuda(x, weight)
-        split = _split()
+        mode = _mode()
         with torch.cuda.device(x.device):
-            xr = E.nchw_to_rows(x, split)
+            xr = E.nchw_to_rows(x, mode)
             P = {"weight": weight.detach(), "bias": bias.detach(),
                  "gamma": gamma.detach() if gamma is not None else None,
                  "beta": beta.detach() if beta is not None else None}
             Bf = None
             if spec.bn:
                 Bf = {"running_mean": bn_mod.running_mean, "running_var": bn_mod.running_var}
-            a, st = E.layer_forward(spec, xr, P, Bf, training, split, y_dtype=None if spec.bn else torch.float32)
+            a, st = E.layer_forward(spec, xr, P, Bf, training, mode, y_dtype=None if spec.bn else torch.float32)
             out = _act_to_nchw(a, spec.dim) if spec.bn else E.rows_to_nchw(a, spec.dim)
-        ctx.st, ctx.P, ctx.split, ctx.spec = st, P, split, spec
+        ctx.st, ctx.P, ctx.mode, ctx.spec = st, P, mode, spec
         ctx.need_dx = x.requires_grad
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        spec, split = ctx.spec, ctx.split
+        spec, mode = ctx.spec, ctx.mode
         with torch.cuda.device(dout.device):
             if spec.bn:
-                da = E.nchw_to_plain_rows(dout, torch.float32 if split else torch.bfloat16)
+                da = E.nchw_to_plain_rows(dout, E.plain_dtype_of(mode))
             else:
-                da = E.nchw_to_rows(dout, split)
-            grads, dx = E.layer_backward(ctx.st, da, ctx.P, split, need_dx=ctx.need_dx)
+                da = E.nchw_to_rows(dout, mode)
+            grads, dx = E.layer_backward(ctx.st, da, ctx.P, mode, need_dx=ctx.need_dx)
             dxn = E.rows_to_nchw(dx, spec.dim) if dx is not None else None
         return dxn, grads["weight"], grads["bias"], grads.get("gamma"), grads.get("beta"), None, None, None
 
@@ -205,14 +206,15 @@ def featnet_backward(feature, wstruct, stats, d_vw, params):
     return grads
 
 
-def scatter_rows(vw, coord, B, dims, split):
-    """model.py:102-106 -> dense Rows (bf16, [hi|lo] when split)"""
+def scatter_rows(vw, coord, B, dims, mode):
+    """model.py:102-106 -> dense Rows in the mode's activation format"""
     D, H, W = dims
     K, C = vw.shape
+    split = E.is_split(mode)
     ch = 2 * C if split else C
-    dense = torch.empty((B, D, H, W, ch), dtype=torch.bfloat16, device=vw.device)
+    dense = torch.empty((B, D, H, W, ch), dtype=E.act_dtype_of(mode), device=vw.device)
     _lib.call("vn_scatter_dense_fwd", vw.data_ptr(), coord.data_ptr(), K, C, B, D, H, W, dense.data_ptr(),
-              _lib.VN_BF16, ch, int(split), E.stream())
+              E._dt(dense), ch, int(split), E.stream())
     return Rows(dense, C, C if split else 0)
 
 
@@ -323,17 +325,20 @@ class _MiddleFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, mod, training, *flat):
         _need_cuda(x)
-        split = _split()
+        mode = _mode()
         names, P, Bf, _ = _collect_middle(mod)
         P = _detached(P)
         P["heads"] = _heads_params([f.detach() for f in flat])
         with torch.cuda.device(x.device):
             B, D, H, W, C = x.shape
-            dense = E.new_rows(B, (D, H, W), 128, torch.bfloat16, split, x.device)
             xc = x.contiguous().float()
-            _lib.call("vn_cast_rows", xc.data_ptr(), _lib.VN_F32, 128, B * D * H * W, 128, dense.ptr(), _lib.VN_BF16,
-                      dense.t.shape[-1], dense.lo_off, E.stream())
-            prob, reg, st = N.middle_forward(dense, P, Bf, mod._block1_stride, training, split)
+            if mode == "fp32":
+                dense = Rows(xc, 128)
+            else:
+                dense = E.new_rows(B, (D, H, W), 128, torch.bfloat16, E.is_split(mode), x.device)
+                _lib.call("vn_cast_rows", xc.data_ptr(), _lib.VN_F32, 128, B * D * H * W, 128, dense.ptr(),
+                          _lib.VN_BF16, dense.t.shape[-1], dense.lo_off, E.stream())
+            prob, reg, st = N.middle_forward(dense, P, Bf, mod._block1_stride, training, mode)
         ctx.st, ctx.P, ctx.names = st, P, names
         ctx.need_dx = x.requires_grad
         return prob, reg
@@ -395,7 +400,7 @@ class _DetectorFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feature, coord, B, rpn, training, *flat):
         _need_cuda(feature, coord)
-        split = _split()
+        mode = _mode()
         fn, mid = rpn.feature_net, rpn.middle_rpn
         nv = 8
         vparams = [p.detach() for p in flat[:nv]]
@@ -404,8 +409,8 @@ class _DetectorFn(torch.autograd.Function):
         P["heads"] = _heads_params([f.detach() for f in flat[nv:]])
         with torch.cuda.device(feature.device):
             vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
-            dense = scatter_rows(vw, coord, B, fn._grid.dims, split)
-            prob, reg, st = N.middle_forward(dense, P, Bf, mid._block1_stride, training, split)
+            dense = scatter_rows(vw, coord, B, fn._grid.dims, mode)
+            prob, reg, st = N.middle_forward(dense, P, Bf, mid._block1_stride, training, mode)
         ctx.saved = (feature, coord, stats, wst, vparams, st, P, names)
         return prob, reg
 

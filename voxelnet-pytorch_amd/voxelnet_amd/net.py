@@ -34,7 +34,7 @@ class MiddleState:
     pass
 
 
-def middle_forward(dense, P, Bf, block1_stride, training, split):
+def middle_forward(dense, P, Bf, block1_stride, training, mode):
     """dense: Rows (B,D,H,W,128[hi|lo]).  P[name] = {weight,bias,gamma,beta}; Bf[name] =
     {running_mean,running_var}; P['heads'] = {weight (16,768,1,1), bias (16)}.
     Returns prob (B,2,h,w) after sigmoid, reg (B,14,h,w) fp32 NCHW, and the saved state."""
@@ -42,12 +42,13 @@ def middle_forward(dense, P, Bf, block1_stride, training, split):
     st = MiddleState()
     st.layers = {}
     st.block1_stride = block1_stride
-    st.split = split
+    st.mode = mode
+    split = E.is_split(mode)
     dev = dense.t.device
     B = dense.B
 
     def run(name, x, **kw):
-        a, s = E.layer_forward(specs[name], x, P[name], Bf[name], training, split, **kw)
+        a, s = E.layer_forward(specs[name], x, P[name], Bf[name], training, mode, **kw)
         st.layers[name] = s
         return a
 
@@ -59,7 +60,7 @@ def middle_forward(dense, P, Bf, block1_stride, training, split):
     x1 = x
     hf, wf = specs["deconv1"].out_dims(x1.dims)[1:]
     width = 768 * (2 if split else 1)
-    cat = Rows(torch.empty((B, 1, hf, wf, width), dtype=torch.bfloat16, device=dev), 768, 768 if split else 0)
+    cat = Rows(torch.empty((B, 1, hf, wf, width), dtype=E.act_dtype_of(mode), device=dev), 768, 768 if split else 0)
 
     def cat_slice(off):
         return Rows(cat.t[..., off:off + 256], 256, cat.lo_off)
@@ -72,7 +73,7 @@ def middle_forward(dense, P, Bf, block1_stride, training, split):
     for i in range(6):
         x = run(f"block3.{i}", x)
     run("deconv3", x, out=cat_slice(0))
-    y, s = E.layer_forward(HEADS, cat, P["heads"], None, training, split, y_dtype=torch.float32)
+    y, s = E.layer_forward(HEADS, cat, P["heads"], None, training, mode, y_dtype=torch.float32)
     st.layers["heads"] = s
     prob = E.rows_to_nchw(Rows(y.t[..., 0:2], 2), 2, sigmoid_first_n=2)
     reg = E.rows_to_nchw(Rows(y.t[..., 2:16], 14), 2)
@@ -83,23 +84,24 @@ def middle_forward(dense, P, Bf, block1_stride, training, split):
 
 def middle_backward(st, d_prob, d_reg, P, need_dx=True):
     """-> ({name: {weight,bias,gamma,beta}}, d_dense Rows (plain f32/bf16) or None)"""
-    split = st.split
+    mode = st.mode
+    split = E.is_split(mode)
     L = st.layers
     dev = d_prob.device
     B = d_prob.shape[0]
     hf, wf = st.fmap
     G = {}
     w16 = 32 if split else 16
-    d_rows = Rows(torch.empty((B, 1, hf, wf, w16), dtype=torch.bfloat16, device=dev), 16, 16 if split else 0)
+    d_rows = Rows(torch.empty((B, 1, hf, wf, w16), dtype=E.act_dtype_of(mode), device=dev), 16, 16 if split else 0)
     _lib.call("vn_heads_bwd", d_prob.contiguous().data_ptr(), d_reg.contiguous().data_ptr(), st.prob.data_ptr(), B,
-              hf * wf, d_rows.ptr(), w16, int(split), E.stream())
-    G["heads"], d_cat = E.layer_backward(L["heads"], d_rows, P["heads"], split)
+              hf * wf, d_rows.ptr(), E._dt(d_rows.t), w16, int(split), E.stream())
+    G["heads"], d_cat = E.layer_backward(L["heads"], d_rows, P["heads"], mode)
 
     def dslice(off):
         return Rows(d_cat.t[..., off:off + 256], 256)
 
     def back(name, da, **kw):
-        g, dx = E.layer_backward(L[name], da, P[name], split, **kw)
+        g, dx = E.layer_backward(L[name], da, P[name], mode, **kw)
         G[name] = g
         return dx
 
