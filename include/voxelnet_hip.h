@@ -148,7 +148,7 @@ typedef struct {
     int32_t B;
     int32_t Ds, Hs, Ws;   /* source (gathered) tensor sites */
     int32_t Dr, Hr, Wr;   /* row (produced) tensor sites */
-    int32_t Cs;           /* GEMM K per tap (multiple of 64 bf16 / 32 fp32; 3C in split mode) */
+    int32_t Cs;           /* GEMM K per tap (multiple of 8 bf16 / 4 fp32 elements; 3C in split mode) */
     int32_t src_wrap;     /* 0, or 2C in split mode (see above) */
     int32_t Cr;           /* GEMM N = row channels (multiple of 4) */
     int32_t kD, kH, kW;   /* taps */

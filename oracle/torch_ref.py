@@ -166,19 +166,27 @@ def feature_net(features, coordinates, sd, dims, training=True):
     return scatter_dense(voxel_features(feature, sd, training), coordinate, (B,) + tuple(dims))
 
 
-def conv_md(x, sd, prefix, dim, stride, pad, bn=True, act=True, training=True):
+def _relu(x, relu_mask=None):
+    """F.relu, or (tests only) multiplication by a given 0/1 mask: the derivative of ReLU is
+    discontinuous at 0, so a checker that must compare BACKWARD passes tightly evaluates the
+    reference with the mask of the implementation under test (they differ only where the
+    pre-activation is within rounding distance of 0)."""
+    return F.relu(x) if relu_mask is None else x * relu_mask.to(x.dtype)
+
+
+def conv_md(x, sd, prefix, dim, stride, pad, bn=True, act=True, training=True, relu_mask=None):
     """model.py:158-167."""
     fn = F.conv3d if dim == 3 else F.conv2d
     x = fn(x, sd[prefix + ".conv.weight"], sd[prefix + ".conv.bias"], stride, pad)
     if bn:
         x = _bn(x, sd, prefix + ".batch_norm", training)
-    return F.relu(x) if act else x
+    return _relu(x, relu_mask) if act else x
 
 
-def deconv2d(x, sd, prefix, stride, pad, training=True):
+def deconv2d(x, sd, prefix, stride, pad, training=True, relu_mask=None):
     """model.py:195-199."""
     x = F.conv_transpose2d(x, sd[prefix + ".deconv.weight"], sd[prefix + ".deconv.bias"], stride, pad)
-    return F.relu(_bn(x, sd, prefix + ".batch_norm", training))
+    return _relu(_bn(x, sd, prefix + ".batch_norm", training), relu_mask)
 
 
 def middle_rpn(dense, sd, cls_name="Car", training=True, taps=None):

@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
             const int qd = t / qH;
             const int sd = qd * p.mulD, sh = qh * p.mulH, sw = qw * p.mulW;
             const int64_t e = (int64_t)db * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW;
-            a_row[i] = (uint32_t)(e * ESZ) + (uint32_t)a_chunk * 16u;
+            a_row[i] = (uint32_t)(e * ESZ);
             uint32_t bits = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -135,8 +135,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         const int rho = (i * 4 + wave) * 8 + (lane >> 3);
         const int rl = rho & 63;
         const int n = n0 + (rho & ~63) + (rl & 15) * 4 + (rl >> 4);
-        const int chunk = (lane & 7) ^ ((rho >> 1) & 7);
-        b_row[i] = n < p.N ? (uint32_t)((int64_t)n * p.Cs * ESZ + chunk * 16) : GG_OOB;
+        b_row[i] = n < p.N ? (uint32_t)((int64_t)n * p.Cs * ESZ) : GG_OOB;   // chunk = a_chunk for every i
     }
 
     // buffer descriptors (wave-uniform by construction: kernel args and blockIdx only)
@@ -149,7 +148,8 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_bytes, 0x00020000);
 
     constexpr int BKE = 128 / ESZ;            // elements per K step
-    const int nk = p.Cs / BKE;
+    constexpr int EPC = 16 / ESZ;             // elements per 16-B chunk
+    const int nk = (p.Cs + BKE - 1) / BKE;    // the last step may be partial: chunks past Cs read zeros
     const int nsteps = cl.ntaps * nk;
 
     auto stage = [&](int s, int buf) {
@@ -159,20 +159,24 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         const int64_t de = (int64_t)cl.offD[tp.id] * p.sD + (int64_t)cl.offH[tp.ih] * p.sH +
                            (int64_t)cl.offW[tp.iw] * p.sW;
         const uint32_t delta = (uint32_t)(int32_t)(de * ESZ);
-        int kb = kc * BKE;
-        if (p.src_wrap > 0 && kb >= p.src_wrap) kb -= p.src_wrap;
-        const uint32_t a_soff = (uint32_t)kb * (uint32_t)ESZ;
-        const uint32_t b_soff = (uint32_t)(((int64_t)tp.widx * p.N * p.Cs + (int64_t)kc * BKE) * ESZ);
+        // this lane's K position inside the step; split rows wrap (k >= 2C reads the hi part again)
+        const int k_lane = kc * BKE + a_chunk * EPC;
+        const bool k_ok = k_lane < p.Cs;
+        const int k_src = (p.src_wrap > 0 && k_lane >= p.src_wrap) ? k_lane - p.src_wrap : k_lane;
+        const uint32_t a_koff = (uint32_t)k_src * (uint32_t)ESZ;
+        const uint32_t b_koff = (uint32_t)k_lane * (uint32_t)ESZ;
+        const uint32_t b_soff = (uint32_t)((int64_t)tp.widx * p.N * p.Cs * ESZ);
         char *la = smem + buf * STAGE + wave * 1024;
         char *lb = smem + buf * STAGE + A_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const bool ok = (a_bits[i] & tapbits) == tapbits;
-            const uint32_t v = ok ? a_row[i] + delta : GG_OOB;
-            lds_dma16(rs_a, la + i * 4096, v, a_soff);
+            const bool ok = k_ok && (a_bits[i] & tapbits) == tapbits;
+            const uint32_t v = ok ? a_row[i] + delta + a_koff : GG_OOB;
+            lds_dma16(rs_a, la + i * 4096, v, 0);
         }
 #pragma unroll
-        for (int i = 0; i < RB; ++i) lds_dma16(rs_b, lb + i * 4096, b_row[i], b_soff);
+        for (int i = 0; i < RB; ++i)
+            lds_dma16(rs_b, lb + i * 4096, (k_ok && b_row[i] != GG_OOB) ? b_row[i] + b_koff : GG_OOB, b_soff);
     };
 
     f32x4_t acc[4][4];
@@ -365,8 +369,9 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32);
     const bool f32 = g->dtype == VN_F32;
     const int esz = f32 ? 4 : 2, bke = 128 / esz, align_e = 16 / esz;
-    if (g->Cs <= 0 || (g->Cs % bke) || g->Cr <= 0 || (g->Cr & 3)) return VN_EUNSUPPORTED;
-    if (g->src_wrap < 0 || (g->src_wrap & 63) || (g->src_wrap > 0 && (g->src_wrap >= g->Cs || f32))) return VN_EUNSUPPORTED;
+    (void)bke;
+    if (g->Cs <= 0 || (g->Cs % align_e) || g->Cr <= 0 || (g->Cr & 3)) return VN_EUNSUPPORTED;
+    if (g->src_wrap < 0 || (g->src_wrap % align_e) || (g->src_wrap > 0 && (g->src_wrap >= g->Cs || f32))) return VN_EUNSUPPORTED;
     if (g->divD * g->divH * g->divW > GG_MAX_CLASSES) return VN_EUNSUPPORTED;
     if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & (align_e - 1)) != 0) return VN_EUNSUPPORTED;   // 16-B chunks
     if (((g->out_sB | g->out_sD | g->out_sH | g->out_sW) & 3) != 0) return VN_EUNSUPPORTED;      // 8/16-B stores
