@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Benchmark of the VoxelNet training hot path on MI355X (BASELINE.json metric:
+point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2 per GPU).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One step = the reference's train step (train.py:148-155) on one batch of synthetic KITTI-shaped
+frames whose raw (N,4) point clouds are already resident in HBM:
+    voxelize (HIP) -> VFE x2 + max (HIP) -> sparse->dense scatter (HIP) -> 3 Conv3d + RPN (MFMA gather-GEMM)
+    -> loss (model.py:310-352) -> backward of all of it -> [N>1: bucketed RCCL all-reduce overlapped with
+    backward] -> clip_grad_norm_(5) -> SGD(lr=0.01) step -> zero_grad.
+Rank 0 prints ONE JSON line.  `roofline` is measured live (HIP events around every launch of the
+MFMA kernels during the timed steps); `cpu_baseline` times the oracle (PyTorch-CPU restatement of the
+reference's op sequence + the C voxelizer) on this box's host cores, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "voxelnet-pytorch_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+FLOP_PER_PC_FWD_BWD = 1732.3e9    # dense-equivalent conv/deconv/head FLOPs, fwd + bwd (x3)
+
+
+def synthetic_targets(B, h, w, seed, device):
+    """seeded pos/neg/targets maps with the shapes utils.generate_targets returns (model.py:309)"""
+    rng = np.random.default_rng(seed)
+    pos = (rng.random((B, h, w, 2)) < 0.002).astype(np.float32)
+    neg = ((rng.random((B, h, w, 2)) < 0.98) & (pos == 0)).astype(np.float32)
+    tgt = (rng.standard_normal((B, h, w, 14)) * 0.1).astype(np.float32)
+    return tuple(torch.from_numpy(a).to(device) for a in (pos, neg, tgt))
+
+
+def cpu_baseline(frames_np, threads):
+    """oracle (kind 'port'): C voxelizer + PyTorch-CPU fwd+bwd of the reference's op sequence, 1 frame"""
+    from oracle import torch_ref as tr
+    from oracle import voxelize as ov
+    torch.set_num_threads(threads)
+    cloud = frames_np[0]
+    t0 = time.perf_counter()
+    v = ov.voxelize(cloud, "Car")
+    f, _, c = ov.prepare_voxel([v])
+    feats, coords = [torch.from_numpy(f[0])], [torch.from_numpy(c[0])]
+    rng = np.random.default_rng(1)
+    dp = torch.from_numpy((rng.standard_normal((1, 2, 200, 176)) * 1e-2).astype(np.float32))
+    dr = torch.from_numpy((rng.standard_normal((1, 14, 200, 176)) * 1e-2).astype(np.float32))
+    tr.forward_backward(feats, coords, tr.make_state_dict("Car"), (10, 400, 352), "Car", dp, dr)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "point-clouds/s", "cores": threads, "kind": "port",
+            "sample": "1 step on 1 car frame (batch=1): C voxelizer + PyTorch-CPU fwd+bwd of the reference op "
+                      "sequence, %.1f s" % dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--batch", type=int, default=2, help="frames per GPU (BASELINE configs[1]: 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from voxelnet_amd import engine as E
+    from voxelnet_amd import model as M
+    from voxelnet_amd import parallel, synth
+    from voxelnet_amd.config import GRADIENT_CLIP, LR, grid_config
+    from voxelnet_amd.voxelize import voxelize_device
+
+    M.set_precision(args.precision)
+    torch.manual_seed(1234)                      # same initial weights on every rank
+    model = M.RPN3D("Car").to(dev)
+    model.train(True)                            # train.py:148
+    named = list(model.named_parameters())
+    params = [p for _, p in named]
+    opt = torch.optim.SGD(params, lr=LR)         # train.py:130
+    if world > 1:
+        for p in params:
+            dist.broadcast(p.data, 0)
+        model.grad_reducer = parallel.GradAllReducer(named)
+
+    B = args.batch
+    grid = grid_config("Car")
+    frames_np = synth.workload_frames(2, batch=B, frame0=rank * B)   # weak scaling: own frames per rank
+    frames = [torch.from_numpy(f).to(dev) for f in frames_np]       # resident in HBM before timing
+    h, w = model.rpn_output_shape
+    targets = synthetic_targets(B, h, w, 99 + rank, dev)
+
+    def step():
+        feats, coords = [], []
+        for b, pts in enumerate(frames):
+            f, c, _ = voxelize_device(pts, grid, b, coord_cols=4)
+            feats.append(f)
+            coords.append(c)
+        batch = (None, None, feats, None, coords, None, None)
+        out = model(batch, dev, targets=targets)
+        out[2].backward()                                                  # train.py:151
+        if model.grad_reducer is not None:
+            model.grad_reducer.finish(named)
+        torch.nn.utils.clip_grad_norm_(params, GRADIENT_CLIP)              # train.py:153
+        opt.step()                                                         # train.py:154
+        opt.zero_grad(set_to_none=True)                                    # train.py:155
+        return out[2]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    sync_all()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = E.KernelTimer()
+        E.TIMER = timer
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    E.TIMER = None
+    assert torch.isfinite(loss).item(), "non-finite loss"
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        value = world * B * args.steps / dt
+        res = {
+            "metric": "point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2",
+            "value": value, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
+            "config": {"workload": "KITTI car config (voxel 0.2x0.2x0.4 m, grid 10x400x352, T=35), batch=%d per GPU, "
+                                   "fwd+bwd train step (BASELINE configs[1])" % B,
+                       "global_batch": world * B, "points_per_frame": int(frames_np[0].shape[0]),
+                       "parallelism": "dp%d" % world,
+                       "step": "voxelize+VFE+scatter+Conv3d+RPN fwd, loss, bwd, clip_grad_norm, SGD"},
+            "model_flops_fraction_of_bf16_peak": value / world * FLOP_PER_PC_FWD_BWD / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+        }
+        if timer is not None:
+            summ = timer.summary()
+            kern = {}
+            for k, (n, fl, ms) in summ.items():
+                kern[k] = {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps,
+                           "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+            dom = max(summ, key=lambda k: summ[k][2])
+            n, fl, ms = summ[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            peak = PEAK_BF16_DENSE_TFLOPS if args.precision != "fp32" else 157.3
+            res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None,
+                               "avg_launch_us": 1e3 * ms / n, "launches": n,
+                               "note": "algorithmic (dense-equivalent) FLOPs of all launches / summed HIP-event time"}
+            res["kernels"] = kern
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                ncpu = len(os.sched_getaffinity(0))
+            except AttributeError:
+                ncpu = os.cpu_count() or 1
+            res["cpu_baseline"] = cpu_baseline(frames_np, max(1, min(ncpu, 16)))   # a 1-GPU box's CPU share is 16
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

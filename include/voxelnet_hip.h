@@ -160,12 +160,14 @@ typedef struct {
     int64_t out_sB, out_sD, out_sH, out_sW; /* row/output strides, elements */
 } vnConv;
 
-/* stats_sums: NULL, or double[2*Cr] receiving per-channel sum / sum of squares of
- * (out - bias) over the valid rows, accumulated with atomics (caller zeroes) —
- * the train-mode BatchNorm reduction fused into the epilogue. */
-int vn_conv_gather_gemm(const void *src /*bf16*/, const void *w_packed /*bf16 [taps][Cr][Cs]*/,
+/* stats_slab: NULL, or float[vn_conv_stats_slab_rows(geom)][2][Cr]: every workgroup
+ * writes the per-channel sum / sum of squares of (out - bias) over its valid rows
+ * (plain stores, deterministic) — the train-mode BatchNorm reduction fused into the
+ * epilogue; vn_bn_finalize_slab reduces it.  Only for div == 1 geometries. */
+int64_t vn_conv_stats_slab_rows(const vnConv *geom);
+int vn_conv_gather_gemm(const void *src, const void *w_packed /*[taps][Cr][Cs]*/,
                         const float *bias /*[Cr] or NULL*/, void *out, vnDtype out_dtype,
-                        const vnConv *geom, int32_t accumulate, double *stats_sums,
+                        const vnConv *geom, int32_t accumulate, float *stats_slab,
                         vnStream stream);
 
 /* Weight-gradient: dw[tap][n][k] += sum_m src[site(m,tap), k] * rows[m, n]
@@ -210,6 +212,10 @@ int vn_bn_stats(const void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stri
 int vn_bn_finalize(const double *sums, int64_t M, int32_t C, int32_t fold, const float *shift,
                    const float *gamma, const float *beta, float *running_mean, float *running_var,
                    int32_t training, float momentum, float eps, float *stats, vnStream stream);
+/* same, from a vn_conv_gather_gemm stats slab: float[rows][2][C] partial sums of (y - shift) */
+int vn_bn_finalize_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *shift,
+                        const float *gamma, const float *beta, float *running_mean, float *running_var,
+                        float momentum, float eps, float *stats, vnStream stream);
 /* a = relu?(S*(y-mean) + beta) -> f32 or bf16 rows.  lo_off != 0 (split mode): the
  * bf16 residual lo = bf16(a - hi) is also written, lo_off elements after hi. */
 int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C,

@@ -119,6 +119,46 @@ __global__ void __launch_bounds__(256) k_bn_finalize(const double *__restrict__ 
     }
 }
 
+// one workgroup per channel: sums the slab column pair in double, then the same epilogue as k_bn_finalize
+__global__ void __launch_bounds__(256) k_bn_finalize_slab(const float *__restrict__ slab, int64_t rows, int64_t M, int C,
+                                                          const float *__restrict__ shift,
+                                                          const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float *running_mean,
+                                                          float *running_var, float momentum, float eps,
+                                                          float *__restrict__ stats) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int64_t r = threadIdx.x; r < rows; r += 256) {
+        s1 += (double)slab[(r * 2 + 0) * C + c];
+        s2 += (double)slab[(r * 2 + 1) * C + c];
+    }
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)M;
+        const double ms = r1[0] / n;
+        double var = r2[0] / n - ms * ms;
+        if (var < 0.0) var = 0.0;
+        const double mean = ms + (shift ? (double)shift[c] : 0.0);
+        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        if (running_var) {
+            const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+        }
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        stats[c] = (float)mean;
+        stats[C + c] = invstd;
+        stats[2 * C + c] = gamma[c] * invstd;
+        stats[3 * C + c] = beta[c];
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, int ydt, int64_t ystride, int64_t M, int C,
                                                   const float *__restrict__ stats, int relu, void *__restrict__ a,
                                                   int adt, int64_t astride, int64_t lo_off) {
@@ -244,6 +284,16 @@ extern "C" int vn_bn_finalize(const double *sums, int64_t M, int32_t C, int32_t 
     VN_CHECK_ARG(training ? (sums != nullptr && M > 0) : (running_mean && running_var));
     k_bn_finalize<<<1, 256, 0, vn_stream(stream)>>>(sums, M, C, fold, shift, gamma, beta, running_mean, running_var,
                                                     training, momentum, eps, stats);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_finalize_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *shift,
+                                   const float *gamma, const float *beta, float *running_mean, float *running_var,
+                                   float momentum, float eps, float *stats, vnStream stream) {
+    VN_CHECK_ARG(slab && gamma && beta && stats && slab_rows > 0 && M > 0 && C > 0);
+    k_bn_finalize_slab<<<C, 256, 0, vn_stream(stream)>>>(slab, slab_rows, M, C, shift, gamma, beta, running_mean,
+                                                         running_var, momentum, eps, stats);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -23,7 +23,8 @@
 //   * Strided transposed gathers (ConvTranspose2d forward, data-gradient of a
 //     strided conv) run as residue classes (blockIdx.y) of stride-1 gathers.
 //   * Optional fused BatchNorm reduction: per-channel sum / sum of squares of
-//     the fp32 accumulators (before the bias is added) -> double atomics.
+//     the fp32 accumulators (before the bias is added), one partial row per
+//     workgroup in a slab (no atomics), reduced in double by vn_bn_finalize.
 #include "common.h"
 
 namespace {
@@ -47,7 +48,7 @@ struct GGParams {
     const char *w;
     const float *bias;
     char *out;
-    double *stats;
+    float *stats;               // [tiles_m][2][N] per-workgroup partial sums, or NULL
     int64_t sB, sD, sH, sW;   // elements
     int64_t oB, oD, oH, oW;
     int32_t B, Ds, Hs, Ws, Do, Ho, Wo;
@@ -298,7 +299,10 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         }
     }
     if (p.stats) {
-        // reduce over the 4 row groups (lane>>4) of the wave, then one double atomic per column per wave
+        // per-workgroup partial sums -> slab[tile_m][2][N] (plain stores, no atomics: thousands of waves adding
+        // into the same 2N addresses serialise at the memory side; vn_bn_finalize reduces the slab in double)
+        __syncthreads();                                  // otab reads done; reuse LDS
+        float *red = reinterpret_cast<float *>(smem);     // [2][BN] per M-wave group
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             s1[j] += __shfl_xor(s1[j], 16, 64);
@@ -306,12 +310,20 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
             s2[j] += __shfl_xor(s2[j], 16, 64);
             s2[j] += __shfl_xor(s2[j], 32, 64);
         }
-        if (fq == 0 && col_ok) {
+        if (fq == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                atomicAdd(p.stats + ncol + j, (double)s1[j]);
-                atomicAdd(p.stats + p.N + ncol + j, (double)s2[j]);
+                red[(wm * 2 + 0) * BN + wn * 64 + fr * 4 + j] = s1[j];
+                red[(wm * 2 + 1) * BN + wn * 64 + fr * 4 + j] = s2[j];
             }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+            const int which = i / BN, c = i - which * BN;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BN + c];
+            if (n0 + c < p.N) p.stats[((int64_t)tile_m * 2 + which) * p.N + n0 + c] = v;
         }
     }
 }
@@ -354,8 +366,14 @@ int axis_classes(int R, int k, int mul, int tmul, int pad, int div, AxisClass *o
 
 }  // namespace
 
+extern "C" int64_t vn_conv_stats_slab_rows(const vnConv *g) {
+    if (!g || g->divD != 1 || g->divH != 1 || g->divW != 1) return 0;
+    const int BM = g->Cr > 64 ? 128 : 256;
+    return vn_ceil_div((int64_t)g->B * g->Dr * g->Hr * g->Wr, BM);
+}
+
 extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const float *bias, void *out,
-                                   vnDtype out_dtype, const vnConv *g, int32_t accumulate, double *stats_sums,
+                                   vnDtype out_dtype, const vnConv *g, int32_t accumulate, float *stats_slab,
                                    vnStream stream) {
     VN_CHECK_ARG(src && w_packed && out && g);
     VN_CHECK_ARG(g->B > 0 && g->Ds > 0 && g->Hs > 0 && g->Ws > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0);
@@ -366,6 +384,7 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     VN_CHECK_ARG(g->divH == 1 || g->mulH == 1);
     VN_CHECK_ARG(g->divW == 1 || g->mulW == 1);
     VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
+    VN_CHECK_ARG(!stats_slab || (g->divD == 1 && g->divH == 1 && g->divW == 1));
     VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32);
     const bool f32 = g->dtype == VN_F32;
     const int esz = f32 ? 4 : 2, bke = 128 / esz, align_e = 16 / esz;
@@ -384,7 +403,7 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     p.w = static_cast<const char *>(w_packed);
     p.bias = bias;
     p.out = static_cast<char *>(out);
-    p.stats = stats_sums;
+    p.stats = stats_slab;
     p.sB = g->src_sB; p.sD = g->src_sD; p.sH = g->src_sH; p.sW = g->src_sW;
     p.oB = g->out_sB; p.oD = g->out_sD; p.oH = g->out_sH; p.oW = g->out_sW;
     p.B = g->B; p.Ds = g->Ds; p.Hs = g->Hs; p.Ws = g->Ws;

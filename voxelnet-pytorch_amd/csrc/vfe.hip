@@ -248,31 +248,51 @@ __global__ void __launch_bounds__(256) k_vfe_p3(const float *__restrict__ featur
     }
 }
 
-// sums slabs -> stats (train) or running stats -> stats (eval); one workgroup
+// block-wide sum of slab columns: pair (c, C + c) of every slab, in double (fixed order -> deterministic)
+__device__ __forceinline__ void slab_pair_sum(const float *__restrict__ slabs, int nslabs, int stride, int off, int C,
+                                              int c, double &o1, double &o2) {
+    __shared__ double r1[256], r2[256];
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = threadIdx.x; b < nslabs; b += 256) {
+        s1 += slabs[(size_t)b * stride + off + c];
+        s2 += slabs[(size_t)b * stride + off + C + c];
+    }
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    o1 = r1[0];
+    o2 = r2[0];
+}
+
+// slabs -> stats (train) or running stats -> stats (eval); one workgroup per channel
 __global__ void __launch_bounds__(256) k_vfe_finalize(const float *__restrict__ slabs, int nslabs, int slab_stride, int C,
                                                       int64_t rows,
                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
                                                       float *running_mean, float *running_var, int training,
                                                       float momentum, float eps, float *__restrict__ st) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double mean, var;
-        if (training) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int b = 0; b < nslabs; ++b) {
-                s1 += slabs[(size_t)b * slab_stride + c];
-                s2 += slabs[(size_t)b * slab_stride + C + c];
-            }
-            const double n = (double)rows;
-            mean = s1 / n;
-            var = s2 / n - mean * mean;
-            if (var < 0.0) var = 0.0;
+    const int c = blockIdx.x;
+    double mean, var;
+    if (training) {
+        double s1, s2;
+        slab_pair_sum(slabs, nslabs, slab_stride, 0, C, c, s1, s2);
+        const double n = (double)rows;
+        mean = s1 / n;
+        var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        if (threadIdx.x == 0) {
             running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
             const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
             running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
-        } else {
-            mean = running_mean[c];
-            var = running_var[c];
         }
+    } else {
+        mean = running_mean[c];
+        var = running_var[c];
+    }
+    if (threadIdx.x == 0) {
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         st[c] = (float)mean;
         st[C + c] = invstd;
@@ -338,18 +358,16 @@ __global__ void __launch_bounds__(256) k_vfe_b1(const float *__restrict__ featur
     slab_write(smem, vals, 2, lane, wave, slabs + (size_t)blockIdx.x * 128);
 }
 
-// BN backward finalize from slabs: coef = [c0|c1|c2], d_gamma, d_beta ; one workgroup
+// BN backward finalize from slabs: coef = [c0|c1|c2], d_gamma, d_beta ; one workgroup per channel
 __global__ void __launch_bounds__(256) k_vfe_bn_bwd_finalize(const float *__restrict__ slabs, int nslabs, int slab_stride,
                                                              int slab_off, int C, int64_t rows,
                                                              const float *__restrict__ gamma,
                                                              const float *__restrict__ st, float *__restrict__ coef,
                                                              float *__restrict__ d_gamma, float *__restrict__ d_beta) {
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int b = 0; b < nslabs; ++b) {
-            s1 += slabs[(size_t)b * slab_stride + slab_off + c];
-            s2 += slabs[(size_t)b * slab_stride + slab_off + C + c];
-        }
+    const int c = blockIdx.x;
+    double s1, s2;
+    slab_pair_sum(slabs, nslabs, slab_stride, slab_off, C, c, s1, s2);
+    if (threadIdx.x == 0) {
         const double n = (double)rows;
         const float invstd = st[C + c];
         const float S = gamma[c] * invstd;
@@ -532,14 +550,17 @@ __global__ void __launch_bounds__(256) k_vfe_b3(const float *__restrict__ featur
     slab_write(smem, vals, 2, lane, wave, slabs + (size_t)blockIdx.x * 128);
 }
 
-// out[i] = sum_b slabs[b*stride + off + i]  (double accumulation, fixed order)
+// out[i] = sum_b slabs[b*stride + off + i]  (double accumulation, fixed order); one wave per output element
 __global__ void __launch_bounds__(256) k_vfe_reduce(const float *__restrict__ slabs, int nslabs, int stride, int off,
                                                     int n, float *__restrict__ out) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
     if (i >= n) return;
     double s = 0.0;
-    for (int b = 0; b < nslabs; ++b) s += slabs[(size_t)b * stride + off + i];
-    out[i] = (float)s;
+    for (int b = lane; b < nslabs; b += 64) s += slabs[(size_t)b * stride + off + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[i] = (float)s;
 }
 
 struct Plan {
@@ -599,18 +620,18 @@ extern "C" int vn_vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVf
         VN_CHECK_ARG(K > 0);
         k_vfe_p1<<<pl.blocks, 256, pl.lds_small, st>>>(feature, K, T, P, slabs);
         VN_LAUNCH_STATUS();
-        k_vfe_finalize<<<1, 64, 0, st>>>(slabs, pl.blocks, 64, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 1, momentum, eps,
+        k_vfe_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, 64, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 1, momentum, eps,
                                          stats + ST1);
         VN_LAUNCH_STATUS();
         k_vfe_p2<<<pl.blocks, 256, pl.lds_full, st>>>(feature, K, T, P, stats, slabs);
         VN_LAUNCH_STATUS();
-        k_vfe_finalize<<<1, 64, 0, st>>>(slabs, pl.blocks, 128, C2, rows, w->g2, w->be2, w->rm2, w->rv2, 1, momentum, eps,
+        k_vfe_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, 128, C2, rows, w->g2, w->be2, w->rm2, w->rv2, 1, momentum, eps,
                                          stats + ST2);
         VN_LAUNCH_STATUS();
     } else {
-        k_vfe_finalize<<<1, 64, 0, st>>>(nullptr, 0, 0, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 0, momentum, eps, stats + ST1);
+        k_vfe_finalize<<<C1, 256, 0, st>>>(nullptr, 0, 0, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 0, momentum, eps, stats + ST1);
         VN_LAUNCH_STATUS();
-        k_vfe_finalize<<<1, 64, 0, st>>>(nullptr, 0, 0, C2, rows, w->g2, w->be2, w->rm2, w->rv2, 0, momentum, eps, stats + ST2);
+        k_vfe_finalize<<<C2, 256, 0, st>>>(nullptr, 0, 0, C2, rows, w->g2, w->be2, w->rm2, w->rv2, 0, momentum, eps, stats + ST2);
         VN_LAUNCH_STATUS();
     }
     if (K == 0) return VN_OK;
@@ -644,22 +665,22 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
     const int64_t rows = K * T;
     k_vfe_b1<<<pl.blocks, 256, pl.lds_full, st>>>(feature, K, T, P, stats, d_voxelwise, slabs);
     VN_LAUNCH_STATUS();
-    k_vfe_bn_bwd_finalize<<<1, 64, 0, st>>>(slabs, pl.blocks, 128, 0, C2, rows, w->g2, stats + ST2, coef2, g->dg2, g->dbe2);
+    k_vfe_bn_bwd_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, 128, 0, C2, rows, w->g2, stats + ST2, coef2, g->dg2, g->dbe2);
     VN_LAUNCH_STATUS();
     k_vfe_b2<<<pl.blocks, 256, pl.lds_full, st>>>(feature, K, T, P, stats, d_voxelwise, coef2, dp1, slabs);
     VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<1, 64, 0, st>>>(slabs, pl.blocks, SLAB_B2, 0, C2, g->db2);
+    k_vfe_reduce<<<C2 / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, 0, C2, g->db2);
     VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<(C2 * 32 + 255) / 256, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2, C2 * 32, g->dw2);
+    k_vfe_reduce<<<C2 * 32 / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2, C2 * 32, g->dw2);
     VN_LAUNCH_STATUS();
-    k_vfe_bn_bwd_finalize<<<1, 64, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2 + C2 * 32, C1, rows, w->g1, stats + ST1, coef1,
+    k_vfe_bn_bwd_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2 + C2 * 32, C1, rows, w->g1, stats + ST1, coef1,
                                             g->dg1, g->dbe1);
     VN_LAUNCH_STATUS();
     k_vfe_b3<<<pl.blocks, 256, pl.lds_small, st>>>(feature, K, T, P, stats, coef1, dp1, slabs);
     VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<1, 128, 0, st>>>(slabs, pl.blocks, 128, 0, C1 * CIN, g->dw1);
+    k_vfe_reduce<<<C1 * CIN / 4, 256, 0, st>>>(slabs, pl.blocks, 128, 0, C1 * CIN, g->dw1);
     VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<1, 64, 0, st>>>(slabs, pl.blocks, 128, C1 * CIN, C1, g->db1);
+    k_vfe_reduce<<<C1 / 4, 256, 0, st>>>(slabs, pl.blocks, 128, C1 * CIN, C1, g->db1);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -156,6 +156,51 @@ def pack_weight(w, spec, orient, mode):
     return packed
 
 
+class KernelTimer:
+    """bench.py's live per-kernel measurement: HIP events (torch.cuda.Event on the stream the kernels are
+    launched on) around every launch of the two MFMA kernels, with the launch's algorithmic FLOPs."""
+
+    def __init__(self):
+        self.records = []    # (kernel, flops, start_event, end_event)
+
+    def time(self, kernel, flops):
+        timer = self
+
+        class _Ctx:
+            def __enter__(self):
+                self.s = torch.cuda.Event(enable_timing=True)
+                self.e = torch.cuda.Event(enable_timing=True)
+                self.s.record()
+
+            def __exit__(self, *a):
+                self.e.record()
+                timer.records.append((kernel, flops, self.s, self.e))
+        return _Ctx()
+
+    def summary(self):
+        """-> {kernel: (launches, total_flops, total_ms)}; call after torch.cuda.synchronize()"""
+        out = {}
+        for k, fl, s, e in self.records:
+            n, f, t = out.get(k, (0, 0.0, 0.0))
+            out[k] = (n + 1, f + fl, t + s.elapsed_time(e))
+        return out
+
+
+TIMER = None   # set to a KernelTimer by bench.py
+
+
+class _NoCtx:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def _timed(kernel, flops):
+    return TIMER.time(kernel, flops) if TIMER is not None else _NoCtx()
+
+
 def gather_gemm(src, wp, bias, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dims, accumulate=False, stats=None):
     """out rows <- gather-GEMM of src rows (vn_conv_gather_gemm)."""
     split = src.lo_off != 0
@@ -163,9 +208,14 @@ def gather_gemm(src, wp, bias, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dim
         assert src.lo_off == src.C, "gather source must be [hi|lo] contiguous"
     g = _geom(src.B, src, row_dims, Cs * (3 if split else 1), 2 * Cs if split else 0, Cr, spec_k, mul, tmul, pad,
               div, out.strides)
-    _lib.call("vn_conv_gather_gemm", src.ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
-              out.ptr(), _dt(out.t), ctypes.byref(g), int(accumulate),
-              stats.data_ptr() if stats is not None else None, stream())
+    rows = src.B * row_dims[0] * row_dims[1] * row_dims[2]
+    # dense-equivalent model FLOPs of this launch: 2*MACs; a residue-class gather visits
+    # taps/prod(div) taps per row
+    flops = 2.0 * rows * Cr * Cs * (spec_k[0] * spec_k[1] * spec_k[2]) / (div[0] * div[1] * div[2])
+    with _timed("k_gather_gemm", flops):
+        _lib.call("vn_conv_gather_gemm", src.ptr(), wp.data_ptr(), bias.data_ptr() if bias is not None else None,
+                  out.ptr(), _dt(out.t), ctypes.byref(g), int(accumulate),
+                  stats.data_ptr() if stats is not None else None, stream())
 
 
 class LayerState:
@@ -191,13 +241,16 @@ def layer_forward(spec, x, params, buffers, training, mode, out=None, y_dtype=No
     if y_dtype is None:
         y_dtype = plain_dtype_of(mode)
     y = Rows(torch.empty((B,) + odims + (spec.cout,), dtype=y_dtype, device=dev), spec.cout)
-    fuse_stats = spec.bn and training
-    sums = torch.zeros(2 * spec.cout, dtype=torch.float64, device=dev) if fuse_stats else None
+    fuse_stats = spec.bn and training and not spec.transposed
+    slab = None
     if spec.transposed:
         mul, tmul, pad, div = (1, 1, 1), (-1, -1, -1), tuple(-p for p in spec.pad), spec.stride
     else:
         mul, tmul, pad, div = spec.stride, (1, 1, 1), spec.pad, (1, 1, 1)
-    gather_gemm(x, wp, bias, y, spec.k, spec.cin, spec.cout, mul, tmul, pad, div, odims, stats=sums)
+    if fuse_stats:
+        slab_rows = -(-y.M // (128 if spec.cout > 64 else 256))
+        slab = torch.empty((slab_rows, 2, spec.cout), dtype=torch.float32, device=dev)
+    gather_gemm(x, wp, bias, y, spec.k, spec.cin, spec.cout, mul, tmul, pad, div, odims, stats=slab)
     st = LayerState()
     st.spec, st.x, st.y, st.in_dims, st.out_dims = spec, x, y, x.dims, odims
     st.stats, st.a = None, None
@@ -205,9 +258,19 @@ def layer_forward(spec, x, params, buffers, training, mode, out=None, y_dtype=No
         return y, st
     M = y.M
     stats = torch.empty(4 * spec.cout, dtype=torch.float32, device=dev)
-    _lib.call("vn_bn_finalize", sums.data_ptr() if sums is not None else None, M, spec.cout, 1, bias.data_ptr(),
-              params["gamma"].data_ptr(), params["beta"].data_ptr(), buffers["running_mean"].data_ptr(),
-              buffers["running_var"].data_ptr(), int(training), BN_MOMENTUM, BN_EPS, stats.data_ptr(), stream())
+    if slab is not None:
+        _lib.call("vn_bn_finalize_slab", slab.data_ptr(), slab.shape[0], M, spec.cout, bias.data_ptr(),
+                  params["gamma"].data_ptr(), params["beta"].data_ptr(), buffers["running_mean"].data_ptr(),
+                  buffers["running_var"].data_ptr(), BN_MOMENTUM, BN_EPS, stats.data_ptr(), stream())
+    else:
+        sums = None
+        if training:   # ConvTranspose2d forward runs as residue classes: separate reduction pass over y
+            sums = torch.zeros(2 * spec.cout, dtype=torch.float64, device=dev)
+            _lib.call("vn_bn_stats", y.ptr(), _dt(y.t), M, spec.cout, y.row_stride(), 1, bias.data_ptr(),
+                      sums.data_ptr(), stream())
+        _lib.call("vn_bn_finalize", sums.data_ptr() if sums is not None else None, M, spec.cout, 1, bias.data_ptr(),
+                  params["gamma"].data_ptr(), params["beta"].data_ptr(), buffers["running_mean"].data_ptr(),
+                  buffers["running_var"].data_ptr(), int(training), BN_MOMENTUM, BN_EPS, stats.data_ptr(), stream())
     if bev_out:
         # model.py:262: (B,C,D,H,W).reshape(B,-1,H,W), channel = c*D + d.  Stored here as channel d*C + c
         # (block1.0's packed weights are permuted to match, LayerSpec.cin_fold).
@@ -266,11 +329,15 @@ def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=Fa
         grads["gamma"], grads["beta"] = dgamma, dbeta
     else:
         dy = da
-    # bias gradient = column sums of dy (hi + lo parts)
-    width = dy.t.shape[-1]
-    cs = torch.zeros(width, dtype=torch.float32, device=dev)
-    _lib.call("vn_col_sums", dy.ptr(), _dt(dy.t), dy.row_stride(), M, width, cs.data_ptr(), stream())
-    grads["bias"] = cs[:C] + cs[C:2 * C] if width == 2 * C else cs
+    if spec.bn:
+        # a bias in front of a train-mode BatchNorm has gradient sum_m dy = c0*sum(dz) + c1*sum(y-mean) + M*c2,
+        # which is identically 0 (the reference's autograd returns its fp32 rounding noise, ~1e-7 of |dy|)
+        grads["bias"] = torch.zeros(C, dtype=torch.float32, device=dev)
+    else:
+        width = dy.t.shape[-1]   # column sums of dy (hi + lo parts)
+        cs = torch.zeros(width, dtype=torch.float32, device=dev)
+        _lib.call("vn_col_sums", dy.ptr(), _dt(dy.t), dy.row_stride(), M, width, cs.data_ptr(), stream())
+        grads["bias"] = cs[:C] + cs[C:2 * C] if width == 2 * C else cs
     # weight gradient
     taps = spec.taps
     if spec.transposed:
@@ -278,14 +345,16 @@ def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=Fa
         dwp = torch.zeros((taps, spec.cin, spec.cout), dtype=torch.float32, device=dev)
         g = _geom(B, dy, st.in_dims, spec.cout, 0, spec.cin, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1),
                   x.strides)
-        _lib.call("vn_conv_wgrad", dy.ptr(), x.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), stream())
+        with _timed("k_wgrad", 2.0 * x.M * spec.cin * spec.cout * taps):
+            _lib.call("vn_conv_wgrad", dy.ptr(), x.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), stream())
         dw = torch.empty_like(params["weight"])
         _lib.call("vn_unpack_wgrad", dwp.data_ptr(), spec.cin, spec.cout, taps, 0, 1, dw.data_ptr(), stream())
     else:
         dwp = torch.zeros((taps, spec.cout, spec.cin), dtype=torch.float32, device=dev)
         g = _geom(B, x, st.out_dims, spec.cin, 0, spec.cout, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1),
                   dy.strides)
-        _lib.call("vn_conv_wgrad", x.ptr(), dy.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), stream())
+        with _timed("k_wgrad", 2.0 * dy.M * spec.cin * spec.cout * taps):
+            _lib.call("vn_conv_wgrad", x.ptr(), dy.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), stream())
         dw = torch.empty_like(params["weight"])
         _lib.call("vn_unpack_wgrad", dwp.data_ptr(), spec.cout, spec.cin, taps, 0, spec.cin_fold, dw.data_ptr(),
                   stream())

@@ -172,6 +172,11 @@ class VFELayer(nn.Module):
             "VFELayer runs fused inside FeatureLearningNet.forward on the HIP path (no standalone kernel)")
 
 
+VFE_KEYS = ["feature_net.vfe_1.fcn.0.weight", "feature_net.vfe_1.fcn.0.bias", "feature_net.vfe_1.bn.weight",
+            "feature_net.vfe_1.bn.bias", "feature_net.vfe_2.fcn.0.weight", "feature_net.vfe_2.fcn.0.bias",
+            "feature_net.vfe_2.bn.weight", "feature_net.vfe_2.bn.bias"]
+
+
 def _vfe_weights(fn):
     v1, v2 = fn.vfe_1, fn.vfe_2
     return [v1.fcn[0].weight, v1.fcn[0].bias, v1.bn.weight, v1.bn.bias,
@@ -412,15 +417,35 @@ class _DetectorFn(torch.autograd.Function):
             dense = scatter_rows(vw, coord, B, fn._grid.dims, mode)
             prob, reg, st = N.middle_forward(dense, P, Bf, mid._block1_stride, training, mode)
         ctx.saved = (feature, coord, stats, wst, vparams, st, P, names)
+        ctx.reducer = rpn.grad_reducer
         return prob, reg
 
     @staticmethod
     def backward(ctx, d_prob, d_reg):
         feature, coord, stats, wst, vparams, st, P, names = ctx.saved
+        red = ctx.reducer
+        on_grads = None
+        if red is not None:
+            def on_grads(name, g):
+                if name == "heads":
+                    hw, hb = g["weight"], g["bias"]
+                    red.grad_ready("middle_rpn.prob_conv.conv.weight", hw[:2])
+                    red.grad_ready("middle_rpn.prob_conv.conv.bias", hb[:2])
+                    red.grad_ready("middle_rpn.reg_conv.conv.weight", hw[2:])
+                    red.grad_ready("middle_rpn.reg_conv.conv.bias", hb[2:])
+                    return
+                cv = "deconv" if name.startswith("deconv") else "conv"
+                red.grad_ready(f"middle_rpn.{name}.{cv}.weight", g["weight"])
+                red.grad_ready(f"middle_rpn.{name}.{cv}.bias", g["bias"])
+                red.grad_ready(f"middle_rpn.{name}.batch_norm.weight", g["gamma"])
+                red.grad_ready(f"middle_rpn.{name}.batch_norm.bias", g["beta"])
         with torch.cuda.device(d_prob.device):
-            G, d_dense = N.middle_backward(st, d_prob.float(), d_reg.float(), P, need_dx=True)
+            G, d_dense = N.middle_backward(st, d_prob.float(), d_reg.float(), P, need_dx=True, on_grads=on_grads)
             d_vw = gather_rows(d_dense, coord, feature.shape[0], 128)
             vg = featnet_backward(feature, wst, stats, d_vw, vparams)
+            if red is not None:
+                for key, g in zip(VFE_KEYS, vg):
+                    red.grad_ready(key, g)
         return (None, None, None, None, None) + tuple(vg) + tuple(_middle_grads_flat(names, G))
 
 
@@ -447,6 +472,7 @@ class RPN3D(nn.Module):
         self.middle_rpn = MiddleConvNet(cls_name)
         self.rpn_output_shape = self.middle_rpn.output_shape
         self.target_fn = None    # callable(label, rpn_output_shape) -> (pos, neg, targets)
+        self.grad_reducer = None  # parallel.GradAllReducer: bucketed all-reduce overlapped with backward
 
     def detect(self, voxel_features, voxel_coordinates):
         """feature_net + middle_rpn (model.py:305-306), fused."""

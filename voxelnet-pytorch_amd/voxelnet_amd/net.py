@@ -82,8 +82,9 @@ def middle_forward(dense, P, Bf, block1_stride, training, mode):
     return prob, reg, st
 
 
-def middle_backward(st, d_prob, d_reg, P, need_dx=True):
-    """-> ({name: {weight,bias,gamma,beta}}, d_dense Rows (plain f32/bf16) or None)"""
+def middle_backward(st, d_prob, d_reg, P, need_dx=True, on_grads=None):
+    """-> ({name: {weight,bias,gamma,beta}}, d_dense Rows (plain f32/bf16) or None).
+    on_grads(layer_name, grads): called as soon as a layer's parameter gradients exist (DDP bucketing)."""
     mode = st.mode
     split = E.is_split(mode)
     L = st.layers
@@ -96,6 +97,8 @@ def middle_backward(st, d_prob, d_reg, P, need_dx=True):
     _lib.call("vn_heads_bwd", d_prob.contiguous().data_ptr(), d_reg.contiguous().data_ptr(), st.prob.data_ptr(), B,
               hf * wf, d_rows.ptr(), E._dt(d_rows.t), w16, int(split), E.stream())
     G["heads"], d_cat = E.layer_backward(L["heads"], d_rows, P["heads"], mode)
+    if on_grads is not None:
+        on_grads("heads", G["heads"])
 
     def dslice(off):
         return Rows(d_cat.t[..., off:off + 256], 256)
@@ -103,6 +106,8 @@ def middle_backward(st, d_prob, d_reg, P, need_dx=True):
     def back(name, da, **kw):
         g, dx = E.layer_backward(L[name], da, P[name], mode, **kw)
         G[name] = g
+        if on_grads is not None:
+            on_grads(name, g)
         return dx
 
     d = back("deconv3", dslice(0))
