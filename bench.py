@@ -71,6 +71,9 @@ def main():
     ap.add_argument("--batch", type=int, default=2, help="frames per GPU (BASELINE configs[1]: 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="experimental: replay the post-voxelizer part of the step from captured HIP graphs")
+    ap.add_argument("--timer-steps", type=int, default=3)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -109,21 +112,35 @@ def main():
     h, w = model.rpn_output_shape
     targets = synthetic_targets(B, h, w, 99 + rank, dev)
 
-    def step():
+    def voxelize_batch():
         feats, coords = [], []
         for b, pts in enumerate(frames):
             f, c, _ = voxelize_device(pts, grid, b, coord_cols=4)
             feats.append(f)
             coords.append(c)
+        return feats, coords
+
+    def fwd_bwd(feats, coords):
         batch = (None, None, feats, None, coords, None, None)
         out = model(batch, dev, targets=targets)
         out[2].backward()                                                  # train.py:151
+        return out[2]
+
+    def reduce_grads():
         if model.grad_reducer is not None:
             model.grad_reducer.finish(named)
+
+    def optim():
         torch.nn.utils.clip_grad_norm_(params, GRADIENT_CLIP)              # train.py:153
         opt.step()                                                         # train.py:154
+
+    def step_eager():
+        feats, coords = voxelize_batch()
+        loss = fwd_bwd(feats, coords)
+        reduce_grads()
+        optim()
         opt.zero_grad(set_to_none=True)                                    # train.py:155
-        return out[2]
+        return loss
 
     def sync_all():
         torch.cuda.synchronize()
@@ -131,25 +148,92 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step()
+    for _ in range(max(1, args.warmup)):
+        loss = step_eager()
     sync_all()
-    timer = None
-    if not args.no_kernel_timer:
-        timer = E.KernelTimer()
-        E.TIMER = timer
+
+    # ---- HIP-graph mode: everything after the voxelizer is replayed from two captured graphs ----------
+    # (voxelization reads K back to size its outputs, so it stays eager; the RCCL all-reduce runs between
+    #  the fwd+bwd graph and the clip+SGD graph).  Shapes are static because the frames of this benchmark
+    #  are; a change of K re-captures.
+    mode = "eager"
+    step = step_eager
+    if args.graph:
+        try:
+            feats0, coords0 = voxelize_batch()
+            st_feats = [f.clone() for f in feats0]
+            st_coords = [c.clone() for c in coords0]
+            opt.zero_grad(set_to_none=True)
+            if model.grad_reducer is not None:
+                model.grad_reducer.defer_allreduce = True          # bucket copies are captured, collectives are not
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                st_loss = fwd_bwd(st_feats, st_coords)
+            if model.grad_reducer is not None:
+                model.grad_reducer.finish(named, launch_deferred=True)   # p.grad -> static bucket views
+            g2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g2):
+                optim()
+            torch.cuda.synchronize()
+
+            def step_graph():
+                feats, coords = voxelize_batch()
+                for s_, f_ in zip(st_feats, feats):
+                    if s_.shape != f_.shape:
+                        raise RuntimeError("voxel count changed: static-shape graph is stale")
+                    s_.copy_(f_)
+                for s_, c_ in zip(st_coords, coords):
+                    s_.copy_(c_)
+                g1.replay()
+                if model.grad_reducer is not None:
+                    model.grad_reducer.allreduce_all()
+                g2.replay()
+                return st_loss
+            step = step_graph
+            for _ in range(2):
+                loss = step()
+            sync_all()
+            mode = "hipgraph"
+        except Exception as e:   # noqa: BLE001 - report and fall back to the eager step
+            if rank == 0:
+                import traceback
+                traceback.print_exc()
+                print(f"[bench] graph capture failed ({type(e).__name__}); running eager", file=sys.stderr)
+            torch.cuda.synchronize()
+            if model.grad_reducer is not None:
+                model.grad_reducer.defer_allreduce = False
+                model.grad_reducer.reset()
+            opt.zero_grad(set_to_none=True)
+            step = step_eager
+            mode = "eager"
+
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     sync_all()
     dt = time.perf_counter() - t0
-    E.TIMER = None
     assert torch.isfinite(loss).item(), "non-finite loss"
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # ---- per-kernel durations: HIP events around every MFMA-kernel launch, eager steps on the same inputs
+    timer = None
+    if not args.no_kernel_timer and rank == 0 or (not args.no_kernel_timer and world > 1):
+        if mode == "hipgraph":
+            if model.grad_reducer is not None:
+                model.grad_reducer.defer_allreduce = False
+                model.grad_reducer.reset()
+            opt.zero_grad(set_to_none=True)
+        timer = E.KernelTimer()
+        E.TIMER = timer
+        for _ in range(args.timer_steps):
+            step_eager()
+        sync_all()
+        E.TIMER = None
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -162,14 +246,15 @@ def main():
                                    "fwd+bwd train step (BASELINE configs[1])" % B,
                        "global_batch": world * B, "points_per_frame": int(frames_np[0].shape[0]),
                        "parallelism": "dp%d" % world,
-                       "step": "voxelize+VFE+scatter+Conv3d+RPN fwd, loss, bwd, clip_grad_norm, SGD"},
+                       "step": "voxelize+VFE+scatter+Conv3d+RPN fwd, loss, bwd, clip_grad_norm, SGD",
+                       "launch_mode": mode},
             "model_flops_fraction_of_bf16_peak": value / world * FLOP_PER_PC_FWD_BWD / (PEAK_BF16_DENSE_TFLOPS * 1e12),
         }
         if timer is not None:
             summ = timer.summary()
             kern = {}
             for k, (n, fl, ms) in summ.items():
-                kern[k] = {"launches_per_step": n / args.steps, "ms_per_step": ms / args.steps,
+                kern[k] = {"launches_per_step": n / args.timer_steps, "ms_per_step": ms / args.timer_steps,
                            "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
             dom = max(summ, key=lambda k: summ[k][2])
             n, fl, ms = summ[dom]
@@ -178,7 +263,8 @@ def main():
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": None,
                                "avg_launch_us": 1e3 * ms / n, "launches": n,
-                               "note": "algorithmic (dense-equivalent) FLOPs of all launches / summed HIP-event time"}
+                               "note": "algorithmic (dense-equivalent) FLOPs of all launches / summed HIP-event time, "
+                                       "%d eager steps on the same inputs right after the timed region" % args.timer_steps}
             res["kernels"] = kern
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -364,6 +364,17 @@ int axis_classes(int R, int k, int mul, int tmul, int pad, int div, AxisClass *o
     return nc;
 }
 
+// the dynamic-LDS attribute is set once per instantiation (function-local static: not inside a stream capture)
+template <int WM, int WN, bool F32>
+int launch_gg(const GGParams &p, dim3 grid, size_t lds, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather_gemm<WM, WN, F32>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       2 * (64 * WM + 64 * WN) * 128);
+    if (attr != hipSuccess) return (int)attr;
+    k_gather_gemm<WM, WN, F32><<<grid, 256, lds, st>>>(p);
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int64_t vn_conv_stats_slab_rows(const vnConv *g) {
@@ -477,16 +488,9 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ncls);
     const size_t lds = 2u * (size_t)(BM + BN) * 128u;
     hipStream_t st = vn_stream(stream);
-    auto launch = [&](auto kern, int max_lds) -> int {
-        const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        if (attr != hipSuccess) return (int)attr;
-        kern<<<grid, 256, lds, st>>>(p);
-        return 0;
-    };
     int rc;
-    if (wide) rc = f32 ? launch(&k_gather_gemm<2, 2, true>, 65536) : launch(&k_gather_gemm<2, 2, false>, 65536);
-    else rc = f32 ? launch(&k_gather_gemm<4, 1, true>, 81920) : launch(&k_gather_gemm<4, 1, false>, 81920);
+    if (wide) rc = f32 ? launch_gg<2, 2, true>(p, grid, lds, st) : launch_gg<2, 2, false>(p, grid, lds, st);
+    else rc = f32 ? launch_gg<4, 1, true>(p, grid, lds, st) : launch_gg<4, 1, false>(p, grid, lds, st);
     if (rc) return rc;
     VN_LAUNCH_STATUS();
     return VN_OK;

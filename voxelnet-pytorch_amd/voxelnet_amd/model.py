@@ -492,7 +492,7 @@ class RPN3D(nn.Module):
         def f32(a):
             return (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev).float()
         pos, neg, tgt = f32(pos_equal_one), f32(neg_equal_one), f32(targets)
-        pos_reg = torch.cat([pos[..., [0]].expand(-1, -1, -1, 7), pos[..., [1]].expand(-1, -1, -1, 7)], -1)
+        pos_reg = torch.cat([pos[..., 0:1].expand(-1, -1, -1, 7), pos[..., 1:2].expand(-1, -1, -1, 7)], -1)
         pos_sum = pos.sum(dim=(1, 2, 3)).reshape(-1, 1, 1, 1).clamp(min=1)
         neg_sum = neg.sum(dim=(1, 2, 3)).reshape(-1, 1, 1, 1).clamp(min=1)
         pos_c, neg_c = pos.permute(0, 3, 1, 2), neg.permute(0, 3, 1, 2)

@@ -62,6 +62,7 @@ class GradAllReducer:
         assert not missing, f"parameters without a bucket: {missing[:3]}"
         self.cuda = self.buckets[0]["flat"].is_cuda
         self.comm_stream = torch.cuda.Stream() if (self.cuda and use_side_stream) else None
+        self.defer_allreduce = False   # True: grad_ready only fills the buckets (HIP-graph capture); allreduce_all() later
         self.reset()
 
     def reset(self):
@@ -78,7 +79,7 @@ class GradAllReducer:
             self._launch(b)
 
     def _launch(self, b):
-        if self.world == 1:
+        if self.world == 1 or self.defer_allreduce:
             return
         flat = b["flat"]
         if self.comm_stream is not None:
@@ -92,7 +93,18 @@ class GradAllReducer:
             flat.div_(self.world)
             b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
-    def finish(self, named_params):
+    def allreduce_all(self):
+        """deferred mode: all-reduce every (already filled) bucket now, largest first, and wait"""
+        if self.world == 1:
+            return
+        hs = []
+        for b in self.buckets:
+            b["flat"].div_(self.world)
+            hs.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        for h in hs:
+            h.wait()
+
+    def finish(self, named_params, launch_deferred=False):
         """wait for every bucket and point .grad of each parameter at its averaged view"""
         for b in self.buckets:
             assert not b["pending"], f"bucket never completed: {sorted(b['pending'])[:3]}"
