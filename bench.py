@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="experimental: replay the post-voxelizer part of the step from captured HIP graphs")
     ap.add_argument("--timer-steps", type=int, default=3)
+    ap.add_argument("--static-voxels", action="store_true",
+                    help="diagnostic: voxelize once, outside the timed steps (NOT the benchmark configuration)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +93,7 @@ def main():
     from voxelnet_amd import model as M
     from voxelnet_amd import parallel, synth
     from voxelnet_amd.config import GRADIENT_CLIP, LR, grid_config
-    from voxelnet_amd.voxelize import voxelize_device
+    from voxelnet_amd.voxelize import voxelize_device_async
 
     M.set_precision(args.precision)
     torch.manual_seed(1234)                      # same initial weights on every rank
@@ -112,12 +114,37 @@ def main():
     h, w = model.rpn_output_shape
     targets = synthetic_targets(B, h, w, 99 + rank, dev)
 
+    # Voxelization is software-pipelined one step ahead on its own HIP stream (the input-pipeline stage of the
+    # step): the K read-back that sizes its outputs (utils.py:69-71 returns (K,T,7)/(K,3)/(K,) arrays) then only
+    # never stalls the training queue (capacity-sized outputs, K read by the gather kernel from device memory,
+    # asynchronous K copy to pinned memory: voxelize_device_async).  Every timed step still runs one
+    # voxelization of its B frames (for the next step) and one train step (on the buffers voxelized during the
+    # previous one).
+    vox_stream = torch.cuda.Stream()
+    pending = {}
+
+    def launch_voxelize():
+        with torch.cuda.stream(vox_stream):
+            pending["next"] = [voxelize_device_async(pts, grid, b, coord_cols=4) for b, pts in enumerate(frames)]
+
     def voxelize_batch():
+        if args.static_voxels and "static" in pending:
+            return pending["static"]
+        if "next" not in pending:
+            launch_voxelize()
+        handles = pending.pop("next")
         feats, coords = [], []
-        for b, pts in enumerate(frames):
-            f, c, _ = voxelize_device(pts, grid, b, coord_cols=4)
+        for hdl in handles:
+            f, c, _ = hdl.result()                       # waits for the (long finished) K copy only
             feats.append(f)
             coords.append(c)
+        torch.cuda.current_stream().wait_event(handles[-1].event)
+        for t in feats + coords:
+            t.record_stream(torch.cuda.current_stream())
+        launch_voxelize()
+        if args.static_voxels:
+            torch.cuda.synchronize()
+            pending["static"] = (feats, coords)
         return feats, coords
 
     def fwd_bwd(feats, coords):
@@ -212,6 +239,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
+    t_enq = time.perf_counter() - t0       # host time to enqueue the K steps (the GPU may still be running)
     sync_all()
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss).item(), "non-finite loss"
@@ -248,6 +276,7 @@ def main():
                        "parallelism": "dp%d" % world,
                        "step": "voxelize+VFE+scatter+Conv3d+RPN fwd, loss, bwd, clip_grad_norm, SGD",
                        "launch_mode": mode},
+            "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "model_flops_fraction_of_bf16_peak": value / world * FLOP_PER_PC_FWD_BWD / (PEAK_BF16_DENSE_TFLOPS * 1e12),
         }
         if timer is not None:

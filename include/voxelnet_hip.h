@@ -67,12 +67,15 @@ int vn_voxelize_index(const float *points /*[N,4]*/, int64_t n_points,
  * input order, centroid offsets on all T slots (float64 divide/subtract as
  * numpy promotes), int64 coordinates with `coord_cols` = 3 (z,y,x) or
  * 4 (batch_index,z,y,x; prepare_voxel's padding), int64 counts.
- * Deterministic: no order-dependent atomics reach the outputs. */
+ * Deterministic: no order-dependent atomics reach the outputs.
+ * k_dev == NULL: K is the exact row count (read back from phase 1).  k_dev != NULL
+ * (phase 1's k_out): K is only the CAPACITY of the output buffers (any K <= n_points
+ * fits) and rows >= *k_dev are left untouched — no host read-back between the phases. */
 int vn_voxelize_gather(const float *points, int64_t n_points, const vnGrid *grid,
                        void *workspace, size_t workspace_bytes, int64_t K,
                        int64_t batch_index, int32_t coord_cols,
                        float *feature /*[K,T,7]*/, int64_t *coord /*[K,coord_cols]*/,
-                       int64_t *number /*[K]*/, vnStream stream);
+                       int64_t *number /*[K]*/, const int32_t *k_dev, vnStream stream);
 
 /* ------------------------------------------------------------------------
  * Voxel feature encoder — FeatureLearningNet.forward up to the scatter
@@ -178,6 +181,30 @@ int vn_conv_gather_gemm(const void *src, const void *w_packed /*[taps][Cr][Cs]*/
  * geom->Cs is the real C here and geom->src_wrap is ignored. */
 int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16*/, float *dw_packed,
                   const vnConv *geom, int32_t split, vnStream stream);
+
+/* Row-list ("sparse rows") variants for the first middle layer, whose input grid is ~99 % empty:
+ * the produced rows are an explicit list of (b,d,h,w) int64 coordinates instead of the dense
+ * (B,Dr,Hr,Wr) grid.  row_count (device int32, may be NULL = row_cap) lets the launch be sized by a
+ * capacity known on the host while the true count stays on the device.  out_linear != 0: output row i is
+ * written at out + i*out_sW (e.g. the (K,128) voxel gradient); else at the site given by the coordinates.
+ * Any div (strided transposed gather) is allowed.  In vn_conv_wgrad_rows the rows operand is the
+ * [n_rows][Cr] matrix of the list rows (stride out_sW) and dw is [taps][Cr][Cs]. */
+int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, const float *bias, void *out,
+                             vnDtype out_dtype, const vnConv *geom, const int64_t *row_list,
+                             int64_t row_cap, const int32_t *row_count, int32_t out_linear,
+                             float *stats_slab, vnStream stream);
+int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_packed, const vnConv *geom,
+                       const int64_t *row_list, int64_t n_rows, vnStream stream);
+/* Active output sites of a forward conv over a sparse input: the ordered (b,d,h,w) list of the sites
+ * whose receptive field contains at least one of the K occupied voxel coordinates (coord (K,4) int64
+ * [b,z,y,x]).  geom = the conv's forward geometry.  list holds up to cap rows; *count = min(n, cap).
+ * Deterministic order (ascending linear site index). */
+size_t vn_active_sites_workspace_bytes(const vnConv *geom);
+int vn_active_sites(const int64_t *coord, int64_t K, const vnConv *geom, void *workspace,
+                    size_t workspace_bytes, int64_t *list, int64_t cap, int32_t *count, vnStream stream);
+/* y[m][0:C] = values[0:C] for M rows (the conv output at inactive sites is the bias) */
+int vn_fill_rows(void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stride, const float *values,
+                 vnStream stream);
 
 /* Packing between torch parameter layouts and the kernels' [taps][N][K] bf16.
  * mode 0: Conv weight (Cout,Cin,k...) -> forward operand   [tap][Cout][Cin]

@@ -57,6 +57,13 @@ struct GGParams {
     int32_t esz;                // operand element size: 2 (bf16) or 4 (fp32, exact v_mfma_f32_16x16x4_f32 path)
     uint32_t w_bytes;
     int64_t src_batch_extent;   // elements spanned by one batch item (for num_records)
+    // row-list mode (sparse first Conv3d): rows are an explicit list of (b,d,h,w) coordinates
+    const int64_t *row_list;    // [row_cap][4] int64, or NULL (dense rows)
+    const int32_t *row_count;   // device: number of valid list rows, or NULL (= row_cap)
+    int32_t row_cap;
+    int32_t out_linear;         // list mode: output row offset = row index * oW (else from the coordinates)
+    int32_t ldivD, ldivH, ldivW;             // list mode: row coordinate = div*q + r
+    int32_t slotcD[4], slotcH[4], slotcW[4]; // list mode: residue r a row must have for offset slot j (-1: any)
     GGClass cls[GG_MAX_CLASSES];
     GGTap taps[GG_MAX_TAPS];
 };
@@ -90,12 +97,20 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     }
     const int tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
     const int qD = cl.qD, qH = cl.qH, qW = cl.qW;
-    const int64_t Mq = (int64_t)p.B * qD * qH * qW;
+    const bool list = p.row_list != nullptr;
+    const int64_t Mq = list ? (p.row_count ? (int64_t)p.row_count[0] : (int64_t)p.row_cap) : (int64_t)p.B * qD * qH * qW;
     const int64_t m0 = (int64_t)tile_m * BM;
-    if (m0 >= Mq) return;   // block-uniform
     const int n0 = tile_n * BN;
+    if (m0 >= Mq) {   // block-uniform
+        if (p.stats)    // capacity launch: the slab rows of empty tiles must read as zero
+            for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+                const int which = i / BN, c = i - which * BN;
+                if (n0 + c < p.N) p.stats[((int64_t)tile_m * 2 + which) * p.N + n0 + c] = 0.f;
+            }
+        return;
+    }
     const int rows_per_b = qD * qH * qW;
-    const int b0 = (int)(m0 / rows_per_b);
+    const int b0 = list ? 0 : (int)(m0 / rows_per_b);
 
     // ---- per-lane loader state ----
     // A rows: instruction i of this wave covers LDS rows ((i*4+wave)*8 .. +7); lane -> row +(lane>>3), slot lane&7
@@ -108,7 +123,24 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         const int64_t m = m0 + r;
         a_row[i] = GG_OOB;
         a_bits[i] = 0;
-        if (m < Mq) {
+        if (m < Mq && list) {
+            const int64_t *rc = p.row_list + m * 4;
+            const int db = (int)rc[0], cd = (int)rc[1], ch = (int)rc[2], cw = (int)rc[3];
+            const int qd = cd / p.ldivD, rd = cd - qd * p.ldivD;
+            const int qh = ch / p.ldivH, rh = ch - qh * p.ldivH;
+            const int qw = cw / p.ldivW, rw = cw - qw * p.ldivW;
+            const int sd = qd * p.mulD, sh = qh * p.mulH, sw = qw * p.mulW;
+            const int64_t e = (int64_t)db * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW;
+            a_row[i] = (uint32_t)(e * ESZ);
+            uint32_t bits = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bits |= (((p.slotcD[j] < 0 || p.slotcD[j] == rd) && (uint32_t)(sd + cl.offD[j]) < (uint32_t)p.Ds) ? 1u : 0u) << j;
+                bits |= (((p.slotcH[j] < 0 || p.slotcH[j] == rh) && (uint32_t)(sh + cl.offH[j]) < (uint32_t)p.Hs) ? 1u : 0u) << (4 + j);
+                bits |= (((p.slotcW[j] < 0 || p.slotcW[j] == rw) && (uint32_t)(sw + cl.offW[j]) < (uint32_t)p.Ws) ? 1u : 0u) << (8 + j);
+            }
+            a_bits[i] = bits;
+        } else if (m < Mq) {
             int t = (int)(m - (int64_t)b0 * rows_per_b);   // row index relative to batch b0 (may span batches)
             const int db = t / rows_per_b;
             t -= db * rows_per_b;
@@ -239,7 +271,14 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     for (int r = threadIdx.x; r < BM; r += 256) {
         const int64_t m = m0 + r;
         int32_t off = -1;
-        if (m < Mq) {
+        if (m < Mq && list) {
+            if (p.out_linear) {
+                off = (int32_t)(m * p.oW);
+            } else {
+                const int64_t *rc = p.row_list + m * 4;
+                off = (int32_t)(rc[0] * p.oB + rc[1] * p.oD + rc[2] * p.oH + rc[3] * p.oW);
+            }
+        } else if (m < Mq) {
             int t = (int)(m % rows_per_b);
             const int b = (int)(m / rows_per_b);
             const int qw = t % qW;
@@ -375,7 +414,116 @@ int launch_gg(const GGParams &p, dim3 grid, size_t lds, hipStream_t st) {
     return 0;
 }
 
+// list-mode slots of one axis: every (residue r, tap t) with (r + t*tmul - pad) divisible by div
+struct AxisSlots {
+    int n, cls[4], off[4], tap[4];
+};
+bool axis_slots(int k, int tmul, int pad, int div, AxisSlots *o) {
+    o->n = 0;
+    for (int r = 0; r < div; ++r)
+        for (int t = 0; t < k; ++t) {
+            const int num = r + t * tmul - pad;
+            if (posmod(num, div) != 0) continue;
+            if (o->n >= 4) return false;
+            o->cls[o->n] = div == 1 ? -1 : r;
+            o->off[o->n] = floordiv(num, div);
+            o->tap[o->n] = t;
+            ++o->n;
+        }
+    return o->n > 0;
+}
+
 }  // namespace
+
+extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, const float *bias, void *out,
+                                        vnDtype out_dtype, const vnConv *g, const int64_t *row_list, int64_t row_cap,
+                                        const int32_t *row_count, int32_t out_linear, float *stats_slab,
+                                        vnStream stream) {
+    VN_CHECK_ARG(src && w_packed && out && g && row_list && row_cap >= 0 && row_cap < (1ll << 31));
+    if (row_cap == 0) return VN_OK;
+    VN_CHECK_ARG(g->B > 0 && g->Ds > 0 && g->Hs > 0 && g->Ws > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0);
+    VN_CHECK_ARG(g->kD >= 1 && g->kD <= 4 && g->kH >= 1 && g->kH <= 4 && g->kW >= 1 && g->kW <= 4);
+    VN_CHECK_ARG(g->divD >= 1 && g->divH >= 1 && g->divW >= 1);
+    VN_CHECK_ARG((g->divD == 1 || g->mulD == 1) && (g->divH == 1 || g->mulH == 1) && (g->divW == 1 || g->mulW == 1));
+    VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
+    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32);
+    const bool f32 = g->dtype == VN_F32;
+    const int esz = f32 ? 4 : 2, align_e = 16 / esz;
+    if (g->Cs <= 0 || (g->Cs % align_e) || g->Cr <= 0 || (g->Cr & 3) || g->src_wrap != 0) return VN_EUNSUPPORTED;
+    if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & (align_e - 1)) != 0) return VN_EUNSUPPORTED;
+    if (((g->out_sB | g->out_sD | g->out_sH | g->out_sW) & 3) != 0) return VN_EUNSUPPORTED;
+    GGParams p{};
+    p.src = static_cast<const char *>(src);
+    p.w = static_cast<const char *>(w_packed);
+    p.bias = bias;
+    p.out = static_cast<char *>(out);
+    p.stats = stats_slab;
+    p.sB = g->src_sB; p.sD = g->src_sD; p.sH = g->src_sH; p.sW = g->src_sW;
+    p.oB = g->out_sB; p.oD = g->out_sD; p.oH = g->out_sH; p.oW = g->out_sW;
+    p.B = g->B; p.Ds = g->Ds; p.Hs = g->Hs; p.Ws = g->Ws;
+    p.Do = g->Dr; p.Ho = g->Hr; p.Wo = g->Wr;
+    p.Cs = g->Cs; p.src_wrap = 0; p.N = g->Cr;
+    p.out_f32 = out_dtype == VN_F32;
+    p.src_row_elems = g->Cs;
+    p.esz = esz;
+    const int taps_total = g->kD * g->kH * g->kW;
+    const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * esz;
+    if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;
+    p.w_bytes = (uint32_t)wb;
+    p.src_batch_extent = (int64_t)(g->Ds - 1) * g->src_sD + (int64_t)(g->Hs - 1) * g->src_sH +
+                         (int64_t)(g->Ws - 1) * g->src_sW + g->Cs;
+    // list rows may come from any batch item: the whole source tensor must fit one 32-bit window
+    if (((int64_t)(g->B - 1) * g->src_sB + p.src_batch_extent) * esz > (int64_t)GG_MAX_WINDOW - 4096) return VN_EUNSUPPORTED;
+    const int64_t out_extent = out_linear ? row_cap * g->out_sW
+                                          : (int64_t)(g->B - 1) * g->out_sB + (int64_t)(g->Dr - 1) * g->out_sD +
+                                                (int64_t)(g->Hr - 1) * g->out_sH + (int64_t)(g->Wr - 1) * g->out_sW + g->Cr;
+    if (out_extent >= (1ll << 31)) return VN_EUNSUPPORTED;
+    AxisSlots sd, sh, sw;
+    if (!axis_slots(g->kD, g->tmulD, g->padD, g->divD, &sd) || !axis_slots(g->kH, g->tmulH, g->padH, g->divH, &sh) ||
+        !axis_slots(g->kW, g->tmulW, g->padW, g->divW, &sw))
+        return VN_EUNSUPPORTED;
+    if (sd.n * sh.n * sw.n > GG_MAX_TAPS) return VN_EUNSUPPORTED;
+    p.row_list = row_list;
+    p.row_count = row_count;
+    p.row_cap = (int32_t)row_cap;
+    p.out_linear = out_linear;
+    p.ldivD = g->divD; p.ldivH = g->divH; p.ldivW = g->divW;
+    p.mulD = g->divD == 1 ? g->mulD : 1;
+    p.mulH = g->divH == 1 ? g->mulH : 1;
+    p.mulW = g->divW == 1 ? g->mulW : 1;
+    p.omulD = p.omulH = p.omulW = 1;
+    GGClass &c = p.cls[0];
+    c.tap_begin = 0;
+    c.qD = c.qH = c.qW = 1;
+    c.ooffD = c.ooffH = c.ooffW = 0;
+    for (int j = 0; j < 4; ++j) {
+        c.offD[j] = j < sd.n ? sd.off[j] : (1 << 29);
+        c.offH[j] = j < sh.n ? sh.off[j] : (1 << 29);
+        c.offW[j] = j < sw.n ? sw.off[j] : (1 << 29);
+        p.slotcD[j] = j < sd.n ? sd.cls[j] : -2;
+        p.slotcH[j] = j < sh.n ? sh.cls[j] : -2;
+        p.slotcW[j] = j < sw.n ? sw.cls[j] : -2;
+    }
+    int ntap = 0;
+    for (int i = 0; i < sd.n; ++i)
+        for (int j = 0; j < sh.n; ++j)
+            for (int k = 0; k < sw.n; ++k)
+                p.taps[ntap++] = GGTap{i, j, k, (sd.tap[i] * g->kH + sh.tap[j]) * g->kW + sw.tap[k]};
+    c.ntaps = ntap;
+    p.nclasses = 1;
+    const bool wide = g->Cr > 64;
+    const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+    const int64_t tiles_m = vn_ceil_div(row_cap, BM), tiles_n = vn_ceil_div(g->Cr, BN);
+    const dim3 grid((unsigned)(tiles_m * tiles_n), 1);
+    const size_t lds = 2u * (size_t)(BM + BN) * 128u;
+    hipStream_t st = vn_stream(stream);
+    int rc;
+    if (wide) rc = f32 ? launch_gg<2, 2, true>(p, grid, lds, st) : launch_gg<2, 2, false>(p, grid, lds, st);
+    else rc = f32 ? launch_gg<4, 1, true>(p, grid, lds, st) : launch_gg<4, 1, false>(p, grid, lds, st);
+    if (rc) return rc;
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
 
 extern "C" int64_t vn_conv_stats_slab_rows(const vnConv *g) {
     if (!g || g->divD != 1 || g->divH != 1 || g->divW != 1) return 0;

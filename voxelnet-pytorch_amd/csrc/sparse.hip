@@ -1,0 +1,197 @@
+// Sparsity support for the first middle layer (ConvMD(3,128,64,3,(2,1,1),(1,1,1)), model.py:207).
+// Its input is the scattered voxel grid (model.py:102-106): ~6k occupied of 1.4 M sites per sample, so
+//   * its forward differs from the bias only at output sites with an occupied voxel in their 3x3x3
+//     receptive field ("active" sites, <= 18 per voxel),
+//   * its weight gradient and the only part of its data gradient anybody reads (the rows the scatter's
+//     backward gathers) are sums over the occupied voxels.
+// This file builds the active-site list: mark (one thread per voxel x tap) + ORDERED compaction
+// (block counts -> single-block exclusive scan -> per-block write), so the list order — and with it every
+// downstream fp32 summation order — is deterministic.  The row-list modes of the two MFMA kernels
+// (conv.hip, wgrad.hip) consume it.  HBM-bound, tiny: 1.4 MB of flags per batch item pair.
+#include "common.h"
+
+namespace {
+
+constexpr int AS_THREADS = 256, AS_ITEMS = 8, AS_TILE = AS_THREADS * AS_ITEMS;
+
+struct ASGeom {
+    int32_t B, Do, Ho, Wo;
+    int32_t kD, kH, kW, sD, sH, sW, pD, pH, pW;
+};
+
+__global__ void __launch_bounds__(256) k_mark(const int64_t *__restrict__ coord, int64_t K, ASGeom g,
+                                              uint8_t *__restrict__ flags) {
+    const int taps = g.kD * g.kH * g.kW;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K * taps) return;
+    const int64_t v = i / taps;
+    const int t = (int)(i - v * taps);
+    const int td = t / (g.kH * g.kW), th = (t / g.kW) % g.kH, tw = t % g.kW;
+    const int64_t *c = coord + v * 4;
+    const int b = (int)c[0];
+    const int nd = (int)c[1] + g.pD - td, nh = (int)c[2] + g.pH - th, nw = (int)c[3] + g.pW - tw;
+    if (nd < 0 || nh < 0 || nw < 0 || nd % g.sD || nh % g.sH || nw % g.sW) return;
+    const int od = nd / g.sD, oh = nh / g.sH, ow = nw / g.sW;
+    if (b < 0 || b >= g.B || od >= g.Do || oh >= g.Ho || ow >= g.Wo) return;
+    flags[(((int64_t)b * g.Do + od) * g.Ho + oh) * g.Wo + ow] = 1;
+}
+
+__device__ int block_excl_scan_i32(int v, int *total) {
+    __shared__ int wsum[AS_THREADS / 64];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < AS_THREADS / 64; ++w) {
+        const int s = wsum[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(AS_THREADS) k_as_count(const uint8_t *__restrict__ flags, int64_t n,
+                                                         int32_t *__restrict__ blk) {
+    const int64_t base = (int64_t)blockIdx.x * AS_TILE + (int64_t)threadIdx.x * AS_ITEMS;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < AS_ITEMS; ++j)
+        if (base + j < n) s += flags[base + j] ? 1 : 0;
+    int tot;
+    block_excl_scan_i32(s, &tot);
+    if (threadIdx.x == 0) blk[blockIdx.x] = tot;
+}
+
+__global__ void __launch_bounds__(AS_THREADS) k_as_scan(int32_t *__restrict__ blk, int64_t nb, int64_t cap,
+                                                        int32_t *__restrict__ count) {
+    int carry = 0;
+    for (int64_t base = 0; base < nb; base += AS_THREADS) {
+        const int64_t i = base + threadIdx.x;
+        const int v = i < nb ? blk[i] : 0;
+        int tot;
+        const int ex = block_excl_scan_i32(v, &tot);
+        if (i < nb) blk[i] = carry + ex;
+        carry += tot;
+    }
+    if (threadIdx.x == 0) count[0] = carry < cap ? carry : (int32_t)cap;
+}
+
+__global__ void __launch_bounds__(AS_THREADS) k_as_write(const uint8_t *__restrict__ flags, int64_t n,
+                                                         const int32_t *__restrict__ blk, ASGeom g,
+                                                         int64_t *__restrict__ list, int64_t cap) {
+    const int64_t base = (int64_t)blockIdx.x * AS_TILE + (int64_t)threadIdx.x * AS_ITEMS;
+    uint8_t f[AS_ITEMS];
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < AS_ITEMS; ++j) {
+        f[j] = base + j < n ? flags[base + j] : 0;
+        s += f[j] ? 1 : 0;
+    }
+    int tot;
+    int pos = block_excl_scan_i32(s, &tot) + blk[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < AS_ITEMS; ++j) {
+        if (!f[j]) continue;
+        if (pos < cap) {
+            int64_t site = base + j;
+            const int64_t ow = site % g.Wo; site /= g.Wo;
+            const int64_t oh = site % g.Ho; site /= g.Ho;
+            const int64_t od = site % g.Do;
+            const int64_t b = site / g.Do;
+            int64_t *o = list + (int64_t)pos * 4;
+            o[0] = b; o[1] = od; o[2] = oh; o[3] = ow;
+        }
+        ++pos;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fill_rows(void *__restrict__ y, int f32, int64_t M, int C, int64_t stride,
+                                                   const float *__restrict__ bias) {
+    const int groups = C >> 2;
+    const int64_t total = M * groups;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / groups;
+        const int c = (int)(i - m * groups) << 2;
+        const float4 b = *reinterpret_cast<const float4 *>(bias + c);
+        if (f32) {
+            *reinterpret_cast<float4 *>(static_cast<float *>(y) + m * stride + c) = b;
+        } else {
+            bf16x4_t o;
+            o[0] = (bf16_t)b.x; o[1] = (bf16_t)b.y; o[2] = (bf16_t)b.z; o[3] = (bf16_t)b.w;
+            *reinterpret_cast<bf16x4_t *>(static_cast<bf16_t *>(y) + m * stride + c) = o;
+        }
+    }
+}
+
+struct ASPlan {
+    int64_t sites, nb;
+    size_t off_flags, off_blk, bytes;
+};
+ASPlan as_plan(const vnConv *g) {
+    ASPlan p{};
+    p.sites = (int64_t)g->B * g->Dr * g->Hr * g->Wr;
+    p.nb = vn_ceil_div(p.sites, AS_TILE);
+    size_t off = 0;
+    p.off_flags = off; off += vn_align((size_t)p.sites);
+    p.off_blk = off; off += vn_align(sizeof(int32_t) * (size_t)(p.nb + 1));
+    p.bytes = off;
+    return p;
+}
+bool as_geom_ok(const vnConv *g) {
+    return g && g->B > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0 && g->kD >= 1 && g->kH >= 1 && g->kW >= 1 &&
+           g->mulD >= 1 && g->mulH >= 1 && g->mulW >= 1 && g->tmulD == 1 && g->tmulH == 1 && g->tmulW == 1 &&
+           g->divD == 1 && g->divH == 1 && g->divW == 1;
+}
+
+}  // namespace
+
+extern "C" size_t vn_active_sites_workspace_bytes(const vnConv *geom) {
+    return as_geom_ok(geom) ? as_plan(geom).bytes : 0;
+}
+
+extern "C" int vn_active_sites(const int64_t *coord, int64_t K, const vnConv *geom, void *workspace,
+                               size_t workspace_bytes, int64_t *list, int64_t cap, int32_t *count, vnStream stream) {
+    VN_CHECK_ARG(as_geom_ok(geom) && workspace && list && count && K >= 0 && cap >= 0 && cap < (1ll << 31));
+    VN_CHECK_ARG(coord || K == 0);
+    const ASPlan pl = as_plan(geom);
+    if (workspace_bytes < pl.bytes) return VN_EWORKSPACE;
+    hipStream_t st = vn_stream(stream);
+    uint8_t *flags = static_cast<uint8_t *>(workspace) + pl.off_flags;
+    int32_t *blk = reinterpret_cast<int32_t *>(static_cast<char *>(workspace) + pl.off_blk);
+    const ASGeom g{geom->B, geom->Dr, geom->Hr, geom->Wr, geom->kD, geom->kH, geom->kW,
+                   geom->mulD, geom->mulH, geom->mulW, geom->padD, geom->padH, geom->padW};
+    VN_HIP(hipMemsetAsync(flags, 0, (size_t)pl.sites, st));
+    if (K > 0) {
+        const int64_t n = K * g.kD * g.kH * g.kW;
+        k_mark<<<(unsigned)vn_ceil_div(n, 256), 256, 0, st>>>(coord, K, g, flags);
+        VN_LAUNCH_STATUS();
+    }
+    k_as_count<<<(unsigned)pl.nb, AS_THREADS, 0, st>>>(flags, pl.sites, blk);
+    VN_LAUNCH_STATUS();
+    k_as_scan<<<1, AS_THREADS, 0, st>>>(blk, pl.nb, cap, count);
+    VN_LAUNCH_STATUS();
+    k_as_write<<<(unsigned)pl.nb, AS_THREADS, 0, st>>>(flags, pl.sites, blk, g, list, cap);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_fill_rows(void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stride, const float *values,
+                            vnStream stream) {
+    VN_CHECK_ARG(M >= 0 && C > 0 && (C & 3) == 0 && (stride & 3) == 0 && stride >= C);
+    if (M == 0) return VN_OK;
+    VN_CHECK_ARG(y && values);
+    int64_t blocks = vn_ceil_div(M * (C >> 2), 256);
+    if (blocks > 8192) blocks = 8192;
+    k_fill_rows<<<(unsigned)blocks, 256, 0, vn_stream(stream)>>>(y, dtype == VN_F32, M, C, stride, values);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}

@@ -189,9 +189,11 @@ __global__ void __launch_bounds__(256) k_gather(const float4 *__restrict__ pts, 
                                                 const int32_t *__restrict__ seg_off, const int32_t *__restrict__ cnt,
                                                 const int32_t *__restrict__ lin, const int32_t *__restrict__ seg,
                                                 int64_t batch_index, int32_t coord_cols, float *__restrict__ feature,
-                                                int64_t *__restrict__ coord, int64_t *__restrict__ number) {
+                                                int64_t *__restrict__ coord, int64_t *__restrict__ number,
+                                                const int32_t *__restrict__ k_dev) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k_dev != nullptr && row >= (int64_t)k_dev[0]) return;   // K still on the device: capacity launch
     if (row >= K) return;   // wave-uniform
     const int T = g.T;
     const int n = cnt[row];
@@ -296,7 +298,8 @@ extern "C" int vn_voxelize_index(const float *points, int64_t n_points, const vn
 
 extern "C" int vn_voxelize_gather(const float *points, int64_t n_points, const vnGrid *grid, void *workspace,
                                   size_t workspace_bytes, int64_t K, int64_t batch_index, int32_t coord_cols,
-                                  float *feature, int64_t *coord, int64_t *number, vnStream stream) {
+                                  float *feature, int64_t *coord, int64_t *number, const int32_t *k_dev,
+                                  vnStream stream) {
     VN_CHECK_ARG(grid_ok(grid) && n_points >= 0 && workspace && K >= 0 && K <= n_points);
     VN_CHECK_ARG(coord_cols == 3 || coord_cols == 4);
     if (K == 0) return VN_OK;
@@ -306,7 +309,7 @@ extern "C" int vn_voxelize_gather(const float *points, int64_t n_points, const v
     if (workspace_bytes < w.bytes) return VN_EWORKSPACE;
     k_gather<<<dim3((unsigned)vn_ceil_div(K, 4)), dim3(256), 0, vn_stream(stream)>>>(
         reinterpret_cast<const float4 *>(points), *grid, K, w.seg_off, w.cnt, w.lin, w.seg, batch_index, coord_cols,
-        feature, coord, number);
+        feature, coord, number, k_dev);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

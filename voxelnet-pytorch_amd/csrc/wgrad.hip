@@ -36,6 +36,11 @@ struct WGParams {
     int32_t rows_per_chunk;   // multiple of 64
     int32_t tiles_k;          // number of DK tiles
     uint32_t src_bytes, rows_bytes;
+    // row-list mode: the reduction rows are an explicit list of (b,d,h,w) coordinates; the rows tensor is then
+    // a plain [n_rows][...] matrix (row index * rW) and the gathered site may be a strided TRANSPOSED one
+    const int64_t *row_list;
+    int64_t n_rows;
+    int32_t divD, divH, divW;
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -77,7 +82,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     const int n0 = tn * DN, k0 = tk * DK;
     const int tap = blockIdx.y;
     const int td = tap / (p.kH * p.kW), th = (tap / p.kW) % p.kH, tw = tap % p.kW;
-    const int64_t M = (int64_t)p.B * p.Dr * p.Hr * p.Wr;
+    const bool list = p.row_list != nullptr;
+    const int64_t M = list ? p.n_rows : (int64_t)p.B * p.Dr * p.Hr * p.Wr;
     const int64_t rbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
     if (rbeg >= M) return;
     int64_t rend = rbeg + p.rows_per_chunk;
@@ -93,7 +99,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     int cb = 0, cd = 0, ch = 0, cw = 0;
     int64_t cm = rbeg + lane;   // the site this lane tracks
     int tstep = 0;              // slab index its coordinates stand for
-    if (wave == 0) {
+    if (wave == 0 && !list) {
         int64_t t = cm;
         cw = (int)(t % p.Wr); t /= p.Wr;
         ch = (int)(t % p.Hr); t /= p.Hr;
@@ -103,6 +109,22 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     auto table_write = [&](int stage_idx) {
         // wave 0 only: entry for slab (stage_idx / nv) into tbl[stage_idx & 1]
         const int step = stage_idx / nv;
+        uint32_t so = WG_OOB, ro = WG_OOB;
+        if (list) {
+            const int64_t m = rbeg + (int64_t)step * ROWS + lane;
+            if (m < rend && lane < ROWS) {
+                const int64_t *rc = p.row_list + m * 4;
+                const int b = (int)rc[0];
+                int sd = (int)rc[1] * p.mulD + td * p.tmulD - p.padD;
+                int sh = (int)rc[2] * p.mulH + th * p.tmulH - p.padH;
+                int sw = (int)rc[3] * p.mulW + tw * p.tmulW - p.padW;
+                ro = (uint32_t)(m * p.rW * ESZ);
+                const bool div_ok = sd >= 0 && sh >= 0 && sw >= 0 && sd % p.divD == 0 && sh % p.divH == 0 && sw % p.divW == 0;
+                sd /= p.divD; sh /= p.divH; sw /= p.divW;
+                if (div_ok && sd < p.Ds && sh < p.Hs && sw < p.Ws)
+                    so = (uint32_t)(((int64_t)b * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW) * ESZ);
+            }
+        } else {
         while (tstep < step) {   // advance by ROWS sites
             cm += ROWS;
             cw += ROWS;
@@ -112,7 +134,6 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
             }
             ++tstep;
         }
-        uint32_t so = WG_OOB, ro = WG_OOB;
         if (cm < rend) {
             const int sd = cd * p.mulD + td * p.tmulD - p.padD;
             const int sh = ch * p.mulH + th * p.tmulH - p.padH;
@@ -120,6 +141,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
             ro = (uint32_t)(((int64_t)cb * p.rB + (int64_t)cd * p.rD + (int64_t)ch * p.rH + (int64_t)cw * p.rW) * ESZ);
             if ((unsigned)sd < (unsigned)p.Ds && (unsigned)sh < (unsigned)p.Hs && (unsigned)sw < (unsigned)p.Ws)
                 so = (uint32_t)(((int64_t)cb * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW) * ESZ);
+        }
         }
         uint32_t *e = tbl + ((stage_idx & 1) * 64 + lane) * 2;
         e[0] = so;
@@ -262,12 +284,28 @@ int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
+static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
+                      const int64_t *row_list, int64_t n_rows, vnStream stream);
+
 extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
                              vnStream stream) {
+    return wgrad_impl(src, rows, dw_packed, g, split, nullptr, 0, stream);
+}
+
+extern "C" int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_packed, const vnConv *g,
+                                  const int64_t *row_list, int64_t n_rows, vnStream stream) {
+    if (!row_list || n_rows < 0) return VN_EINVAL;
+    if (n_rows == 0) return VN_OK;
+    return wgrad_impl(src, rows, dw_packed, g, 0, row_list, n_rows, stream);
+}
+
+static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
+                      const int64_t *row_list, int64_t n_rows, vnStream stream) {
     VN_CHECK_ARG(src && rows && dw_packed && g);
     VN_CHECK_ARG(g->B > 0 && g->Ds > 0 && g->Hs > 0 && g->Ws > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0);
     VN_CHECK_ARG(g->kD >= 1 && g->kH >= 1 && g->kW >= 1 && g->kD * g->kH * g->kW <= 65535);
-    if (g->divD != 1 || g->divH != 1 || g->divW != 1) return VN_EUNSUPPORTED;
+    if (!row_list && (g->divD != 1 || g->divH != 1 || g->divW != 1)) return VN_EUNSUPPORTED;
+    if (g->divD < 1 || g->divH < 1 || g->divW < 1) return VN_EINVAL;
     VN_CHECK_ARG(g->dtype == VN_BF16 || (g->dtype == VN_F32 && !split));
     const bool f32 = g->dtype == VN_F32;
     const int esz = f32 ? 4 : 2, al = 16 / esz - 1;
@@ -291,8 +329,9 @@ extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed
     const int wmul = split ? 2 : 1;
     const int64_t sbytes = ((int64_t)(g->B - 1) * g->src_sB + (int64_t)(g->Ds - 1) * g->src_sD +
                             (int64_t)(g->Hs - 1) * g->src_sH + (int64_t)(g->Ws - 1) * g->src_sW + wmul * g->Cs) * esz;
-    const int64_t rbytes = ((int64_t)(g->B - 1) * g->out_sB + (int64_t)(g->Dr - 1) * g->out_sD +
-                            (int64_t)(g->Hr - 1) * g->out_sH + (int64_t)(g->Wr - 1) * g->out_sW + wmul * g->Cr) * esz;
+    const int64_t rbytes = row_list ? ((n_rows - 1) * g->out_sW + wmul * g->Cr) * esz
+                                    : ((int64_t)(g->B - 1) * g->out_sB + (int64_t)(g->Dr - 1) * g->out_sD +
+                                       (int64_t)(g->Hr - 1) * g->out_sH + (int64_t)(g->Wr - 1) * g->out_sW + wmul * g->Cr) * esz;
     if (sbytes > (int64_t)WG_MAX_WINDOW || rbytes > (int64_t)WG_MAX_WINDOW) return VN_EUNSUPPORTED;
     p.src_bytes = (uint32_t)sbytes;
     p.rows_bytes = (uint32_t)rbytes;
@@ -302,9 +341,15 @@ extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed
     const int DN = n128 ? 128 : 64, DK = k128 ? 128 : 64;
     const int tiles_n = (int)vn_ceil_div(g->Cr, DN), tiles_k = (int)vn_ceil_div(g->Cs, DK);
     p.tiles_k = tiles_k;
-    const int64_t M = (int64_t)g->B * g->Dr * g->Hr * g->Wr;
-    // ~2048 workgroups in flight, at least 64 sites each
-    int64_t chunks = 2048 / ((int64_t)taps * tiles_n * tiles_k);
+    p.row_list = row_list;
+    p.n_rows = n_rows;
+    p.divD = g->divD; p.divH = g->divH; p.divW = g->divW;
+    const int64_t M = row_list ? n_rows : (int64_t)g->B * g->Dr * g->Hr * g->Wr;
+    // ~1024 workgroups, but every workgroup gets at least 24 slabs of sites: a chunk ends with DN x DK fp32
+    // atomics (64 KB for a 128x128 tile), which must stay small against the chunk's MFMA work
+    int64_t chunks = 1024 / ((int64_t)taps * tiles_n * tiles_k);
+    const int64_t slabs = vn_ceil_div(M, 64);
+    if (chunks > slabs / 24) chunks = slabs / 24;
     if (chunks < 1) chunks = 1;
     int64_t rpc = vn_ceil_div(vn_ceil_div(M, chunks), 64) * 64;
     if (rpc < 64) rpc = 64;

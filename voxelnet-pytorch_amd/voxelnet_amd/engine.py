@@ -375,6 +375,105 @@ def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=Fa
     return grads, dx
 
 
+# ---- sparse first middle layer (model.py:207 on the 99 %-empty scattered grid) -----------------------------------
+
+def first_layer_forward_sparse(spec, x, coord, params, buffers, training, mode):
+    """layer_forward for a conv whose input x is the scattered voxel grid with occupied sites `coord`
+    ((K,4) int64 [b,z,y,x]): MFMA work only at the active output sites (csrc/sparse.hip + the row-list
+    mode of k_gather_gemm), bias everywhere else; BatchNorm statistics from the active rows (all other
+    rows contribute exactly 0 to sum(y-bias) and sum((y-bias)^2))."""
+    assert not spec.transposed and spec.bn and not is_split(mode)
+    dev = x.t.device
+    B = x.B
+    odims = spec.out_dims(x.dims)
+    w, bias = params["weight"], params["bias"]
+    wp = pack_weight(w, spec, 0, mode)
+    y = Rows(torch.empty((B,) + odims + (spec.cout,), dtype=plain_dtype_of(mode), device=dev), spec.cout)
+    M = y.M
+    _lib.call("vn_fill_rows", y.ptr(), _dt(y.t), M, spec.cout, spec.cout, bias.data_ptr(), stream())
+    g = _geom(B, x, odims, spec.cin, 0, spec.cout, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1), y.strides)
+    K = coord.shape[0]
+    per = 1
+    for kk, ss in zip(spec.k, spec.stride):
+        per *= -(-kk // ss)
+    cap = max(1, min(M, K * per))
+    lib = _lib.load()
+    ws_bytes = lib.vn_active_sites_workspace_bytes(ctypes.byref(g))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    lst = torch.empty((cap, 4), dtype=torch.int64, device=dev)
+    cnt = torch.empty(1, dtype=torch.int32, device=dev)
+    _lib.call("vn_active_sites", coord.data_ptr(), K, ctypes.byref(g), ws.data_ptr(), ws_bytes, lst.data_ptr(), cap,
+              cnt.data_ptr(), stream())
+    bm = 128 if spec.cout > 64 else 256
+    slab = None
+    if training:
+        slab = torch.empty((-(-cap // bm), 2, spec.cout), dtype=torch.float32, device=dev)
+    taps = spec.taps
+    with _timed("k_gather_gemm_rows", 2.0 * cap * spec.cout * spec.cin * taps):
+        _lib.call("vn_conv_gather_gemm_rows", x.ptr(), wp.data_ptr(), bias.data_ptr(), y.ptr(), _dt(y.t),
+                  ctypes.byref(g), lst.data_ptr(), cap, cnt.data_ptr(), 0,
+                  slab.data_ptr() if slab is not None else None, stream())
+    st = LayerState()
+    st.spec, st.x, st.y, st.in_dims, st.out_dims = spec, x, y, x.dims, odims
+    stats = torch.empty(4 * spec.cout, dtype=torch.float32, device=dev)
+    if slab is not None:
+        _lib.call("vn_bn_finalize_slab", slab.data_ptr(), slab.shape[0], M, spec.cout, bias.data_ptr(),
+                  params["gamma"].data_ptr(), params["beta"].data_ptr(), buffers["running_mean"].data_ptr(),
+                  buffers["running_var"].data_ptr(), BN_MOMENTUM, BN_EPS, stats.data_ptr(), stream())
+    else:
+        _lib.call("vn_bn_finalize", None, M, spec.cout, 1, bias.data_ptr(), params["gamma"].data_ptr(),
+                  params["beta"].data_ptr(), buffers["running_mean"].data_ptr(), buffers["running_var"].data_ptr(),
+                  0, BN_MOMENTUM, BN_EPS, stats.data_ptr(), stream())
+    a = new_rows(B, odims, spec.cout, act_dtype_of(mode), False, dev)
+    _lib.call("vn_bn_apply", y.ptr(), _dt(y.t), y.row_stride(), M, spec.cout, stats.data_ptr(), int(spec.relu),
+              a.ptr(), _dt(a.t), a.row_stride(), 0, stream())
+    st.stats, st.a = stats, a
+    return a, st
+
+
+def first_layer_backward_sparse(st, da, params, mode, coord, vw_rows):
+    """backward of first_layer_forward_sparse: BN backward on the dense rows, then weight gradient and data
+    gradient ONLY over the K occupied voxels (row-list modes of k_wgrad / k_gather_gemm).
+    vw_rows: (K,Cin) voxel features in the operand dtype.  -> (grads, d_vw (K,Cin) fp32)"""
+    spec, y = st.spec, st.y
+    dev = y.t.device
+    B, M, C = y.B, y.M, spec.cout
+    adt = act_dtype_of(mode)
+    sums = torch.zeros(2 * C, dtype=torch.float64, device=dev)
+    _lib.call("vn_bn_bwd_reduce", da.ptr(), _dt(da.t), da.row_stride(), y.ptr(), _dt(y.t), y.row_stride(), M, C,
+              st.stats.data_ptr(), int(spec.relu), sums.data_ptr(), stream())
+    coef = torch.empty(3 * C, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(C, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(C, dtype=torch.float32, device=dev)
+    _lib.call("vn_bn_bwd_finalize", sums.data_ptr(), M, C, 1, params["gamma"].data_ptr(), st.stats.data_ptr(),
+              coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream())
+    dy = new_rows(B, st.out_dims, C, adt, False, dev)
+    _lib.call("vn_bn_bwd_apply", da.ptr(), _dt(da.t), da.row_stride(), y.ptr(), _dt(y.t), y.row_stride(), M, C,
+              st.stats.data_ptr(), coef.data_ptr(), int(spec.relu), dy.ptr(), _dt(dy.t), dy.row_stride(), 0, stream())
+    grads = {"gamma": dgamma, "beta": dbeta, "bias": torch.zeros(C, dtype=torch.float32, device=dev)}
+    K = coord.shape[0]
+    taps = spec.taps
+    neg_pad = tuple(-q for q in spec.pad)
+    # gathered = dy at (c + pad - t)/stride ; rows = the K voxels
+    g = _geom(B, dy, st.in_dims, C, 0, spec.cin, spec.k, (1, 1, 1), (-1, -1, -1), neg_pad, spec.stride,
+              (0, 0, 0, vw_rows.shape[1]))
+    dwp = torch.zeros((taps, spec.cin, C), dtype=torch.float32, device=dev)
+    with _timed("k_wgrad_rows", 2.0 * K * spec.cin * C * taps):
+        _lib.call("vn_conv_wgrad_rows", dy.ptr(), vw_rows.data_ptr(), dwp.data_ptr(), ctypes.byref(g),
+                  coord.data_ptr(), K, stream())
+    dw = torch.empty_like(params["weight"])
+    _lib.call("vn_unpack_wgrad", dwp.data_ptr(), spec.cin, C, taps, 2, 1, dw.data_ptr(), stream())
+    grads["weight"] = dw
+    wp = pack_weight(params["weight"], spec, 1, mode)
+    d_vw = torch.empty((K, spec.cin), dtype=torch.float32, device=dev)
+    g2 = _geom(B, dy, st.in_dims, C, 0, spec.cin, spec.k, (1, 1, 1), (-1, -1, -1), neg_pad, spec.stride,
+               (0, 0, 0, spec.cin))
+    with _timed("k_gather_gemm_rows", 2.0 * K * spec.cin * C * taps):
+        _lib.call("vn_conv_gather_gemm_rows", dy.ptr(), wp.data_ptr(), None, d_vw.data_ptr(), VN_F32,
+                  ctypes.byref(g2), coord.data_ptr(), K, None, 1, None, stream())
+    return grads, d_vw
+
+
 # ---- NC(D)HW fp32 <-> rows (module boundary) -------------------------------------------------
 
 def nchw_to_rows(x, mode):

@@ -415,7 +415,16 @@ class _DetectorFn(torch.autograd.Function):
         with torch.cuda.device(feature.device):
             vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
             dense = scatter_rows(vw, coord, B, fn._grid.dims, mode)
-            prob, reg, st = N.middle_forward(dense, P, Bf, mid._block1_stride, training, mode)
+            sparse = None
+            if rpn.sparse_first_layer and not E.is_split(mode):
+                if mode == "fp32":
+                    vw_rows = vw
+                else:
+                    vw_rows = torch.empty((vw.shape[0], 128), dtype=torch.bfloat16, device=vw.device)
+                    _lib.call("vn_cast_rows", vw.data_ptr(), _lib.VN_F32, 128, vw.shape[0], 128, vw_rows.data_ptr(),
+                              _lib.VN_BF16, 128, 0, E.stream())
+                sparse = (coord, vw_rows)
+            prob, reg, st = N.middle_forward(dense, P, Bf, mid._block1_stride, training, mode, sparse=sparse)
         ctx.saved = (feature, coord, stats, wst, vparams, st, P, names)
         ctx.reducer = rpn.grad_reducer
         return prob, reg
@@ -441,7 +450,7 @@ class _DetectorFn(torch.autograd.Function):
                 red.grad_ready(f"middle_rpn.{name}.batch_norm.bias", g["beta"])
         with torch.cuda.device(d_prob.device):
             G, d_dense = N.middle_backward(st, d_prob.float(), d_reg.float(), P, need_dx=True, on_grads=on_grads)
-            d_vw = gather_rows(d_dense, coord, feature.shape[0], 128)
+            d_vw = d_dense if torch.is_tensor(d_dense) else gather_rows(d_dense, coord, feature.shape[0], 128)
             vg = featnet_backward(feature, wst, stats, d_vw, vparams)
             if red is not None:
                 for key, g in zip(VFE_KEYS, vg):
@@ -472,6 +481,7 @@ class RPN3D(nn.Module):
         self.middle_rpn = MiddleConvNet(cls_name)
         self.rpn_output_shape = self.middle_rpn.output_shape
         self.target_fn = None    # callable(label, rpn_output_shape) -> (pos, neg, targets)
+        self.sparse_first_layer = True   # first Conv3d only at active sites / occupied voxels (same results)
         self.grad_reducer = None  # parallel.GradAllReducer: bucketed all-reduce overlapped with backward
 
     def detect(self, voxel_features, voxel_coordinates):

@@ -34,9 +34,12 @@ class MiddleState:
     pass
 
 
-def middle_forward(dense, P, Bf, block1_stride, training, mode):
+def middle_forward(dense, P, Bf, block1_stride, training, mode, sparse=None):
     """dense: Rows (B,D,H,W,128[hi|lo]).  P[name] = {weight,bias,gamma,beta}; Bf[name] =
     {running_mean,running_var}; P['heads'] = {weight (16,768,1,1), bias (16)}.
+    sparse = (coord (K,4) int64, vw_rows (K,128) operand dtype): the occupied sites of `dense`; the first
+    Conv3d then runs in its sparse form (engine.first_layer_forward_sparse) and middle_backward returns the
+    (K,128) voxel gradient instead of a dense grid gradient.
     Returns prob (B,2,h,w) after sigmoid, reg (B,14,h,w) fp32 NCHW, and the saved state."""
     specs = dict(layer_table(block1_stride))
     st = MiddleState()
@@ -52,7 +55,13 @@ def middle_forward(dense, P, Bf, block1_stride, training, mode):
         st.layers[name] = s
         return a
 
-    x = run("middle_layer.0", dense)
+    st.sparse = sparse if (sparse is not None and not E.is_split(mode)) else None
+    if st.sparse is not None:
+        x, s0 = E.first_layer_forward_sparse(specs["middle_layer.0"], dense, st.sparse[0], P["middle_layer.0"],
+                                             Bf["middle_layer.0"], training, mode)
+        st.layers["middle_layer.0"] = s0
+    else:
+        x = run("middle_layer.0", dense)
     x = run("middle_layer.1", x)
     x = run("middle_layer.2", x, bev_out=True)           # -> (B,1,H,W,128) BEV rows
     for i in range(5):
@@ -121,5 +130,12 @@ def middle_backward(st, d_prob, d_reg, P, need_dx=True, on_grads=None):
         d = back(f"block1.{i}", d)
     d = back("middle_layer.2", d, bev_da=True)
     d = back("middle_layer.1", d)
+    if st.sparse is not None:
+        g0, d = E.first_layer_backward_sparse(L["middle_layer.0"], d, P["middle_layer.0"], mode, st.sparse[0],
+                                              st.sparse[1])
+        G["middle_layer.0"] = g0
+        if on_grads is not None:
+            on_grads("middle_layer.0", g0)
+        return G, d          # d: (K,128) fp32 gradient of the voxel features
     d = back("middle_layer.0", d, need_dx=need_dx)
     return G, d

@@ -49,8 +49,57 @@ def voxelize_device(points, grid, batch_index=0, coord_cols=4):
         coord = torch.empty((K, coord_cols), dtype=torch.int64, device=dev)
         number = torch.empty((K,), dtype=torch.int64, device=dev)
         _lib.call("vn_voxelize_gather", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes, K,
-                  int(batch_index), coord_cols, feature.data_ptr(), coord.data_ptr(), number.data_ptr(), st)
+                  int(batch_index), coord_cols, feature.data_ptr(), coord.data_ptr(), number.data_ptr(), None, st)
     return feature, coord, number
+
+
+class AsyncVoxels:
+    """Handle of a voxelization that was enqueued WITHOUT a host read-back: the outputs are allocated at
+    capacity (K <= N), the gather kernel takes K from device memory, and K travels to pinned host memory
+    with an asynchronous copy.  result() waits for that copy only (normally long finished) and returns the
+    reference-format views (K,T,7) / (K,cols) / (K,)."""
+
+    def __init__(self, feature, coord, number, k_host, event):
+        self._f, self._c, self._n, self._k, self._ev = feature, coord, number, k_host, event
+
+    def result(self):
+        self._ev.synchronize()
+        K = int(self._k[0])
+        return self._f[:K], self._c[:K], self._n[:K]
+
+    @property
+    def event(self):
+        return self._ev
+
+
+def voxelize_device_async(points, grid, batch_index=0, coord_cols=4):
+    """as voxelize_device, on the current stream, without any host synchronisation"""
+    if not (points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 4):
+        raise ValueError("points must be a CUDA float32 (N,4) tensor")
+    points = points.contiguous()
+    n = points.shape[0]
+    dev = points.device
+    gs = _grid_struct(grid)
+    lib = _lib.load()
+    ws_bytes = lib.vn_voxelize_workspace_bytes(n, ctypes.byref(gs))
+    cap = min(n, grid.cells)
+    with torch.cuda.device(dev):
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        k_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        feature = torch.empty((cap, grid.T, 7), dtype=torch.float32, device=dev)
+        coord = torch.empty((cap, coord_cols), dtype=torch.int64, device=dev)
+        number = torch.empty((cap,), dtype=torch.int64, device=dev)
+        st = _stream()
+        _lib.call("vn_voxelize_index", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes,
+                  k_dev.data_ptr(), st)
+        _lib.call("vn_voxelize_gather", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes, cap,
+                  int(batch_index), coord_cols, feature.data_ptr(), coord.data_ptr(), number.data_ptr(),
+                  k_dev.data_ptr(), st)
+        k_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        k_host.copy_(k_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+    return AsyncVoxels(feature, coord, number, k_host, ev)
 
 
 def pcl_to_voxels(pcl, target, verbose=False, device="cuda:0"):
