@@ -222,6 +222,48 @@ int vn_unpack_wgrad(const float *dw_packed, int32_t c_out, int32_t c_in, int32_t
                     int32_t mode, int32_t cin_fold, float *dw, vnStream stream);
 
 /* ------------------------------------------------------------------------
+ * Native step executor — MiddleConvNet.forward (model.py:257-281) and its backward as ONE call
+ * each (csrc/runtime.hip): layer table, launch geometry and workspace arena live in C++, so the
+ * ~450 launches of a step cost microseconds of host time instead of a Python round trip each.
+ * The workspace (vn_net_workspace_bytes, caller allocated) also keeps the activations between
+ * the two calls.  mode: 0 = bf16 operands, 1 = fp32 operands (parity mode).  Layers are indexed
+ * in execution order: middle_layer.0-2, block1.0-4, deconv1, block2.0-5, deconv2, block3.0-5,
+ * deconv3 (23 entries); the two 1x1 heads are passed concatenated (prob rows first).
+ * sparse_first: the first Conv3d runs in its row-list form (needs coord, K; backward returns
+ * the (K,128) fp32 voxel gradient in d_input and needs vw_rows (K,128) in the operand dtype);
+ * else d_input receives the dense (B,D,H,W,128) gradient in the operand dtype (may be NULL).
+ * The backward can be issued in segments of its 24 steps (0 = heads, 1..23 = layers in backward
+ * order: deconv3, block3.5..0, deconv2, block2.5..0, deconv1, block1.4..0, middle_layer.2..0) so
+ * a caller can start the gradient all-reduce of finished parameter groups in between.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+    int32_t B, D, H, W;      /* dense voxel grid (D must be 10) */
+    int32_t block1_stride;   /* 2: Car, 1: Pedestrian/Cyclist (model.py:212-227) */
+    int32_t mode;            /* 0 bf16, 1 fp32 */
+    int32_t training;        /* BatchNorm: batch statistics + running-stat update, or running statistics */
+    int32_t sparse_first;
+} vnNetConfig;
+typedef struct {
+    const float *weight, *bias, *gamma, *beta;
+    float *running_mean, *running_var;
+} vnLayerParams;
+typedef struct {
+    float *weight, *bias, *gamma, *beta;   /* overwritten */
+} vnLayerGrads;
+size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K);
+int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,
+                   const float *heads_w /*[16,768]*/, const float *heads_b /*[16]*/,
+                   const void *dense, const int64_t *coord, int64_t K, void *workspace,
+                   size_t workspace_bytes, float *prob /*(B,2,h,w)*/, float *reg /*(B,14,h,w)*/,
+                   vnStream stream);
+int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
+                    const float *d_prob, const float *d_reg, const float *prob, const void *dense,
+                    const int64_t *coord, const void *vw_rows, int64_t K, void *workspace,
+                    size_t workspace_bytes, const vnLayerGrads *grads /*[23]*/, float *d_heads_w,
+                    float *d_heads_b, void *d_input, int32_t seg_begin, int32_t seg_end,
+                    vnStream stream);
+
+/* ------------------------------------------------------------------------
  * BatchNorm(+ReLU) over channels-last rows — nn.BatchNorm{1,2,3}d defaults
  * (momentum 0.1, eps 1e-5) as used at model.py:72,142,153,193.
  * Rows are M x C with `stride` elements between rows.  `fold` (1 or 2): the C

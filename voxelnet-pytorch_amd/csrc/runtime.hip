@@ -1,0 +1,472 @@
+// Native step executor for MiddleConvNet (model.py:202-281): the whole forward and the whole backward of
+// the 3 Conv3d + 17 Conv2d + 3 ConvTranspose2d + heads stack as ONE C-ABI call each.
+//
+// Why: a train step is ~450 kernel launches of 2-2000 us.  Issued one by one from Python (ctypes +
+// torch.empty/zeros per launch) the host needs ~9 ms per step — as long as the GPU needs to execute them.
+// Here the layer table, the geometry of every launch, and a bump-allocated workspace arena (caller
+// allocated, one buffer for the whole step, zeroed regions grouped so ONE memset per pass replaces ~100
+// fill launches) live in C++; a launch costs a few microseconds of host time and Python makes two calls.
+// The arena keeps the activations between vn_net_forward and vn_net_backward (the autograd "saved
+// tensors").  No state lives in the library: the plan is a pure function of (config, K).
+//
+// The per-layer call sequences are exactly those of voxelnet_amd/engine.py (the Python reference
+// orchestration, still used by the per-layer tests and the bf16x3 mode).
+#include "common.h"
+#include <string.h>
+
+namespace {
+
+constexpr int NL = 23;   // conv layers with BatchNorm, in execution order (net.layer_table)
+
+struct Spec {
+    int dim, cin, cout, k[3], s[3], p[3];
+    bool transposed;
+    int cin_fold;
+};
+
+struct Rows {            // channels-last rows (B,D,H,W,C) with element strides
+    char *ptr;
+    int dtype;           // VN_F32 / VN_BF16
+    int B, D, H, W, C;
+    int64_t sB, sD, sH, sW;
+    int64_t M() const { return (int64_t)B * D * H * W; }
+};
+
+Rows dense_rows(void *ptr, int dtype, int B, int D, int H, int W, int C, int64_t width = 0) {
+    if (!width) width = C;
+    return Rows{static_cast<char *>(ptr), dtype, B, D, H, W, C, (int64_t)D * H * W * width, (int64_t)H * W * width,
+                (int64_t)W * width, width};
+}
+
+void layer_table(int block1_stride, Spec *t) {
+    int i = 0;
+    auto c3 = [&](int ci, int co, int sd, int pd) { t[i++] = Spec{3, ci, co, {3, 3, 3}, {sd, 1, 1}, {pd, 1, 1}, false, 1}; };
+    auto c2 = [&](int ci, int co, int s, int fold = 1) { t[i++] = Spec{2, ci, co, {1, 3, 3}, {1, s, s}, {0, 1, 1}, false, fold}; };
+    auto d2 = [&](int ci, int co, int k, int s, int p) { t[i++] = Spec{2, ci, co, {1, k, k}, {1, s, s}, {0, p, p}, true, 1}; };
+    c3(128, 64, 2, 1); c3(64, 64, 1, 0); c3(64, 64, 2, 1);                       // model.py:207-209
+    c2(128, 128, block1_stride, 2); for (int j = 0; j < 4; ++j) c2(128, 128, 1);  // block1 (model.py:212-227)
+    d2(128, 256, 3, 1, 1);                                                         // deconv1 (229)
+    c2(128, 128, 2); for (int j = 0; j < 5; ++j) c2(128, 128, 1);                  // block2 (231-238)
+    d2(128, 256, 2, 2, 0);                                                         // deconv2 (240)
+    c2(128, 256, 2); for (int j = 0; j < 5; ++j) c2(256, 256, 1);                  // block3 (242-249)
+    d2(256, 256, 4, 4, 0);                                                         // deconv3 (251)
+}
+// indices into the table
+constexpr int L_M0 = 0, L_M2 = 2, L_B1 = 3, L_D1 = 8, L_B2 = 9, L_D2 = 15, L_B3 = 16, L_D3 = 22;
+
+void out_dims(const Spec &sp, const int in[3], int out[3]) {
+    for (int a = 0; a < 3; ++a)
+        out[a] = sp.transposed ? (in[a] - 1) * sp.s[a] - 2 * sp.p[a] + sp.k[a] : (in[a] + 2 * sp.p[a] - sp.k[a]) / sp.s[a] + 1;
+}
+
+struct Arena {
+    char *base;
+    size_t off, cap;
+    void *take(size_t bytes) {
+        void *r = base ? base + off : nullptr;
+        off += vn_align(bytes, 256);
+        return r;
+    }
+};
+
+// everything the two passes need, laid out by one deterministic walk (plan == allocation)
+struct Plan {
+    Spec spec[NL];
+    int in_dims[NL][3], odims[NL][3];
+    int esz, adt, pdt;           // operand element size / activation dtype / plain (y, gradient) dtype
+    // per layer
+    void *wp_f[NL], *wp_d[NL];   // packed weights (forward / data-gradient orientation)
+    Rows y[NL], a[NL];           // conv output (pre-BN), activation
+    float *slab[NL]; int64_t slab_rows[NL];
+    double *fsums[NL];           // forward bn_stats sums (deconvs)
+    float *stats[NL];
+    // backward
+    double *bsums[NL];
+    float *coef[NL];
+    Rows dy[NL], dx[NL];
+    float *dwp[NL];
+    // heads
+    void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs;
+    // sparse first layer
+    int64_t *alist; int32_t *acount; int64_t acap; void *aws; size_t aws_bytes;
+    // zeroed regions
+    char *zf_begin, *zf_end, *zb_begin, *zb_end;
+    size_t bytes;
+    int hf, wf;
+};
+
+vnConv geom(const Rows &src, const int row_dims[3], int Cs, int Cr, const int k[3], const int mul[3], const int tmul[3],
+            const int pad[3], const int div[3], const int64_t ostr[4]) {
+    vnConv g;
+    memset(&g, 0, sizeof(g));
+    g.dtype = src.dtype;
+    g.B = src.B; g.Ds = src.D; g.Hs = src.H; g.Ws = src.W;
+    g.Dr = row_dims[0]; g.Hr = row_dims[1]; g.Wr = row_dims[2];
+    g.Cs = Cs; g.src_wrap = 0; g.Cr = Cr;
+    g.kD = k[0]; g.kH = k[1]; g.kW = k[2];
+    g.mulD = mul[0]; g.mulH = mul[1]; g.mulW = mul[2];
+    g.tmulD = tmul[0]; g.tmulH = tmul[1]; g.tmulW = tmul[2];
+    g.padD = pad[0]; g.padH = pad[1]; g.padW = pad[2];
+    g.divD = div[0]; g.divH = div[1]; g.divW = div[2];
+    g.src_sB = src.sB; g.src_sD = src.sD; g.src_sH = src.sH; g.src_sW = src.sW;
+    g.out_sB = ostr[0]; g.out_sD = ostr[1]; g.out_sH = ostr[2]; g.out_sW = ostr[3];
+    return g;
+}
+const int ONE[3] = {1, 1, 1}, NEG[3] = {-1, -1, -1};
+
+vnConv fwd_geom(const Spec &sp, const Rows &x, const int od[3], const Rows &out) {
+    const int64_t os[4] = {out.sB, out.sD, out.sH, out.sW};
+    if (sp.transposed) {
+        const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
+        return geom(x, od, sp.cin, sp.cout, sp.k, ONE, NEG, np, sp.s, os);
+    }
+    return geom(x, od, sp.cin, sp.cout, sp.k, sp.s, ONE, sp.p, ONE, os);
+}
+
+bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
+    if (!c || c->B <= 0 || c->D != 10 || c->H <= 0 || c->W <= 0 || (c->H & 7) || (c->W & 7)) return false;
+    if (c->mode != 0 && c->mode != 1) return false;
+    if (c->block1_stride != 1 && c->block1_stride != 2) return false;
+    memset(P, 0, sizeof(*P));
+    layer_table(c->block1_stride, P->spec);
+    const bool f32 = c->mode == 1;
+    P->esz = f32 ? 4 : 2;
+    P->adt = f32 ? VN_F32 : VN_BF16;
+    P->pdt = P->adt;
+    const int B = c->B;
+    Arena A{base, 0, 0};
+    auto rows_new = [&](int dtype, const int d[3], int C, int64_t width = 0) {
+        if (!width) width = C;
+        void *p = A.take((size_t)B * d[0] * d[1] * d[2] * width * (dtype == VN_F32 ? 4 : 2));
+        return dense_rows(p, dtype, B, d[0], d[1], d[2], C, width);
+    };
+    // ---- dims walk
+    int cur[3] = {c->D, c->H, c->W};
+    int x1[3] = {0, 0, 0}, x2[3] = {0, 0, 0};
+    for (int l = 0; l < NL; ++l) {
+        int in[3] = {cur[0], cur[1], cur[2]};
+        if (l == L_B1) { in[0] = 1; }                       // BEV: (B,2,H,W,64) -> (B,1,H,W,128)
+        if (l == L_B2 || l == L_D1) { in[0] = x1[0]; in[1] = x1[1]; in[2] = x1[2]; }
+        if (l == L_B3 || l == L_D2) { in[0] = x2[0]; in[1] = x2[1]; in[2] = x2[2]; }
+        memcpy(P->in_dims[l], in, sizeof(in));
+        out_dims(P->spec[l], in, P->odims[l]);
+        if (!P->spec[l].transposed) memcpy(cur, P->odims[l], sizeof(cur));
+        if (l == L_D1 - 1) memcpy(x1, cur, sizeof(cur));
+        if (l == L_D2 - 1) memcpy(x2, cur, sizeof(cur));
+        if (l == L_M2 && P->odims[l][0] != 2) return false;
+    }
+    P->hf = P->odims[L_D1][1];
+    P->wf = P->odims[L_D1][2];
+    for (int l : {L_D2, L_D3})
+        if (P->odims[l][1] != P->hf || P->odims[l][2] != P->wf) return false;
+    // ---- packed weights
+    for (int l = 0; l < NL; ++l) {
+        const Spec &sp = P->spec[l];
+        const size_t n = (size_t)sp.k[0] * sp.k[1] * sp.k[2] * sp.cin * sp.cout * P->esz;
+        P->wp_f[l] = A.take(n);
+        P->wp_d[l] = A.take(n);
+    }
+    P->hwp_f = A.take((size_t)16 * 768 * P->esz);
+    P->hwp_d = A.take((size_t)16 * 768 * P->esz);
+    // ---- forward-zeroed region (deconv bn sums)
+    P->zf_begin = base ? base + A.off : nullptr;
+    for (int l = 0; l < NL; ++l) P->fsums[l] = P->spec[l].transposed ? (double *)A.take(2 * 256 * sizeof(double)) : nullptr;
+    P->zf_end = base ? base + A.off : nullptr;
+    // ---- concat buffer and activations
+    const int fm[3] = {1, P->hf, P->wf};
+    P->cat = rows_new(P->adt, fm, 768);
+    for (int l = 0; l < NL; ++l) {
+        const Spec &sp = P->spec[l];
+        P->y[l] = rows_new(P->pdt, P->odims[l], sp.cout);
+        P->stats[l] = (float *)A.take(4 * 256 * sizeof(float));
+        const int64_t M = P->y[l].M();
+        P->slab_rows[l] = 0;
+        P->slab[l] = nullptr;
+        if (!sp.transposed) {
+            P->slab_rows[l] = vn_ceil_div(M, sp.cout > 64 ? 128 : 256);
+            P->slab[l] = (float *)A.take((size_t)P->slab_rows[l] * 2 * sp.cout * sizeof(float));
+        }
+        if (sp.transposed) {   // activation = channel slice of the concat: cat([d3,d2,d1]) (model.py:271-273)
+            const int off = l == L_D3 ? 0 : (l == L_D2 ? 256 : 512);
+            Rows r = P->cat;
+            r.ptr += (size_t)off * P->esz;
+            r.C = 256;
+            P->a[l] = r;
+        } else if (l == L_M2) {   // BEV fold (model.py:262): stored channel d*64 + c
+            const int bd[3] = {1, P->odims[l][1], P->odims[l][2]};
+            P->a[l] = rows_new(P->adt, bd, 128);
+        } else {
+            P->a[l] = rows_new(P->adt, P->odims[l], sp.cout);
+        }
+    }
+    P->hy = rows_new(VN_F32, fm, 16);
+    // ---- sparse first layer
+    P->acap = 0;
+    if (c->sparse_first) {
+        int64_t per = 1;
+        for (int a = 0; a < 3; ++a) per *= (P->spec[0].k[a] + P->spec[0].s[a] - 1) / P->spec[0].s[a];
+        int64_t cap = K * per;
+        const int64_t M0 = P->y[0].M();
+        if (cap > M0) cap = M0;
+        if (cap < 1) cap = 1;
+        P->acap = cap;
+        P->alist = (int64_t *)A.take((size_t)cap * 4 * sizeof(int64_t));
+        P->acount = (int32_t *)A.take(256);
+        const int od[3] = {P->odims[0][0], P->odims[0][1], P->odims[0][2]};
+        Rows dummy = dense_rows(nullptr, P->adt, B, c->D, c->H, c->W, 128);
+        vnConv g = fwd_geom(P->spec[0], dummy, od, P->y[0]);
+        P->aws_bytes = vn_active_sites_workspace_bytes(&g);
+        P->aws = A.take(P->aws_bytes);
+        P->slab_rows[0] = vn_ceil_div(cap, 256);
+    }
+    // ---- backward buffers
+    P->zb_begin = base ? base + A.off : nullptr;
+    for (int l = 0; l < NL; ++l) {
+        const Spec &sp = P->spec[l];
+        P->bsums[l] = (double *)A.take(2 * 256 * sizeof(double));
+        P->dwp[l] = (float *)A.take((size_t)sp.k[0] * sp.k[1] * sp.k[2] * sp.cin * sp.cout * sizeof(float));
+    }
+    P->hdwp = (float *)A.take((size_t)16 * 768 * sizeof(float));
+    P->hcs = (float *)A.take(64 * sizeof(float));
+    P->zb_end = base ? base + A.off : nullptr;
+    for (int l = 0; l < NL; ++l) {
+        const Spec &sp = P->spec[l];
+        P->coef[l] = (float *)A.take(3 * 256 * sizeof(float));
+        P->dy[l] = rows_new(P->adt, P->odims[l], sp.cout);
+        // data gradient buffer of the layer's input (shared where two consumers accumulate)
+        P->dx[l] = Rows{};
+    }
+    // dx buffers: one per distinct layer input
+    for (int l = 1; l < NL; ++l) {
+        if (l == L_D1 || l == L_D2) continue;             // written into the block output's dx (accumulate)
+        const Spec &sp = P->spec[l];
+        P->dx[l] = rows_new(P->pdt, P->in_dims[l], sp.cin);
+    }
+    P->dx[L_D1] = P->dx[L_B2];
+    P->dx[L_D2] = P->dx[L_B3];
+    if (!c->sparse_first) P->dx[0] = rows_new(P->pdt, P->in_dims[0], 128);
+    P->d_rows = rows_new(P->adt, fm, 16);
+    P->d_cat = rows_new(P->pdt, fm, 768);
+    P->bytes = A.off;
+    return true;
+}
+
+#define RT(call) do { int rc_ = (call); if (rc_ != VN_OK) return rc_; } while (0)
+
+int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, vnStream st) {
+    return vn_bn_apply(y.ptr, (vnDtype)y.dtype, y.sW, y.M(), C, stats, 1, a.ptr, (vnDtype)a.dtype, a.sW, 0, st);
+}
+
+}  // namespace
+
+extern "C" size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K) {
+    Plan P;
+    if (K < 0 || !make_plan(cfg, K, nullptr, &P)) return 0;
+    return P.bytes;
+}
+
+extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const float *heads_b,
+                              const void *dense, const int64_t *coord, int64_t K, void *workspace,
+                              size_t workspace_bytes, float *prob, float *reg, vnStream stream) {
+    VN_CHECK_ARG(cfg && L && heads_w && heads_b && dense && workspace && prob && reg && K >= 0);
+    VN_CHECK_ARG(!cfg->sparse_first || coord);
+    Plan P;
+    if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
+    if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
+    hipStream_t hs = vn_stream(stream);
+    const int training = cfg->training;
+    const float mom = 0.1f, eps = 1e-5f;
+    if (P.zf_end > P.zf_begin) VN_HIP(hipMemsetAsync(P.zf_begin, 0, (size_t)(P.zf_end - P.zf_begin), hs));
+    Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
+    Rows x1{}, x2{};
+    for (int l = 0; l < NL; ++l) {
+        const Spec &sp = P.spec[l];
+        const int taps = sp.k[0] * sp.k[1] * sp.k[2];
+        if (l == L_D1) x = x1;                 // deconv1 and block2 both read the block1 output
+        if (l == L_B2) x = x1;
+        if (l == L_D2 || l == L_B3) x = x2;
+        RT(vn_pack_weight(L[l].weight, sp.cout, sp.cin, taps, sp.transposed ? 2 : 0, 0, sp.cin_fold, P.wp_f[l],
+                          (vnDtype)P.adt, stream));
+        const Rows &y = P.y[l];
+        const int64_t M = y.M();
+        vnConv g = fwd_geom(sp, x, P.odims[l], y);
+        float *slab = (training && !sp.transposed) ? P.slab[l] : nullptr;
+        if (l == 0 && cfg->sparse_first) {
+            RT(vn_fill_rows(y.ptr, (vnDtype)y.dtype, M, sp.cout, sp.cout, L[l].bias, stream));
+            RT(vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
+            RT(vn_conv_gather_gemm_rows(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, &g, P.alist, P.acap,
+                                        P.acount, 0, slab, stream));
+        } else {
+            RT(vn_conv_gather_gemm(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, &g, 0, slab, stream));
+        }
+        if (slab) {
+            RT(vn_bn_finalize_slab(slab, P.slab_rows[l], M, sp.cout, L[l].bias, L[l].gamma, L[l].beta, L[l].running_mean,
+                                   L[l].running_var, mom, eps, P.stats[l], stream));
+        } else {
+            if (training)
+                RT(vn_bn_stats(y.ptr, (vnDtype)y.dtype, M, sp.cout, y.sW, 1, L[l].bias, P.fsums[l], stream));
+            RT(vn_bn_finalize(training ? P.fsums[l] : nullptr, M, sp.cout, 1, L[l].bias, L[l].gamma, L[l].beta,
+                              L[l].running_mean, L[l].running_var, training, mom, eps, P.stats[l], stream));
+        }
+        const Rows &a = P.a[l];
+        if (l == L_M2) {
+            const int H = P.odims[l][1], W = P.odims[l][2];
+            for (int b = 0; b < cfg->B; ++b)
+                for (int d = 0; d < 2; ++d)
+                    RT(vn_bn_apply(y.ptr + ((size_t)(b * 2 + d) * H * W * 64) * (y.dtype == VN_F32 ? 4 : 2),
+                                   (vnDtype)y.dtype, 64, (int64_t)H * W, 64, P.stats[l], 1,
+                                   a.ptr + ((size_t)b * H * W * 128 + d * 64) * P.esz, (vnDtype)a.dtype, 128, 0, stream));
+        } else {
+            RT(bn_apply_rows(y, P.stats[l], a, sp.cout, stream));
+        }
+        if (!sp.transposed) x = a;
+        if (l == L_D1 - 1) x1 = a;
+        if (l == L_D2 - 1) x2 = a;
+    }
+    // heads: one N=16 GEMM over the 768-channel concat + sigmoid on the first two channels (model.py:276-281)
+    {
+        Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
+        RT(vn_pack_weight(heads_w, 16, 768, 1, 0, 0, 1, P.hwp_f, (vnDtype)P.adt, stream));
+        const int od[3] = {1, P.hf, P.wf};
+        vnConv g = fwd_geom(hs16, P.cat, od, P.hy);
+        RT(vn_conv_gather_gemm(P.cat.ptr, P.hwp_f, heads_b, P.hy.ptr, VN_F32, &g, 0, nullptr, stream));
+        const int64_t S = (int64_t)P.hf * P.wf;
+        RT(vn_rows_to_nchw(P.hy.ptr, VN_F32, 16, cfg->B, 2, S, prob, 2, stream));
+        RT(vn_rows_to_nchw(P.hy.ptr + 2 * sizeof(float), VN_F32, 16, cfg->B, 14, S, reg, 0, stream));
+    }
+    return VN_OK;
+}
+
+extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const float *d_prob,
+                               const float *d_reg, const float *prob, const void *dense, const int64_t *coord,
+                               const void *vw_rows, int64_t K, void *workspace, size_t workspace_bytes,
+                               const vnLayerGrads *G, float *d_heads_w, float *d_heads_b, void *d_input,
+                               int32_t seg_begin, int32_t seg_end, vnStream stream) {
+    VN_CHECK_ARG(cfg && L && heads_w && d_prob && d_reg && prob && dense && workspace && G && d_heads_w && d_heads_b);
+    VN_CHECK_ARG(!cfg->sparse_first || (coord && vw_rows && d_input));
+    Plan P;
+    if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
+    if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
+    hipStream_t hs = vn_stream(stream);
+    // backward steps: 0 = heads, 1..23 = the BatchNorm layers in backward order; [seg_begin, seg_end) runs now
+    VN_CHECK_ARG(seg_begin >= 0 && seg_end <= NL + 1 && seg_begin < seg_end);
+    if (seg_begin == 0) VN_HIP(hipMemsetAsync(P.zb_begin, 0, (size_t)(P.zb_end - P.zb_begin), hs));
+    const int B = cfg->B;
+    const int64_t S = (int64_t)P.hf * P.wf;
+    // ---- heads
+    if (seg_begin == 0) {
+        Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
+        RT(vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows.ptr, (vnDtype)P.adt, 16, 0, stream));
+        RT(vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, P.hcs, stream));
+        VN_HIP(hipMemcpyAsync(d_heads_b, P.hcs, 16 * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        const int od[3] = {1, P.hf, P.wf};
+        const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
+        vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
+        RT(vn_conv_wgrad(P.cat.ptr, P.d_rows.ptr, P.hdwp, &gw, 0, stream));
+        RT(vn_unpack_wgrad(P.hdwp, 16, 768, 1, 0, 1, d_heads_w, stream));
+        RT(vn_pack_weight(heads_w, 16, 768, 1, 1, 0, 1, P.hwp_d, (vnDtype)P.adt, stream));
+        const int64_t os[4] = {P.d_cat.sB, P.d_cat.sD, P.d_cat.sH, P.d_cat.sW};
+        vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
+        RT(vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.pdt, &gd, 0, nullptr, stream));
+    }
+    auto cat_slice = [&](int off) {
+        Rows r = P.d_cat;
+        r.ptr += (size_t)off * (P.pdt == VN_F32 ? 4 : 2);
+        r.C = 256;
+        return r;
+    };
+    // input activation of every layer (as in the forward)
+    auto input_of = [&](int l) -> Rows {
+        if (l == 0) return dense_rows(const_cast<void *>(dense), P.adt, B, cfg->D, cfg->H, cfg->W, 128);
+        if (l == L_D1 || l == L_B2) return P.a[L_D1 - 1];
+        if (l == L_D2 || l == L_B3) return P.a[L_D2 - 1];
+        return P.a[l - 1];
+    };
+    // backward order: deconv3, block3 (5..0), deconv2, block2, deconv1, block1, middle 2,1,0
+    int order[NL], n = 0;
+    order[n++] = L_D3; for (int l = L_D3 - 1; l >= L_B3; --l) order[n++] = l;
+    order[n++] = L_D2; for (int l = L_D2 - 1; l >= L_B2; --l) order[n++] = l;
+    order[n++] = L_D1; for (int l = L_D1 - 1; l >= L_B1; --l) order[n++] = l;
+    order[n++] = 2; order[n++] = 1; order[n++] = 0;
+    for (int oi = 0; oi < NL; ++oi) {
+        if (oi + 1 < seg_begin || oi + 1 >= seg_end) continue;
+        const int l = order[oi];
+        const Spec &sp = P.spec[l];
+        const int taps = sp.k[0] * sp.k[1] * sp.k[2];
+        const int C = sp.cout;
+        const Rows &y = P.y[l];
+        const int64_t M = y.M();
+        // gradient w.r.t. this layer's activation
+        Rows da;
+        if (l == L_D3) da = cat_slice(0);
+        else if (l == L_D2) da = cat_slice(256);
+        else if (l == L_D1) da = cat_slice(512);
+        else if (l == L_D3 - 1) da = P.dx[L_D3];
+        else if (l == L_D2 - 1) da = P.dx[L_B3];   // block3.0's dx, deconv2 accumulated into it
+        else if (l == L_D1 - 1) da = P.dx[L_B2];
+        else da = P.dx[l + 1];
+        const Rows &dy = P.dy[l];
+        if (l == L_M2) {   // da is the BEV gradient (B,1,H,W,128): channel d*64+c
+            const int H = P.odims[l][1], W = P.odims[l][2];
+            const size_t des = da.dtype == VN_F32 ? 4 : 2, yes = y.dtype == VN_F32 ? 4 : 2;
+            for (int b = 0; b < B; ++b)
+                for (int d = 0; d < 2; ++d)
+                    RT(vn_bn_bwd_reduce(da.ptr + ((size_t)b * H * W * 128 + d * 64) * des, (vnDtype)da.dtype, 128,
+                                        y.ptr + (size_t)(b * 2 + d) * H * W * 64 * yes, (vnDtype)y.dtype, 64,
+                                        (int64_t)H * W, 64, P.stats[l], 1, P.bsums[l], stream));
+            RT(vn_bn_bwd_finalize(P.bsums[l], M, C, 1, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma, G[l].beta, stream));
+            for (int b = 0; b < B; ++b)
+                for (int d = 0; d < 2; ++d)
+                    RT(vn_bn_bwd_apply(da.ptr + ((size_t)b * H * W * 128 + d * 64) * des, (vnDtype)da.dtype, 128,
+                                       y.ptr + (size_t)(b * 2 + d) * H * W * 64 * yes, (vnDtype)y.dtype, 64,
+                                       (int64_t)H * W, 64, P.stats[l], P.coef[l], 1,
+                                       dy.ptr + (size_t)(b * 2 + d) * H * W * 64 * P.esz, (vnDtype)dy.dtype, 64, 0, stream));
+        } else {
+            RT(vn_bn_bwd_reduce(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
+                                P.bsums[l], stream));
+            RT(vn_bn_bwd_finalize(P.bsums[l], M, C, 1, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma, G[l].beta, stream));
+            RT(vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
+                               P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, stream));
+        }
+        VN_HIP(hipMemsetAsync(G[l].bias, 0, C * sizeof(float), hs));   // bias before a train-mode BN: exactly 0
+        const Rows x = input_of(l);
+        const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
+        if (l == 0 && cfg->sparse_first) {
+            const int64_t rs[4] = {0, 0, 0, 128};
+            vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
+            RT(vn_conv_wgrad_rows(dy.ptr, vw_rows, P.dwp[l], &gw, coord, K, stream));
+            RT(vn_unpack_wgrad(P.dwp[l], sp.cin, C, taps, 2, 1, G[l].weight, stream));
+            RT(vn_pack_weight(L[l].weight, sp.cout, sp.cin, taps, 1, 0, 1, P.wp_d[l], (vnDtype)P.adt, stream));
+            RT(vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr,
+                                        stream));
+            continue;
+        }
+        // weight gradient
+        if (sp.transposed) {
+            const int64_t rs[4] = {x.sB, x.sD, x.sH, x.sW};
+            vnConv gw = geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, rs);
+            RT(vn_conv_wgrad(dy.ptr, x.ptr, P.dwp[l], &gw, 0, stream));
+            RT(vn_unpack_wgrad(P.dwp[l], sp.cin, C, taps, 0, 1, G[l].weight, stream));
+        } else {
+            const int64_t rs[4] = {dy.sB, dy.sD, dy.sH, dy.sW};
+            vnConv gw = geom(x, P.odims[l], sp.cin, C, sp.k, sp.s, ONE, sp.p, ONE, rs);
+            RT(vn_conv_wgrad(x.ptr, dy.ptr, P.dwp[l], &gw, 0, stream));
+            RT(vn_unpack_wgrad(P.dwp[l], C, sp.cin, taps, 0, sp.cin_fold, G[l].weight, stream));
+        }
+        // data gradient
+        Rows dx = P.dx[l];
+        if (l == 0) {
+            if (!d_input) continue;
+            dx = dense_rows(d_input, P.pdt, B, cfg->D, cfg->H, cfg->W, 128);
+        }
+        const bool accumulate = (l == L_D1 || l == L_D2);
+        RT(vn_pack_weight(L[l].weight, sp.cout, sp.cin, taps, sp.transposed ? 3 : 1, 0, sp.cin_fold, P.wp_d[l],
+                          (vnDtype)P.adt, stream));
+        const int64_t os[4] = {dx.sB, dx.sD, dx.sH, dx.sW};
+        vnConv gd = sp.transposed ? geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, os)
+                                  : geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, os);
+        RT(vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr,
+                               stream));
+    }
+    return VN_OK;
+}

@@ -43,6 +43,18 @@ class VnVfeGrads(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in ("dw1", "db1", "dg1", "dbe1", "dw2", "db2", "dg2", "dbe2")]
 
 
+class VnNetConfig(ctypes.Structure):
+    _fields_ = [(n, c_i32) for n in ("B", "D", "H", "W", "block1_stride", "mode", "training", "sparse_first")]
+
+
+class VnLayerParams(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("weight", "bias", "gamma", "beta", "running_mean", "running_var")]
+
+
+class VnLayerGrads(ctypes.Structure):
+    _fields_ = [(n, c_vp) for n in ("weight", "bias", "gamma", "beta")]
+
+
 # name -> (restype, argtypes); mirrors include/voxelnet_hip.h one to one
 _P = ctypes.POINTER
 SIGNATURES = {
@@ -58,6 +70,11 @@ SIGNATURES = {
                                      c_i32, c_vp]),
     "vn_scatter_dense_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vn_conv_gather_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_i32, c_vp, c_vp]),
+    "vn_net_workspace_bytes": (c_sz, [_P(VnNetConfig), c_i64]),
+    "vn_net_forward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
+                               c_vp, c_vp]),
+    "vn_net_backward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                c_vp, c_sz, _P(VnLayerGrads), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vn_conv_stats_slab_rows": (c_i64, [_P(VnConv)]),
     "vn_bn_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
     "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp]),

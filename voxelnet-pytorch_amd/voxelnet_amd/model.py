@@ -200,10 +200,10 @@ def featnet_forward(feature, params, bufs, training):
     return vw, stats, (w, ws, ws_bytes)
 
 
-def featnet_backward(feature, wstruct, stats, d_vw, params):
+def featnet_backward(feature, wstruct, stats, d_vw, params, out=None):
     w, ws, ws_bytes = wstruct
     K, T = feature.shape[0], feature.shape[1]
-    grads = [torch.empty_like(p) for p in params]
+    grads = out if out is not None else [torch.empty_like(p) for p in params]
     g = _lib.VnVfeGrads(*[t.data_ptr() for t in grads])
     d_vw = d_vw.contiguous()
     _lib.call("vn_vfe_bwd", feature.data_ptr(), K, T, ctypes.byref(w), stats.data_ptr(), d_vw.data_ptr(),
@@ -398,6 +398,57 @@ class MiddleConvNet(nn.Module):
         return prob, reg
 
 
+# backward segments of the native executor (vn_net_backward steps) that complete a DDP bucket each
+# (parallel.BUCKET_PLAN): heads+deconv3+block3 | deconv2+block2+deconv1 | block1 | middle_layer (+ VFE after it)
+NATIVE_SEGMENTS = [(0, 8), (8, 16), (16, 21), (21, 24)]
+
+
+def _native_layer_arrays(mid, grad_views=None):
+    """ctypes arrays of vnLayerParams (and vnLayerGrads) in execution order"""
+    table = N.layer_table(mid._block1_stride)
+    arr = (_lib.VnLayerParams * len(table))()
+    garr = (_lib.VnLayerGrads * len(table))() if grad_views is not None else None
+    for i, (name, spec) in enumerate(table):
+        blk, _, idx = name.partition(".")
+        m = getattr(mid, blk)
+        if idx:
+            m = m[int(idx)]
+        conv = m.deconv if spec.transposed else m.conv
+        bn = m.batch_norm
+        arr[i] = _lib.VnLayerParams(conv.weight.data_ptr(), conv.bias.data_ptr(), bn.weight.data_ptr(),
+                                    bn.bias.data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr())
+        if garr is not None:
+            cv = "deconv" if spec.transposed else "conv"
+            pre = f"middle_rpn.{name}."
+            garr[i] = _lib.VnLayerGrads(grad_views[pre + cv + ".weight"].data_ptr(), grad_views[pre + cv + ".bias"].data_ptr(),
+                                        grad_views[pre + "batch_norm.weight"].data_ptr(),
+                                        grad_views[pre + "batch_norm.bias"].data_ptr())
+    return arr, garr
+
+
+def _grad_views(rpn):
+    """name -> gradient tensor the kernels write into: the DDP buckets' views when a reducer is attached, else
+    views of one persistent flat buffer owned by the module (no per-step allocation of 104 tensors)."""
+    if rpn.grad_reducer is not None:
+        out = {}
+        for b in rpn.grad_reducer.buckets:
+            out.update(b["views"])
+        return out
+    named = list(rpn.named_parameters())
+    key = tuple((n, p.data_ptr()) for n, p in named[:2]) + (named[0][1].device,)
+    cache = rpn.__dict__.get("_flat_grads")
+    if cache is None or cache[0] != key:
+        total = sum(p.numel() for _, p in named)
+        flat = torch.zeros(total, dtype=torch.float32, device=named[0][1].device)
+        views, off = {}, 0
+        for n, p in named:
+            views[n] = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        cache = (key, flat, views)
+        rpn.__dict__["_flat_grads"] = cache
+    return cache[2]
+
+
 class _DetectorFn(torch.autograd.Function):
     """feature_net + middle_rpn fused: the dense grid is written once, directly in the conv
     kernels' bf16 / [hi|lo] row format, and never exists as an fp32 NDHWC tensor."""
@@ -412,6 +463,40 @@ class _DetectorFn(torch.autograd.Function):
         names, P, Bf, _ = _collect_middle(mid)
         P = _detached(P)
         P["heads"] = _heads_params([f.detach() for f in flat[nv:]])
+        native = rpn.native_executor and not E.is_split(mode) and fn._grid.D == 10
+        if native:
+            with torch.cuda.device(feature.device):
+                vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
+                dense = scatter_rows(vw, coord, B, fn._grid.dims, mode)
+                if mode == "fp32":
+                    vw_rows = vw
+                else:
+                    vw_rows = torch.empty((vw.shape[0], 128), dtype=torch.bfloat16, device=vw.device)
+                    _lib.call("vn_cast_rows", vw.data_ptr(), _lib.VN_F32, 128, vw.shape[0], 128, vw_rows.data_ptr(),
+                              _lib.VN_BF16, 128, 0, E.stream())
+                D, H, W = fn._grid.dims
+                cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, 1 if mode == "fp32" else 0, int(training),
+                                       int(bool(rpn.sparse_first_layer)))
+                K = vw.shape[0]
+                heads = _heads_params([f.detach() for f in flat[nv:]])
+                arr, _ = _native_layer_arrays(mid)
+                lib = _lib.load()
+                ws_bytes = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
+                if ws_bytes == 0:
+                    raise _lib.VoxelnetHipError("vn_net_workspace_bytes: unsupported network configuration")
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=vw.device)
+                hf, wf = H // mid._block1_stride, W // mid._block1_stride
+                prob = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=vw.device)
+                reg = torch.empty((B, 14, hf, wf), dtype=torch.float32, device=vw.device)
+                _lib.call("vn_net_forward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), heads["bias"].data_ptr(),
+                          dense.ptr(), coord.data_ptr(), K, ws.data_ptr(), ws_bytes, prob.data_ptr(), reg.data_ptr(),
+                          E.stream())
+            ctx.saved = (feature, coord, stats, wst, vparams, (cfg, ws, ws_bytes, dense, vw_rows, heads, prob), None, None)
+            ctx.reducer = rpn.grad_reducer
+            ctx.rpn = rpn
+            ctx.native = True
+            return prob, reg
+        ctx.native = False
         with torch.cuda.device(feature.device):
             vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
             dense = scatter_rows(vw, coord, B, fn._grid.dims, mode)
@@ -433,6 +518,8 @@ class _DetectorFn(torch.autograd.Function):
     def backward(ctx, d_prob, d_reg):
         feature, coord, stats, wst, vparams, st, P, names = ctx.saved
         red = ctx.reducer
+        if ctx.native:
+            return _DetectorFn._backward_native(ctx, d_prob, d_reg)
         on_grads = None
         if red is not None:
             def on_grads(name, g):
@@ -456,6 +543,71 @@ class _DetectorFn(torch.autograd.Function):
                 for key, g in zip(VFE_KEYS, vg):
                     red.grad_ready(key, g)
         return (None, None, None, None, None) + tuple(vg) + tuple(_middle_grads_flat(names, G))
+
+
+def _detector_backward_native(ctx, d_prob, d_reg):
+    feature, coord, stats, wst, vparams, nat, _, _ = ctx.saved
+    cfg, ws, ws_bytes, dense, vw_rows, heads, prob = nat
+    rpn, red = ctx.rpn, ctx.reducer
+    mid = rpn.middle_rpn
+    K = feature.shape[0]
+    dev = d_prob.device
+    views = _grad_views(rpn)
+    accumulate = any(p.grad is not None for p in rpn.parameters())   # someone wants sums: hand out copies
+    with torch.cuda.device(dev):
+        arr, garr = _native_layer_arrays(mid, views)
+        dhw = torch.empty((16, 768, 1, 1), dtype=torch.float32, device=dev)
+        dhb = torch.empty(16, dtype=torch.float32, device=dev)
+        d_vw = torch.empty((K, 128), dtype=torch.float32, device=dev)
+        dp, dr = d_prob.contiguous().float(), d_reg.contiguous().float()
+        d_in = d_vw if cfg.sparse_first else torch.empty_like(dense.t)
+        table = N.layer_table(mid._block1_stride)
+        order = [22] + list(range(21, 15, -1)) + [15] + list(range(14, 8, -1)) + [8] + list(range(7, 2, -1)) + [2, 1, 0]
+        for sb, se in NATIVE_SEGMENTS:
+            _lib.call("vn_net_backward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
+                      prob.data_ptr(), dense.ptr(), coord.data_ptr(), vw_rows.data_ptr(), K, ws.data_ptr(), ws_bytes, garr,
+                      dhw.data_ptr(), dhb.data_ptr(), d_in.data_ptr(), sb, se, E.stream())
+            if sb == 0:
+                views["middle_rpn.prob_conv.conv.weight"].copy_(dhw[:2])
+                views["middle_rpn.prob_conv.conv.bias"].copy_(dhb[:2])
+                views["middle_rpn.reg_conv.conv.weight"].copy_(dhw[2:])
+                views["middle_rpn.reg_conv.conv.bias"].copy_(dhb[2:])
+            if red is not None:
+                names = []
+                if sb == 0:
+                    names += ["middle_rpn.prob_conv.conv.weight", "middle_rpn.prob_conv.conv.bias",
+                              "middle_rpn.reg_conv.conv.weight", "middle_rpn.reg_conv.conv.bias"]
+                for step in range(max(sb, 1), se):
+                    name, spec = table[order[step - 1]]
+                    cv = "deconv" if spec.transposed else "conv"
+                    names += [f"middle_rpn.{name}.{cv}.weight", f"middle_rpn.{name}.{cv}.bias",
+                              f"middle_rpn.{name}.batch_norm.weight", f"middle_rpn.{name}.batch_norm.bias"]
+                if se < 24:
+                    for n in names:
+                        red.grad_ready(n, views[n])
+                else:
+                    last_names = names
+        if not cfg.sparse_first:
+            d_vw = gather_rows(Rows(d_in, 128), coord, K, 128)
+        vg = featnet_backward(feature, wst, stats, d_vw, vparams, out=[views[k] for k in VFE_KEYS])
+        if red is not None:
+            for n in last_names + VFE_KEYS:
+                red.grad_ready(n, views[n])
+    mg = []
+    for name, spec in table:
+        cv = "deconv" if spec.transposed else "conv"
+        pre = f"middle_rpn.{name}."
+        mg += [views[pre + cv + ".weight"], views[pre + cv + ".bias"], views[pre + "batch_norm.weight"],
+               views[pre + "batch_norm.bias"]]
+    mg += [views["middle_rpn.prob_conv.conv.weight"], views["middle_rpn.prob_conv.conv.bias"],
+           views["middle_rpn.reg_conv.conv.weight"], views["middle_rpn.reg_conv.conv.bias"]]
+    out = list(vg) + mg
+    if accumulate:
+        out = [g.clone() for g in out]
+    return (None, None, None, None, None) + tuple(out)
+
+
+_DetectorFn._backward_native = staticmethod(_detector_backward_native)
 
 
 def smooth_L1_loss(deltas, targets, sigma=3.0):
@@ -482,6 +634,7 @@ class RPN3D(nn.Module):
         self.rpn_output_shape = self.middle_rpn.output_shape
         self.target_fn = None    # callable(label, rpn_output_shape) -> (pos, neg, targets)
         self.sparse_first_layer = True   # first Conv3d only at active sites / occupied voxels (same results)
+        self.native_executor = True      # C++ step executor (csrc/runtime.hip) instead of per-launch Python calls
         self.grad_reducer = None  # parallel.GradAllReducer: bucketed all-reduce overlapped with backward
 
     def detect(self, voxel_features, voxel_coordinates):

@@ -73,7 +73,8 @@ class GradAllReducer:
     def grad_ready(self, name, grad):
         """called as soon as a parameter's gradient exists (in backward order)"""
         b = self.buckets[self.where[name]]
-        b["views"][name].copy_(grad)
+        if grad.data_ptr() != b["views"][name].data_ptr():   # the kernels may already have written into the bucket
+            b["views"][name].copy_(grad)
         b["pending"].discard(name)
         if not b["pending"]:
             self._launch(b)
