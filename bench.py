@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="experimental: replay the post-voxelizer part of the step from captured HIP graphs")
     ap.add_argument("--timer-steps", type=int, default=3)
+    ap.add_argument("--force-reducer", action="store_true",
+                    help="diagnostic: run the DDP bucket path (flat buckets, segmented backward) on one GPU")
     ap.add_argument("--static-voxels", action="store_true",
                     help="diagnostic: voxelize once, outside the timed steps (NOT the benchmark configuration)")
     args = ap.parse_args()
@@ -105,6 +107,7 @@ def main():
     if world > 1:
         for p in params:
             dist.broadcast(p.data, 0)
+    if world > 1 or args.force_reducer:
         model.grad_reducer = parallel.GradAllReducer(named)
 
     B = args.batch

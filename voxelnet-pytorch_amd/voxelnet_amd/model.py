@@ -387,9 +387,11 @@ class MiddleConvNet(nn.Module):
 
     def _tick(self):
         if self.training:
-            for m in self.modules():
-                if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d)):
-                    m.num_batches_tracked += 1
+            ctrs = self.__dict__.get("_nbt")
+            if ctrs is None or ctrs[0].device != self.prob_conv.conv.weight.device:
+                ctrs = [m.num_batches_tracked for m in self.modules() if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm3d))]
+                self.__dict__["_nbt"] = ctrs
+            torch._foreach_add_(ctrs, 1)
 
     def forward(self, x):
         _, _, _, flat = _collect_middle(self)
@@ -603,7 +605,14 @@ def _detector_backward_native(ctx, d_prob, d_reg):
            views["middle_rpn.reg_conv.conv.weight"], views["middle_rpn.reg_conv.conv.bias"]]
     out = list(vg) + mg
     if accumulate:
-        out = [g.clone() for g in out]
+        return (None, None, None, None, None) + tuple(g.clone() for g in out)
+    if rpn.direct_grads:
+        # hand the gradients to the parameters directly: returning the (shared) views through autograd would make
+        # AccumulateGrad clone all 104 of them every step
+        plist = _vfe_weights(rpn.feature_net) + _collect_middle(mid)[3]
+        for p_, g_ in zip(plist, out):
+            p_.grad = g_
+        return (None,) * (5 + len(out))
     return (None, None, None, None, None) + tuple(out)
 
 
@@ -634,6 +643,8 @@ class RPN3D(nn.Module):
         self.rpn_output_shape = self.middle_rpn.output_shape
         self.target_fn = None    # callable(label, rpn_output_shape) -> (pos, neg, targets)
         self.sparse_first_layer = True   # first Conv3d only at active sites / occupied voxels (same results)
+        self.direct_grads = True         # native path: .grad = views of one persistent flat buffer (no clones);
+        #                                  set False to accumulate gradients over several backward() calls
         self.native_executor = True      # C++ step executor (csrc/runtime.hip) instead of per-launch Python calls
         self.grad_reducer = None  # parallel.GradAllReducer: bucketed all-reduce overlapped with backward
 
