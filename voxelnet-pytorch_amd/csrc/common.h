@@ -46,3 +46,15 @@ __device__ __forceinline__ int vn_wave_min_i32(int v) {
     for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Buffer descriptor from values the compiler can PROVE wave-uniform (cdna_hip_programming.md T20): without
+// the readfirstlane of the pointer halves and the size, hipcc wraps every buffer_load ... lds that uses the
+// descriptor in a waterfall loop (v_readfirstlane x4 + s_and_saveexec + loop), ~15 instructions and a
+// serialisation point per load.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t vn_uniform_rsrc(const void *base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    const uint32_t n = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, (int)n, 0x00020000);
+}

@@ -175,10 +175,8 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     const char *src_base = p.src + (int64_t)b0 * p.sB * ESZ;
     int64_t src_bytes = ((int64_t)(p.B - b0 - 1) * p.sB + p.src_batch_extent) * ESZ;
     if (src_bytes > (int64_t)GG_MAX_WINDOW) src_bytes = GG_MAX_WINDOW;
-    const __amdgpu_buffer_rsrc_t rs_a =
-        __builtin_amdgcn_make_buffer_rsrc((void *)src_base, 0, (int)(uint32_t)src_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b =
-        __builtin_amdgcn_make_buffer_rsrc((void *)p.w, 0, (int)p.w_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_a = vn_uniform_rsrc(src_base, (uint32_t)src_bytes);
+    const __amdgpu_buffer_rsrc_t rs_b = vn_uniform_rsrc(p.w, p.w_bytes);
 
     constexpr int BKE = 128 / ESZ;            // elements per K step
     constexpr int EPC = 16 / ESZ;             // elements per 16-B chunk
@@ -198,7 +196,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         const int k_src = (p.src_wrap > 0 && k_lane >= p.src_wrap) ? k_lane - p.src_wrap : k_lane;
         const uint32_t a_koff = (uint32_t)k_src * (uint32_t)ESZ;
         const uint32_t b_koff = (uint32_t)k_lane * (uint32_t)ESZ;
-        const uint32_t b_soff = (uint32_t)((int64_t)tp.widx * p.N * p.Cs * ESZ);
+        const uint32_t b_soff = __builtin_amdgcn_readfirstlane((uint32_t)((int64_t)tp.widx * p.N * p.Cs * ESZ));
         char *la = smem + buf * STAGE + wave * 1024;
         char *lb = smem + buf * STAGE + A_BYTES + wave * 1024;
 #pragma unroll

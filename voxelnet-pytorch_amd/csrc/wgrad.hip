@@ -61,18 +61,19 @@ __device__ __forceinline__ int chunk_swz(int row) {
     return ((row & 3) << 1) | (((row >> 3) & 1) << 3);   // 256-B rows
 }
 
-template <int TN, int TK, bool F32>   // wave tile in units of 16 channels; 2x2 waves
+template <int TN, int TK, bool F32, int TPB>   // wave tile in units of 16 channels; 2x2 waves; taps per workgroup
 __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     constexpr int ESZ = F32 ? 4 : 2;
     constexpr int ROWS = F32 ? 32 : 64;                     // sites per stage (same bytes either way)
     constexpr int DN = 32 * TN, DK = 32 * TK;
     constexpr int RBN = DN * ESZ, RBK = DK * ESZ;           // LDS row bytes
     constexpr int TILE_N = ROWS * RBN, TILE_K = ROWS * RBK; // bytes per stage
-    constexpr int STAGE = TILE_N + TILE_K;
-    constexpr int IN = TILE_N / 4096, IK = TILE_K / 4096;   // DMA instructions per wave per stage
+    constexpr int STAGE = TILE_N + TPB * TILE_K;            // one `rows` slab shared by TPB gathered slabs
+    constexpr int IN = TILE_N / 4096, IK = TILE_K / 4096;   // DMA instructions per wave per stage (per tile)
     constexpr int LPR_N = RBN / 16, LPR_K = RBK / 16;       // lanes per row
+    constexpr int TW = TPB + 1;                             // table words per row: TPB source offsets + row offset
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + 2 * STAGE);   // [2][64][2]
+    uint32_t *tbl = reinterpret_cast<uint32_t *>(smem + 2 * STAGE);   // [2][64][TW]
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -80,8 +81,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     const int tile = blockIdx.z;
     const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
     const int n0 = tn * DN, k0 = tk * DK;
-    const int tap = blockIdx.y;
-    const int td = tap / (p.kH * p.kW), th = (tap / p.kW) % p.kH, tw = tap % p.kW;
+    const int tap0 = blockIdx.y * TPB;          // TPB == 3: the three kW taps of one (kd, kh)
+    const int td = tap0 / (p.kH * p.kW), th = (tap0 / p.kW) % p.kH, tw0 = tap0 % p.kW;
     const bool list = p.row_list != nullptr;
     const int64_t M = list ? p.n_rows : (int64_t)p.B * p.Dr * p.Hr * p.Wr;
     const int64_t rbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
@@ -92,10 +93,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     const int nv = p.split ? 3 : 1;
     const int nstages = nsteps * nv;
 
-    const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc((void *)p.src, 0, (int)p.src_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc((void *)p.rows, 0, (int)p.rows_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_s = vn_uniform_rsrc(p.src, p.src_bytes);
+    const __amdgpu_buffer_rsrc_t rs_r = vn_uniform_rsrc(p.rows, p.rows_bytes);
 
-    // ---- row table producer state (wave 0: lane <-> row of the current 64-row slab) ----
+    // ---- row table producer state (wave 0: lane <-> row of the current slab) ----
     int cb = 0, cd = 0, ch = 0, cw = 0;
     int64_t cm = rbeg + lane;   // the site this lane tracks
     int tstep = 0;              // slab index its coordinates stand for
@@ -107,9 +108,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
         cb = (int)(t / p.Dr);
     }
     auto table_write = [&](int stage_idx) {
-        // wave 0 only: entry for slab (stage_idx / nv) into tbl[stage_idx & 1]
+        // wave 0 only: entries for slab (stage_idx / nv) into tbl[stage_idx & 1]
         const int step = stage_idx / nv;
-        uint32_t so = WG_OOB, ro = WG_OOB;
+        uint32_t so[TPB], ro = WG_OOB;
+#pragma unroll
+        for (int j = 0; j < TPB; ++j) so[j] = WG_OOB;
         if (list) {
             const int64_t m = rbeg + (int64_t)step * ROWS + lane;
             if (m < rend && lane < ROWS) {
@@ -117,68 +120,84 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
                 const int b = (int)rc[0];
                 int sd = (int)rc[1] * p.mulD + td * p.tmulD - p.padD;
                 int sh = (int)rc[2] * p.mulH + th * p.tmulH - p.padH;
-                int sw = (int)rc[3] * p.mulW + tw * p.tmulW - p.padW;
                 ro = (uint32_t)(m * p.rW * ESZ);
-                const bool div_ok = sd >= 0 && sh >= 0 && sw >= 0 && sd % p.divD == 0 && sh % p.divH == 0 && sw % p.divW == 0;
-                sd /= p.divD; sh /= p.divH; sw /= p.divW;
-                if (div_ok && sd < p.Ds && sh < p.Hs && sw < p.Ws)
-                    so = (uint32_t)(((int64_t)b * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW) * ESZ);
+                const bool dh_ok = sd >= 0 && sh >= 0 && sd % p.divD == 0 && sh % p.divH == 0;
+                sd /= p.divD; sh /= p.divH;
+#pragma unroll
+                for (int j = 0; j < TPB; ++j) {
+                    int sw = (int)rc[3] * p.mulW + (tw0 + j) * p.tmulW - p.padW;
+                    const bool ok = dh_ok && sw >= 0 && sw % p.divW == 0;
+                    sw /= p.divW;
+                    if (ok && sd < p.Ds && sh < p.Hs && sw < p.Ws)
+                        so[j] = (uint32_t)(((int64_t)b * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW) * ESZ);
+                }
             }
         } else {
-        while (tstep < step) {   // advance by ROWS sites
-            cm += ROWS;
-            cw += ROWS;
-            while (cw >= p.Wr) {
-                cw -= p.Wr;
-                if (++ch >= p.Hr) { ch = 0; if (++cd >= p.Dr) { cd = 0; ++cb; } }
+            while (tstep < step) {   // advance by ROWS sites
+                cm += ROWS;
+                cw += ROWS;
+                while (cw >= p.Wr) {
+                    cw -= p.Wr;
+                    if (++ch >= p.Hr) { ch = 0; if (++cd >= p.Dr) { cd = 0; ++cb; } }
+                }
+                ++tstep;
             }
-            ++tstep;
+            if (cm < rend) {
+                const int sd = cd * p.mulD + td * p.tmulD - p.padD;
+                const int sh = ch * p.mulH + th * p.tmulH - p.padH;
+                ro = (uint32_t)(((int64_t)cb * p.rB + (int64_t)cd * p.rD + (int64_t)ch * p.rH + (int64_t)cw * p.rW) * ESZ);
+                if ((unsigned)sd < (unsigned)p.Ds && (unsigned)sh < (unsigned)p.Hs) {
+                    const int64_t base = (int64_t)cb * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH;
+#pragma unroll
+                    for (int j = 0; j < TPB; ++j) {
+                        const int sw = cw * p.mulW + (tw0 + j) * p.tmulW - p.padW;
+                        if ((unsigned)sw < (unsigned)p.Ws) so[j] = (uint32_t)((base + (int64_t)sw * p.sW) * ESZ);
+                    }
+                }
+            }
         }
-        if (cm < rend) {
-            const int sd = cd * p.mulD + td * p.tmulD - p.padD;
-            const int sh = ch * p.mulH + th * p.tmulH - p.padH;
-            const int sw = cw * p.mulW + tw * p.tmulW - p.padW;
-            ro = (uint32_t)(((int64_t)cb * p.rB + (int64_t)cd * p.rD + (int64_t)ch * p.rH + (int64_t)cw * p.rW) * ESZ);
-            if ((unsigned)sd < (unsigned)p.Ds && (unsigned)sh < (unsigned)p.Hs && (unsigned)sw < (unsigned)p.Ws)
-                so = (uint32_t)(((int64_t)cb * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH + (int64_t)sw * p.sW) * ESZ);
-        }
-        }
-        uint32_t *e = tbl + ((stage_idx & 1) * 64 + lane) * 2;
-        e[0] = so;
-        e[1] = ro;
+        uint32_t *e = tbl + ((stage_idx & 1) * 64 + lane) * TW;
+#pragma unroll
+        for (int j = 0; j < TPB; ++j) e[j] = so[j];
+        e[TPB] = ro;
     };
 
     // per-lane DMA geometry: instruction i of this wave covers LDS bytes ((i*4+wave)*1024 .. +1023) of a tile
     auto stage = [&](int sidx, int buf) {
         const int v = sidx % nv;   // bf16x3 variant: 0 hi*hi, 1 lo(src)*hi(rows), 2 hi(src)*lo(rows)
-        const uint32_t s_col = (uint32_t)((k0 + (v == 1 ? p.C : 0)) * ESZ);
-        const uint32_t r_col = (uint32_t)((n0 + (v == 2 ? p.N : 0)) * ESZ);
-        const uint32_t *t = tbl + (sidx & 1) * 128;
+        const uint32_t s_col = __builtin_amdgcn_readfirstlane((uint32_t)((k0 + (v == 1 ? p.C : 0)) * ESZ));
+        const uint32_t r_col = __builtin_amdgcn_readfirstlane((uint32_t)((n0 + (v == 2 ? p.N : 0)) * ESZ));
+        const uint32_t *t = tbl + (sidx & 1) * 64 * TW;
         char *ln = smem + buf * STAGE + wave * 1024;
-        char *lk = smem + buf * STAGE + TILE_N + wave * 1024;
 #pragma unroll
         for (int i = 0; i < IN; ++i) {
             const int r = ((i * 4 + wave) * 1024) / RBN + lane / LPR_N;
             const int c = (lane % LPR_N) ^ chunk_swz<RBN, F32>(r);
-            const uint32_t ro = t[r * 2 + 1];
+            const uint32_t ro = t[r * TW + TPB];
             const bool ok = ro != WG_OOB && (n0 + c * (16 / ESZ)) < p.N;
             lds_dma16(rs_r, ln + i * 4096, ok ? ro + (uint32_t)c * 16u : WG_OOB, r_col);
         }
 #pragma unroll
-        for (int i = 0; i < IK; ++i) {
-            const int r = ((i * 4 + wave) * 1024) / RBK + lane / LPR_K;
-            const int c = (lane % LPR_K) ^ chunk_swz<RBK, F32>(r);
-            const uint32_t so = t[r * 2];
-            const bool ok = so != WG_OOB && (k0 + c * (16 / ESZ)) < p.C;
-            lds_dma16(rs_s, lk + i * 4096, ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
+        for (int j = 0; j < TPB; ++j) {
+            char *lk = smem + buf * STAGE + TILE_N + j * TILE_K + wave * 1024;
+#pragma unroll
+            for (int i = 0; i < IK; ++i) {
+                const int r = ((i * 4 + wave) * 1024) / RBK + lane / LPR_K;
+                const int c = (lane % LPR_K) ^ chunk_swz<RBK, F32>(r);
+                const uint32_t so = t[r * TW + j];
+                const bool ok = so != WG_OOB && (k0 + c * (16 / ESZ)) < p.C;
+                lds_dma16(rs_s, lk + i * 4096, ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
+            }
         }
     };
 
-    f32x4_t acc[TN][TK];
+    f32x4_t acc[TPB][TN][TK];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int t = 0; t < TPB; ++t)
 #pragma unroll
-        for (int j = 0; j < TK; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TK; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // transposed-read lane geometry: lane = 16g + 4q + pp -> row (8g + q [+4]), 8-B piece pp of a 16-column tile
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
@@ -194,7 +213,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
         if (s + 1 < nstages) stage(s + 1, buf ^ 1);
         if (wave == 0 && s + 2 < nstages) table_write(s + 2);
         const char *ln = smem + buf * STAGE;
-        const char *lk = smem + buf * STAGE + TILE_N;
+        const char *lk0 = smem + buf * STAGE + TILE_N;
         if constexpr (F32) {
             // v_mfma_f32_16x16x4_f32: lane (c = lane&15, kq = lane>>4) supplies element [site 4s+kq][col c]
             const int fc = lane & 15, kq = lane >> 4;
@@ -202,82 +221,93 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
             for (int ss = 0; ss < ROWS / 4; ++ss) {
                 const int r = ss * 4 + kq;
                 const int sw = chunk_swz<RBN, true>(r);     // same function for both tiles (row & 3)
-                float a[TN], b[TK];
+                float a[TN];
 #pragma unroll
                 for (int i = 0; i < TN; ++i) {
                     const int col = (wn * TN + i) * 16 + fc;
                     a[i] = *reinterpret_cast<const float *>(ln + r * RBN + ((((col >> 2) ^ sw)) << 4) + (col & 3) * 4);
                 }
 #pragma unroll
-                for (int j = 0; j < TK; ++j) {
-                    const int col = (wk * TK + j) * 16 + fc;
-                    b[j] = *reinterpret_cast<const float *>(lk + r * RBK + ((((col >> 2) ^ sw)) << 4) + (col & 3) * 4);
+                for (int t = 0; t < TPB; ++t) {
+                    float b[TK];
+#pragma unroll
+                    for (int j = 0; j < TK; ++j) {
+                        const int col = (wk * TK + j) * 16 + fc;
+                        b[j] = *reinterpret_cast<const float *>(lk0 + t * TILE_K + r * RBK + ((((col >> 2) ^ sw)) << 4) + (col & 3) * 4);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TK; ++j)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[t][i][j], 0, 0, 0);
                 }
-#pragma unroll
-                for (int i = 0; i < TN; ++i)
-#pragma unroll
-                    for (int j = 0; j < TK; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
             }
         } else {
-        typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const int r0 = ks * 32 + g * 8 + q, r1 = r0 + 4;
-            bf16x8_t a[TN], b[TK];
+            for (int ks = 0; ks < 2; ++ks) {
+                const int r0 = ks * 32 + g * 8 + q, r1 = r0 + 4;
+                bf16x8_t a[TN];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) {
-                const int col = (wn * TN + i) * 16 + pp * 4;          // element column inside the tile
-                const int c16 = col >> 3, half = (col >> 2) & 1;      // 16-B chunk, 8-B half
-                const char *p0 = ln + r0 * RBN + ((c16 ^ chunk_swz<RBN, false>(r0)) << 4) + half * 8;
-                const char *p1 = ln + r1 * RBN + ((c16 ^ chunk_swz<RBN, false>(r1)) << 4) + half * 8;
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
-                const s16x8_t t8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                a[i] = __builtin_bit_cast(bf16x8_t, t8);
+                for (int i = 0; i < TN; ++i) {
+                    const int col = (wn * TN + i) * 16 + pp * 4;          // element column inside the tile
+                    const int c16 = col >> 3, half = (col >> 2) & 1;      // 16-B chunk, 8-B half
+                    const char *p0 = ln + r0 * RBN + ((c16 ^ chunk_swz<RBN, false>(r0)) << 4) + half * 8;
+                    const char *p1 = ln + r1 * RBN + ((c16 ^ chunk_swz<RBN, false>(r1)) << 4) + half * 8;
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
+                    const s16x8_t t8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    a[i] = __builtin_bit_cast(bf16x8_t, t8);
+                }
+#pragma unroll
+                for (int t = 0; t < TPB; ++t) {
+                    bf16x8_t b[TK];
+#pragma unroll
+                    for (int j = 0; j < TK; ++j) {
+                        const int col = (wk * TK + j) * 16 + pp * 4;
+                        const int c16 = col >> 3, half = (col >> 2) & 1;
+                        const char *p0 = lk0 + t * TILE_K + r0 * RBK + ((c16 ^ chunk_swz<RBK, false>(r0)) << 4) + half * 8;
+                        const char *p1 = lk0 + t * TILE_K + r1 * RBK + ((c16 ^ chunk_swz<RBK, false>(r1)) << 4) + half * 8;
+                        const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
+                        const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
+                        const s16x8_t t8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        b[j] = __builtin_bit_cast(bf16x8_t, t8);
+                    }
+#pragma unroll
+                    for (int i = 0; i < TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < TK; ++j)
+                            acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[t][i][j], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int j = 0; j < TK; ++j) {
-                const int col = (wk * TK + j) * 16 + pp * 4;
-                const int c16 = col >> 3, half = (col >> 2) & 1;
-                const char *p0 = lk + r0 * RBK + ((c16 ^ chunk_swz<RBK, false>(r0)) << 4) + half * 8;
-                const char *p1 = lk + r1 * RBK + ((c16 ^ chunk_swz<RBK, false>(r1)) << 4) + half * 8;
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
-                const s16x8_t t8 = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                b[j] = __builtin_bit_cast(bf16x8_t, t8);
-            }
-#pragma unroll
-            for (int i = 0; i < TN; ++i)
-#pragma unroll
-                for (int j = 0; j < TK; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
         }
     }
 
     // D[n][k]: n = (lane>>4)*4 + e, k = lane&15
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int t = 0; t < TPB; ++t)
 #pragma unroll
-        for (int j = 0; j < TK; ++j) {
-            const int k = k0 + (wk * TK + j) * 16 + (lane & 15);
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = n0 + (wn * TN + i) * 16 + (lane >> 4) * 4 + e;
-                if (n < p.N && k < p.C) atomicAdd(p.dw + ((int64_t)tap * p.N + n) * p.C + k, acc[i][j][e]);
+            for (int j = 0; j < TK; ++j) {
+                const int k = k0 + (wk * TK + j) * 16 + (lane & 15);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + (wn * TN + i) * 16 + (lane >> 4) * 4 + e;
+                    if (n < p.N && k < p.C) atomicAdd(p.dw + ((int64_t)(tap0 + t) * p.N + n) * p.C + k, acc[t][i][j][e]);
+                }
             }
-        }
 }
 
-template <int TN, int TK, bool F32>
+template <int TN, int TK, bool F32, int TPB>
 int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
     constexpr int DN = 32 * TN, DK = 32 * TK;
-    constexpr size_t lds = 2u * 64u * (DN + DK) * 2u + 2u * 64u * 2u * 4u;   // same bytes for bf16 (64 sites) and fp32 (32)
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK, F32>),
+    // same stage bytes for bf16 (64 sites) and fp32 (32 sites); + the row table
+    constexpr size_t lds = 2u * 64u * (DN + TPB * DK) * 2u + 2u * 64u * (TPB + 1) * 4u;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK, F32, TPB>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    k_wgrad<TN, TK, F32><<<grid, 256, lds, st>>>(p);
+    k_wgrad<TN, TK, F32, TPB><<<grid, 256, lds, st>>>(p);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -337,17 +367,21 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     p.rows_bytes = (uint32_t)rbytes;
 
     const int taps = g->kD * g->kH * g->kW;
-    const bool n128 = g->Cr > 64, k128 = g->Cs > 64;
+    // three-tap mode (bf16): one workgroup owns the three kW taps of a (kd,kh) pair, a 64-row `rows` slab is
+    // staged and fragment-read once for all three -> 3x the MFMA work per barrier
+    const bool tri = !f32 && !split && g->kW == 3 && g->Cr <= 64;   // (wider outputs: the 128x128 single-tap tile wins)
+    const bool n128 = !tri && g->Cr > 64, k128 = g->Cs > 64;
     const int DN = n128 ? 128 : 64, DK = k128 ? 128 : 64;
     const int tiles_n = (int)vn_ceil_div(g->Cr, DN), tiles_k = (int)vn_ceil_div(g->Cs, DK);
+    const int groups = tri ? taps / 3 : taps;
     p.tiles_k = tiles_k;
     p.row_list = row_list;
     p.n_rows = n_rows;
     p.divD = g->divD; p.divH = g->divH; p.divW = g->divW;
     const int64_t M = row_list ? n_rows : (int64_t)g->B * g->Dr * g->Hr * g->Wr;
     // ~1024 workgroups, but every workgroup gets at least 24 slabs of sites: a chunk ends with DN x DK fp32
-    // atomics (64 KB for a 128x128 tile), which must stay small against the chunk's MFMA work
-    int64_t chunks = 1024 / ((int64_t)taps * tiles_n * tiles_k);
+    // atomics per tap, which must stay small against the chunk's MFMA work
+    int64_t chunks = 1024 / ((int64_t)groups * tiles_n * tiles_k);
     const int64_t slabs = vn_ceil_div(M, 64);
     if (chunks > slabs / 24) chunks = slabs / 24;
     if (chunks < 1) chunks = 1;
@@ -356,16 +390,17 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     if (rpc > (1 << 30)) return VN_EUNSUPPORTED;
     p.rows_per_chunk = (int32_t)rpc;
     chunks = vn_ceil_div(M, rpc);
-    const dim3 grid((unsigned)chunks, (unsigned)taps, (unsigned)(tiles_n * tiles_k));
+    const dim3 grid((unsigned)chunks, (unsigned)groups, (unsigned)(tiles_n * tiles_k));
     hipStream_t st = vn_stream(stream);
+    if (tri) return k128 ? launch_wgrad<2, 4, false, 3>(p, grid, st) : launch_wgrad<2, 2, false, 3>(p, grid, st);
     if (f32) {
-        if (n128 && k128) return launch_wgrad<4, 4, true>(p, grid, st);
-        if (n128) return launch_wgrad<4, 2, true>(p, grid, st);
-        if (k128) return launch_wgrad<2, 4, true>(p, grid, st);
-        return launch_wgrad<2, 2, true>(p, grid, st);
+        if (n128 && k128) return launch_wgrad<4, 4, true, 1>(p, grid, st);
+        if (n128) return launch_wgrad<4, 2, true, 1>(p, grid, st);
+        if (k128) return launch_wgrad<2, 4, true, 1>(p, grid, st);
+        return launch_wgrad<2, 2, true, 1>(p, grid, st);
     }
-    if (n128 && k128) return launch_wgrad<4, 4, false>(p, grid, st);
-    if (n128) return launch_wgrad<4, 2, false>(p, grid, st);
-    if (k128) return launch_wgrad<2, 4, false>(p, grid, st);
-    return launch_wgrad<2, 2, false>(p, grid, st);
+    if (n128 && k128) return launch_wgrad<4, 4, false, 1>(p, grid, st);
+    if (n128) return launch_wgrad<4, 2, false, 1>(p, grid, st);
+    if (k128) return launch_wgrad<2, 4, false, 1>(p, grid, st);
+    return launch_wgrad<2, 2, false, 1>(p, grid, st);
 }
