@@ -95,7 +95,7 @@ def main():
     from voxelnet_amd import model as M
     from voxelnet_amd import parallel, synth
     from voxelnet_amd.config import GRADIENT_CLIP, LR, grid_config
-    from voxelnet_amd.voxelize import voxelize_device_async
+    from voxelnet_amd.voxelize import VoxelBuffers, voxelize_device_async
 
     M.set_precision(args.precision)
     torch.manual_seed(1234)                      # same initial weights on every rank
@@ -126,9 +126,15 @@ def main():
     vox_stream = torch.cuda.Stream()
     pending = {}
 
+    slots = [[VoxelBuffers(pts.shape[0], grid, 4, dev) for pts in frames] for _ in range(3)]   # 3-deep ring
+    ring = {"i": 0}
+
     def launch_voxelize():
+        bufs = slots[ring["i"] % 3]
+        ring["i"] += 1
         with torch.cuda.stream(vox_stream):
-            pending["next"] = [voxelize_device_async(pts, grid, b, coord_cols=4) for b, pts in enumerate(frames)]
+            pending["next"] = [voxelize_device_async(pts, grid, b, coord_cols=4, buffers=bufs[b])
+                               for b, pts in enumerate(frames)]
 
     def voxelize_batch():
         if args.static_voxels and "static" in pending:
@@ -142,8 +148,6 @@ def main():
             feats.append(f)
             coords.append(c)
         torch.cuda.current_stream().wait_event(handles[-1].event)
-        for t in feats + coords:
-            t.record_stream(torch.cuda.current_stream())
         launch_voxelize()
         if args.static_voxels:
             torch.cuda.synchronize()
@@ -240,11 +244,19 @@ def main():
 
     sync_all()
     t0 = time.perf_counter()
+    step_events = []
     for _ in range(args.steps):
         loss = step()
+        if os.environ.get("VN_BENCH_STEP_TIMES"):
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            step_events.append(ev)
     t_enq = time.perf_counter() - t0       # host time to enqueue the K steps (the GPU may still be running)
     sync_all()
     dt = time.perf_counter() - t0
+    if step_events and rank == 0:
+        print("[bench] per-step ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(step_events, step_events[1:])),
+              file=sys.stderr)
     assert torch.isfinite(loss).item(), "non-finite loss"
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)

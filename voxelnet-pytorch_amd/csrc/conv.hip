@@ -36,6 +36,7 @@ constexpr uint32_t GG_MAX_WINDOW = 0xFFFFE000u;
 
 struct GGClass {
     int32_t tap_begin, ntaps;
+    int32_t nD, nH, nW;            // taps per axis (taps are enumerated D-major: t = (id*nH + ih)*nW + iw)
     int32_t qD, qH, qW;            // row grid of this class
     int32_t ooffD, ooffH, ooffW;   // out coord = q * omul + ooff
     int32_t offD[4], offH[4], offW[4];   // src coord = q * mul + off[axis index]
@@ -181,10 +182,33 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     constexpr int BKE = 128 / ESZ;            // elements per K step
     constexpr int EPC = 16 / ESZ;             // elements per 16-B chunk
     const int nk = (p.Cs + BKE - 1) / BKE;    // the last step may be partial: chunks past Cs read zeros
-    const int nsteps = cl.ntaps * nk;
 
-    auto stage = [&](int s, int buf) {
-        const int tap = s / nk, kc = s - tap * nk;
+    // taps that are invalid for EVERY row of this tile (whole padding planes: the tile lies in the first/last
+    // depth plane or image line) are skipped block-uniformly
+    uint32_t tapmask = 0;
+    {
+        uint32_t mine = 0;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) mine |= a_bits[i];
+        uint32_t wavebits = 0;                // OR over the wave: one ballot per validity bit
+#pragma unroll
+        for (int b = 0; b < 12; ++b) wavebits |= (__builtin_amdgcn_ballot_w64((mine >> b) & 1u) != 0 ? 1u : 0u) << b;
+        // the last 16 bytes of LDS stage 1 are not written before the first loop barrier has been passed
+        uint32_t *words = reinterpret_cast<uint32_t *>(smem + 2 * STAGE - 16);
+        if (lane == 0) words[wave] = wavebits;
+        __syncthreads();
+        const uint32_t blockbits = __builtin_amdgcn_readfirstlane(words[0] | words[1] | words[2] | words[3]);
+        int t = 0;
+        for (int id = 0; id < cl.nD; ++id)
+            for (int ih = 0; ih < cl.nH; ++ih)
+                for (int iw = 0; iw < cl.nW; ++iw, ++t) {
+                    const uint32_t tb = (1u << id) | (16u << ih) | (256u << iw);
+                    if ((blockbits & tb) == tb) tapmask |= 1u << t;
+                }
+    }
+    const int nsteps = __builtin_popcount(tapmask) * nk;
+
+    auto stage = [&](int tap, int kc, int buf) {
         const GGTap tp = p.taps[cl.tap_begin + tap];
         const uint32_t tapbits = (1u << tp.id) | (16u << tp.ih) | (256u << tp.iw);
         const int64_t de = (int64_t)cl.offD[tp.id] * p.sD + (int64_t)cl.offH[tp.ih] * p.sH +
@@ -209,6 +233,16 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         for (int i = 0; i < RB; ++i)
             lds_dma16(rs_b, lb + i * 4096, (k_ok && b_row[i] != GG_OOB) ? b_row[i] + b_koff : GG_OOB, b_soff);
     };
+    // iterator over the (valid tap, K chunk) steps, one step ahead of the compute
+    uint32_t it_mask = tapmask;
+    int it_tap = tapmask ? __builtin_ctz(tapmask) : 0, it_kc = 0;
+    auto advance = [&]() {
+        if (++it_kc == nk) {
+            it_kc = 0;
+            it_mask &= it_mask - 1;
+            it_tap = it_mask ? __builtin_ctz(it_mask) : 0;
+        }
+    };
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -221,12 +255,18 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     const int frag_off0 = fr * 128 + (((0 + fq) ^ (fr >> 1)) << 4);
     const int frag_off1 = fr * 128 + (((4 + fq) ^ (fr >> 1)) << 4);
 
-    stage(0, 0);
+    if (nsteps > 0) {
+        stage(it_tap, it_kc, 0);
+        advance();
+    }
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < nsteps) stage(s + 1, buf ^ 1);
+        if (s + 1 < nsteps) {
+            stage(it_tap, it_kc, buf ^ 1);
+            advance();
+        }
         const char *la = smem + buf * STAGE + wm * (64 * 128);
         const char *lb = smem + buf * STAGE + A_BYTES + wn * (64 * 128);
 #pragma unroll
@@ -492,6 +532,7 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
     p.omulD = p.omulH = p.omulW = 1;
     GGClass &c = p.cls[0];
     c.tap_begin = 0;
+    c.nD = sd.n; c.nH = sh.n; c.nW = sw.n;
     c.qD = c.qH = c.qW = 1;
     c.ooffD = c.ooffH = c.ooffW = 0;
     for (int j = 0; j < 4; ++j) {
@@ -593,6 +634,7 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
                 const AxisClass &D = ad[cd], &H = ah[ch], &W = aw[cw];
                 GGClass &c = p.cls[ncls];
                 c.tap_begin = ntap;
+                c.nD = D.n; c.nH = H.n; c.nW = W.n;
                 c.qD = D.q; c.qH = H.q; c.qW = W.q;
                 c.ooffD = D.r; c.ooffH = H.r; c.ooffW = W.r;
                 for (int j = 0; j < 4; ++j) {

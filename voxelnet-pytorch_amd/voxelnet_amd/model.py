@@ -486,7 +486,7 @@ class _DetectorFn(torch.autograd.Function):
                 ws_bytes = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
                 if ws_bytes == 0:
                     raise _lib.VoxelnetHipError("vn_net_workspace_bytes: unsupported network configuration")
-                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=vw.device)
+                ws = rpn._ws_acquire(ws_bytes, vw.device)
                 hf, wf = H // mid._block1_stride, W // mid._block1_stride
                 prob = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=vw.device)
                 reg = torch.empty((B, 14, hf, wf), dtype=torch.float32, device=vw.device)
@@ -497,6 +497,8 @@ class _DetectorFn(torch.autograd.Function):
             ctx.reducer = rpn.grad_reducer
             ctx.rpn = rpn
             ctx.native = True
+            if not any(ctx.needs_input_grad):      # forward-only call: nothing will read the arena again
+                rpn._ws_release(ws)
             return prob, reg
         ctx.native = False
         with torch.cuda.device(feature.device):
@@ -603,6 +605,7 @@ def _detector_backward_native(ctx, d_prob, d_reg):
                views[pre + "batch_norm.bias"]]
     mg += [views["middle_rpn.prob_conv.conv.weight"], views["middle_rpn.prob_conv.conv.bias"],
            views["middle_rpn.reg_conv.conv.weight"], views["middle_rpn.reg_conv.conv.bias"]]
+    rpn._ws_release(ws)
     out = list(vg) + mg
     if accumulate:
         return (None, None, None, None, None) + tuple(g.clone() for g in out)
@@ -647,6 +650,21 @@ class RPN3D(nn.Module):
         #                                  set False to accumulate gradients over several backward() calls
         self.native_executor = True      # C++ step executor (csrc/runtime.hip) instead of per-launch Python calls
         self.grad_reducer = None  # parallel.GradAllReducer: bucketed all-reduce overlapped with backward
+
+    # The native executor's workspace arena (~1.5 GB for the car grid at batch 2) is kept in a small pool owned by
+    # the module: handing a buffer of that size back to the caching allocator every step makes it re-hipMalloc
+    # (~90 ms) whenever another stream's allocations got in between.
+    def _ws_acquire(self, nbytes, device):
+        pool = self.__dict__.setdefault("_ws_pool", [])
+        for i, t in enumerate(pool):
+            if t.numel() >= nbytes and t.device == device:
+                return pool.pop(i)
+        return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+    def _ws_release(self, ws):
+        pool = self.__dict__.setdefault("_ws_pool", [])
+        if len(pool) < 2 and all(t is not ws for t in pool):
+            pool.append(ws)
 
     def detect(self, voxel_features, voxel_coordinates):
         """feature_net + middle_rpn (model.py:305-306), fused."""

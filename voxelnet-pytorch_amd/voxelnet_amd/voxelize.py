@@ -72,8 +72,25 @@ class AsyncVoxels:
         return self._ev
 
 
-def voxelize_device_async(points, grid, batch_index=0, coord_cols=4):
-    """as voxelize_device, on the current stream, without any host synchronisation"""
+class VoxelBuffers:
+    """Reusable capacity-sized output/workspace buffers of one voxelization (input-pipeline slot)."""
+
+    def __init__(self, n_points, grid, coord_cols, device):
+        gs = _grid_struct(grid)
+        self.n, self.cols = n_points, coord_cols
+        self.cap = min(n_points, grid.cells)
+        self.ws_bytes = _lib.load().vn_voxelize_workspace_bytes(n_points, ctypes.byref(gs))
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.k_dev = torch.zeros(1, dtype=torch.int32, device=device)
+        self.feature = torch.empty((self.cap, grid.T, 7), dtype=torch.float32, device=device)
+        self.coord = torch.empty((self.cap, coord_cols), dtype=torch.int64, device=device)
+        self.number = torch.empty((self.cap,), dtype=torch.int64, device=device)
+        self.k_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+
+
+def voxelize_device_async(points, grid, batch_index=0, coord_cols=4, buffers=None):
+    """as voxelize_device, on the current stream, without any host synchronisation.
+    buffers: a VoxelBuffers slot to write into (reused across steps by an input pipeline)."""
     if not (points.is_cuda and points.dtype == torch.float32 and points.dim() == 2 and points.shape[1] == 4):
         raise ValueError("points must be a CUDA float32 (N,4) tensor")
     points = points.contiguous()
@@ -84,18 +101,23 @@ def voxelize_device_async(points, grid, batch_index=0, coord_cols=4):
     ws_bytes = lib.vn_voxelize_workspace_bytes(n, ctypes.byref(gs))
     cap = min(n, grid.cells)
     with torch.cuda.device(dev):
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        k_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        feature = torch.empty((cap, grid.T, 7), dtype=torch.float32, device=dev)
-        coord = torch.empty((cap, coord_cols), dtype=torch.int64, device=dev)
-        number = torch.empty((cap,), dtype=torch.int64, device=dev)
+        if buffers is not None:
+            if buffers.n != n or buffers.cols != coord_cols:
+                raise ValueError("VoxelBuffers slot was sized for a different cloud")
+            ws, k_dev, feature, coord, number = buffers.ws, buffers.k_dev, buffers.feature, buffers.coord, buffers.number
+        else:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            k_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+            feature = torch.empty((cap, grid.T, 7), dtype=torch.float32, device=dev)
+            coord = torch.empty((cap, coord_cols), dtype=torch.int64, device=dev)
+            number = torch.empty((cap,), dtype=torch.int64, device=dev)
         st = _stream()
         _lib.call("vn_voxelize_index", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes,
                   k_dev.data_ptr(), st)
         _lib.call("vn_voxelize_gather", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes, cap,
                   int(batch_index), coord_cols, feature.data_ptr(), coord.data_ptr(), number.data_ptr(),
                   k_dev.data_ptr(), st)
-        k_host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        k_host = buffers.k_host if buffers is not None else torch.empty(1, dtype=torch.int32, pin_memory=True)
         k_host.copy_(k_dev, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
