@@ -57,6 +57,24 @@ __device__ __forceinline__ void block_reduce_atomic(const float s1[8], const flo
     }
 }
 
+// same reduction, written as one slab row per workgroup: slab[block][2][C] floats (plain stores)
+__device__ __forceinline__ void block_reduce_slab(const float s1[8], const float s2[8], int groups, int rpb, int C,
+                                                  float *slab_row) {
+    __shared__ float red[256 * 16];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x * 16 + j] = s1[j];
+        red[threadIdx.x * 16 + 8 + j] = s2[j];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < groups * 16; t += 256) {
+        const int g = t >> 4, slot = t & 15;
+        float acc = 0.f;
+        for (int r = 0; r < rpb; ++r) acc += red[(r * groups + g) * 16 + slot];
+        slab_row[(slot >= 8 ? C : 0) + g * 8 + (slot & 7)] = acc;
+    }
+}
+
 __global__ void __launch_bounds__(256) k_bn_stats(const void *__restrict__ y, int dtype, int64_t M, int C,
                                                   int64_t stride, int fold, const float *__restrict__ shift,
                                                   double *__restrict__ sums) {
@@ -181,7 +199,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ da, int dadt, int64_t dastride,
                                                        const void *__restrict__ y, int ydt, int64_t ystride, int64_t M,
                                                        int C, const float *__restrict__ stats, int relu,
-                                                       double *__restrict__ sums) {
+                                                       double *__restrict__ sums, float *__restrict__ slab) {
     const int groups = C >> 3, rpb = 256 / groups;
     const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
     float mean[8], invstd[8], S[8], be[8];
@@ -206,7 +224,39 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
             }
         }
     }
-    block_reduce_atomic(s1, s2, groups, rpb, C, sums);
+    if (slab) block_reduce_slab(s1, s2, groups, rpb, C, slab + (size_t)blockIdx.x * 2 * C);
+    else block_reduce_atomic(s1, s2, groups, rpb, C, sums);
+}
+
+// one workgroup per channel: coef from the slab of k_bn_bwd_reduce
+__global__ void __launch_bounds__(256) k_bn_bwd_finalize_slab(const float *__restrict__ slab, int rows, int64_t M, int C,
+                                                              const float *__restrict__ gamma,
+                                                              const float *__restrict__ stats, float *__restrict__ coef,
+                                                              float *__restrict__ d_gamma, float *__restrict__ d_beta) {
+    __shared__ double r1[256], r2[256];
+    const int c = blockIdx.x;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        s1 += (double)slab[((size_t)r * 2 + 0) * C + c];
+        s2 += (double)slab[((size_t)r * 2 + 1) * C + c];
+    }
+    r1[threadIdx.x] = s1;
+    r2[threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double n = (double)M;
+        const float invstd = stats[C + c];
+        const float S = gamma[c] * invstd;
+        if (d_gamma) d_gamma[c] = (float)r2[0];
+        if (d_beta) d_beta[c] = (float)r1[0];
+        coef[c] = S;
+        coef[C + c] = -S * invstd * (float)(r2[0] / n);
+        coef[2 * C + c] = -S * (float)(r1[0] / n);
+    }
 }
 
 __global__ void __launch_bounds__(256) k_bn_bwd_finalize(const double *__restrict__ sums, int64_t M, int C, int fold,
@@ -318,7 +368,34 @@ extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_str
     const int rpb = 256 / (C >> 3);
     k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
-                                                                                 relu, sums);
+                                                                                 relu, sums, nullptr);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int64_t vn_bn_bwd_slab_rows(int64_t M, int32_t C) {
+    if (M <= 0 || !rows_ok(C, 8)) return 0;
+    return gs_blocks(M, (256 / (C >> 3)) * 8, 2048);
+}
+
+extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y, vnDtype y_dtype,
+                                     int64_t y_stride, int64_t M, int32_t C, const float *stats, int32_t relu,
+                                     float *slab, vnStream stream) {
+    VN_CHECK_ARG(slab && M > 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0 && da && y && stats);
+    const int rpb = 256 / (C >> 3);
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+                                                                                 (int)y_dtype, y_stride, M, C, stats,
+                                                                                 relu, nullptr, slab);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_bwd_finalize_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *gamma,
+                                       const float *stats, float *coef, float *d_gamma, float *d_beta,
+                                       vnStream stream) {
+    VN_CHECK_ARG(slab && gamma && stats && coef && slab_rows > 0 && M > 0 && C > 0);
+    k_bn_bwd_finalize_slab<<<C, 256, 0, vn_stream(stream)>>>(slab, (int)slab_rows, M, C, gamma, stats, coef, d_gamma,
+                                                             d_beta);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -82,6 +82,7 @@ struct Plan {
     float *stats[NL];
     // backward
     double *bsums[NL];
+    float *bslab[NL]; int64_t bslab_rows[NL];
     float *coef[NL];
     Rows dy[NL], dx[NL];
     float *dwp[NL];
@@ -232,6 +233,8 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     for (int l = 0; l < NL; ++l) {
         const Spec &sp = P->spec[l];
         P->coef[l] = (float *)A.take(3 * 256 * sizeof(float));
+        P->bslab_rows[l] = vn_bn_bwd_slab_rows(P->y[l].M(), sp.cout);
+        P->bslab[l] = (float *)A.take((size_t)P->bslab_rows[l] * 2 * sp.cout * sizeof(float));
         P->dy[l] = rows_new(P->adt, P->odims[l], sp.cout);
         // data gradient buffer of the layer's input (shared where two consumers accumulate)
         P->dx[l] = Rows{};
@@ -422,9 +425,10 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                                        (int64_t)H * W, 64, P.stats[l], P.coef[l], 1,
                                        dy.ptr + (size_t)(b * 2 + d) * H * W * 64 * P.esz, (vnDtype)dy.dtype, 64, 0, stream));
         } else {
-            RT(vn_bn_bwd_reduce(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
-                                P.bsums[l], stream));
-            RT(vn_bn_bwd_finalize(P.bsums[l], M, C, 1, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma, G[l].beta, stream));
+            RT(vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
+                                     P.bslab[l], stream));
+            RT(vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
+                                       G[l].beta, stream));
             RT(vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
                                P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, stream));
         }

@@ -91,6 +91,9 @@ SIGNATURES = {
     "vn_bn_apply": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
     "vn_bn_bwd_reduce": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "vn_bn_bwd_finalize": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vn_bn_bwd_slab_rows": (c_i64, [c_i64, c_i32]),
+    "vn_bn_bwd_reduce_slab": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "vn_bn_bwd_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vn_bn_bwd_apply": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp,
                                 c_i32, c_i64, c_i64, c_vp]),
     "vn_nchw_to_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_vp]),
