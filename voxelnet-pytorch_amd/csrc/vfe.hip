@@ -35,6 +35,7 @@ constexpr int TS = 65;                          // tile row stride (floats)
 constexpr int V_AGG1 = 0, V_U = 16, V_MK = 80, V_R1 = 144, V_G1 = 208, V_R2 = 272, V_G2 = 336, V_AM1 = 400,
               V_DAG1 = 416, V_S = 432, V_SIZE = 512;
 constexpr int VFE_BLOCKS_MAX = 1024;
+#define VFE_O_UNROLL 4   // the o loops read 16 uniform weights per step from LDS; a full unroll spills
 // slab (per workgroup) float counts
 constexpr int SLAB_P1 = 2 * C1, SLAB_P2 = 2 * C2, SLAB_B1 = 2 * C2;
 constexpr int SLAB_B2 = C2 + C2 * 32 + 64;   // db2 | dW2[64][32] | bn1 sums (32 used, written 64 wide)
@@ -44,7 +45,7 @@ struct VfeParams {
     const float *w1, *b1, *w2, *b2;
 };
 
-__device__ __forceinline__ size_t wave_lds_floats(int T) { return (size_t)T * TS + (size_t)T * 16 + V_SIZE; }
+__device__ __forceinline__ size_t wave_lds_floats(int T) { return (size_t)(T + 1) * TS + (size_t)T * 16 + V_SIZE; }
 
 struct WaveLds {
     float *tile;   // [T][65]
@@ -54,8 +55,14 @@ struct WaveLds {
 
 __device__ __forceinline__ WaveLds carve_lds(float *base, int wave, int T) {
     float *p = base + (size_t)wave * wave_lds_floats(T);
-    return WaveLds{p, p + (size_t)T * TS, p + (size_t)T * TS + (size_t)T * 16};
+    return WaveLds{p, p + (size_t)(T + 1) * TS, p + (size_t)(T + 1) * TS + (size_t)T * 16};
 }
+
+// The skinny-MLP weights (2.2k floats) are wave-uniform.  As kernel-argument loads hipcc hoists ~2000 s_loads out
+// of the per-voxel loop and spills the SGPRs into VGPR lanes (v_readlane around every FMA: +20k instructions per
+// voxel); re-loading them with s_load inside the loop serialises on SMEM latency (4x slower still).  So they live
+// in LDS, one copy per workgroup, and are read as broadcast ds_read_b128 (4 weights per LDS instruction).
+constexpr int WL_W2A = 0, WL_W2B = 1024, WL_W1 = 2048, WL_B1 = 2160, WL_B2 = 2176, WL_SIZE = 2304;   // floats
 
 // ---- row-lane pieces --------------------------------------------------------------------
 __device__ __forceinline__ void load_row(const float *__restrict__ feature, int64_t v, int T, int lane, float x[CIN],
@@ -83,6 +90,16 @@ __device__ __forceinline__ void layer1(const VfeParams &P, const float x[CIN], f
     }
 }
 
+__device__ __forceinline__ void layer1_lds(const float *__restrict__ wl, const float x[CIN], float h1[C1]) {
+#pragma unroll
+    for (int o = 0; o < C1; ++o) {
+        float a = wl[WL_B1 + o];
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) a = fmaf(wl[WL_W1 + o * CIN + i], x[i], a);
+        h1[o] = fmaxf(a, 0.f);
+    }
+}
+
 // lane-as-channel scan of tile[t][c] (holding h): max / argmax of p = S*(h-mean)+beta over t < T
 __device__ __forceinline__ void scan_max(const float *tile, int T, int c, float mean, float S, float beta, float &mx,
                                          int &amx) {
@@ -97,10 +114,11 @@ __device__ __forceinline__ void scan_max(const float *tile, int T, int c, float 
 // forward of one voxel up to h2 (row-lane), leaving: tile = h2[t][0..63], vec[V_AGG1], vec[V_MK], p1t = p1*m
 // returns per-lane x, m, h1, p1 (unmasked) and h2.  am1 (argmax of p1 over t) is written to vec[V_AM1] when WANT_AM1.
 template <bool WANT_AM1>
-__device__ __forceinline__ void forward_to_h2(const VfeParams &P, const float *__restrict__ stats,
-                                              const float *__restrict__ w2b_lds, const WaveLds &L, int T, int lane,
-                                              const float x[CIN], float m, float h1[C1], float p1[C1], float h2[C2]) {
-    layer1(P, x, h1);
+__device__ __forceinline__ void forward_to_h2(const float *__restrict__ wl, const float *__restrict__ stats,
+                                              const WaveLds &L, int T, int lane,
+                                              const float x[CIN], float m, float h1[C1], float p1[C1]) {
+    const float *w2b_lds = wl + WL_W2B;
+    layer1_lds(wl, x, h1);
     // tile <- h1 (16 cols); mask vector
     if (lane < T) {
 #pragma unroll
@@ -130,19 +148,16 @@ __device__ __forceinline__ void forward_to_h2(const VfeParams &P, const float *_
         for (int i = 0; i < C1; ++i) L.p1t[lane * 16 + i] = p1[i] * m;
     }
     __builtin_amdgcn_wave_barrier();
-    // h2[o] = relu(b2[o] + sum_{i<16} W2[o][i]*p1[i]*m + m*u[o])
-#pragma unroll
+    // h2[o] = relu(b2[o] + sum_{i<16} W2[o][i]*p1[i]*m + m*u[o]) -> straight into the tile (h1 was consumed
+    // by the scan above; this lane's own tile row is written, never held in 64 registers)
+    const int trow = (lane < T ? lane : T) * TS;      // lanes >= T dump into the spare row T
+#pragma unroll VFE_O_UNROLL
     for (int o = 0; o < C2; ++o) {
         float a = 0.f;
 #pragma unroll
-        for (int i = 0; i < C1; ++i) a = fmaf(P.w2[o * 32 + i], p1[i], a);
-        a = fmaf(m, a + L.vec[V_U + o], P.b2[o]);
-        h2[o] = fmaxf(a, 0.f);
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < T) {
-#pragma unroll
-        for (int o = 0; o < C2; ++o) L.tile[lane * TS + o] = h2[o];
+        for (int i = 0; i < C1; ++i) a = fmaf(wl[WL_W2A + o * C1 + i], p1[i], a);
+        a = fmaf(m, a + L.vec[V_U + o], wl[WL_B2 + o]);
+        L.tile[trow + o] = fmaxf(a, 0.f);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -157,12 +172,16 @@ __device__ __forceinline__ void slab_write(float *red /*[4][n]*/, const float *v
     for (int i = threadIdx.x; i < n; i += 256) slab[i] = red[i] + red[n + i] + red[2 * n + i] + red[3 * n + i];
 }
 
-__device__ __forceinline__ void load_w2b(const VfeParams &P, float *w2b) {
-    // transposed second half of W2: w2b[i][o] = W2[o][16+i]
+__device__ __forceinline__ void load_weights_lds(const VfeParams &P, float *wl) {
     for (int idx = threadIdx.x; idx < C1 * C2; idx += 256) {
-        const int i = idx / C2, o = idx - i * C2;
-        w2b[idx] = P.w2[o * 32 + 16 + i];
+        const int o = idx / C1, i = idx - o * C1;
+        wl[WL_W2A + idx] = P.w2[o * 32 + i];                 // first half of W2, [o][i]
+        const int i2 = idx / C2, o2 = idx - i2 * C2;
+        wl[WL_W2B + idx] = P.w2[o2 * 32 + 16 + i2];          // second half transposed: [i][o] = W2[o][16+i]
     }
+    for (int idx = threadIdx.x; idx < C1 * CIN; idx += 256) wl[WL_W1 + idx] = P.w1[idx];
+    if (threadIdx.x < C1) wl[WL_B1 + threadIdx.x] = P.b1[threadIdx.x];
+    if (threadIdx.x < C2) wl[WL_B2 + threadIdx.x] = P.b2[threadIdx.x];
     __syncthreads();
 }
 
@@ -175,6 +194,7 @@ __global__ void __launch_bounds__(256) k_vfe_p1(const float *__restrict__ featur
     float *tile = smem + (size_t)wave * T * TS;
     float s1 = 0.f, s2 = 0.f;
     for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
+        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
         float x[CIN], m, h1[C1];
         load_row(feature, v, T, lane, x, m);
         layer1(P, x, h1);
@@ -200,14 +220,15 @@ __global__ void __launch_bounds__(256) k_vfe_p2(const float *__restrict__ featur
                                                 const float *__restrict__ stats, float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *w2b = smem;
-    load_w2b(P, w2b);
-    const WaveLds L = carve_lds(smem + C1 * C2, wave, T);
+    float *wl = smem;
+    load_weights_lds(P, wl);
+    const WaveLds L = carve_lds(smem + WL_SIZE, wave, T);
     float s1 = 0.f, s2 = 0.f;
     for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        float x[CIN], m, h1[C1], p1[C1], h2[C2];
+        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
+        float x[CIN], m, h1[C1], p1[C1];
         load_row(feature, v, T, lane, x, m);
-        forward_to_h2<false>(P, stats, w2b, L, T, lane, x, m, h1, p1, h2);
+        forward_to_h2<false>(wl, stats, L, T, lane, x, m, h1, p1);
         for (int t = 0; t < T; ++t) { const float h = L.tile[t * TS + lane]; s1 += h; s2 += h * h; }
         __builtin_amdgcn_wave_barrier();
     }
@@ -221,14 +242,15 @@ __global__ void __launch_bounds__(256) k_vfe_p3(const float *__restrict__ featur
                                                 const float *__restrict__ stats, float *__restrict__ voxelwise) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *w2b = smem;
-    load_w2b(P, w2b);
-    const WaveLds L = carve_lds(smem + C1 * C2, wave, T);
+    float *wl = smem;
+    load_weights_lds(P, wl);
+    const WaveLds L = carve_lds(smem + WL_SIZE, wave, T);
     const float mean2 = stats[ST2 + lane], S2 = stats[ST2 + 2 * C2 + lane], be2 = stats[ST2 + 3 * C2 + lane];
     for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        float x[CIN], m, h1[C1], p1[C1], h2[C2];
+        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
+        float x[CIN], m, h1[C1], p1[C1];
         load_row(feature, v, T, lane, x, m);
-        forward_to_h2<false>(P, stats, w2b, L, T, lane, x, m, h1, p1, h2);
+        forward_to_h2<false>(wl, stats, L, T, lane, x, m, h1, p1);
         // lane = channel: agg2 = max_t p2 ; vw_lo = max_t p2*m ; vw_hi = max_t agg2*m
         float agg = -INFINITY, vlo = -INFINITY;
         float anym = 0.f, allm = 1.f;
@@ -336,16 +358,17 @@ __global__ void __launch_bounds__(256) k_vfe_b1(const float *__restrict__ featur
                                                 float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *w2b = smem;
-    load_w2b(P, w2b);
-    const WaveLds L = carve_lds(smem + C1 * C2, wave, T);
+    float *wl = smem;
+    load_weights_lds(P, wl);
+    const WaveLds L = carve_lds(smem + WL_SIZE, wave, T);
     const float mean2 = stats[ST2 + lane], inv2 = stats[ST2 + C2 + lane], S2 = stats[ST2 + 2 * C2 + lane],
                 be2 = stats[ST2 + 3 * C2 + lane];
     float s1 = 0.f, s2 = 0.f;
     for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        float x[CIN], m, h1[C1], p1[C1], h2[C2];
+        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
+        float x[CIN], m, h1[C1], p1[C1];
         load_row(feature, v, T, lane, x, m);
-        forward_to_h2<false>(P, stats, w2b, L, T, lane, x, m, h1, p1, h2);
+        forward_to_h2<false>(wl, stats, L, T, lane, x, m, h1, p1);
         int r1, r2; float g1, g2, xh1, xh2;
         impulses(L, T, lane, mean2, S2, be2, dvw[v * 128 + lane], dvw[v * 128 + 64 + lane], r1, g1, r2, g2, xh1, xh2,
                  inv2);
@@ -382,23 +405,30 @@ __global__ void __launch_bounds__(256) k_vfe_bn_bwd_finalize(const float *__rest
 // backward pass 2: layer-2 parameter grads, d_p1 rows -> workspace, BN1 sums
 //   slab = [db2 (64) | dW2 (64*32) | sum d_p1 (16) | sum d_p1*xhat1 (16)]
 __global__ void __launch_bounds__(256) k_vfe_b2(const float *__restrict__ feature, int64_t K, int T, VfeParams P,
-                                                const float *__restrict__ stats, const float *__restrict__ dvw,
-                                                const float *__restrict__ coef2, float *__restrict__ dp1_ws,
+                                                const float *__restrict__ stats_g, const float *__restrict__ dvw,
+                                                const float *__restrict__ coef2_g, float *__restrict__ dp1_ws,
                                                 float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *w2b = smem;
-    load_w2b(P, w2b);
-    const WaveLds L = carve_lds(smem + C1 * C2, wave, T);
+    float *wl = smem;
+    load_weights_lds(P, wl);
+    // this kernel also keeps the BN statistics and the BN2 backward coefficients in LDS (512 more uniform floats)
+    float *st_l = smem + WL_SIZE, *cf_l = st_l + STATS_FLOATS;
+    for (int i = threadIdx.x; i < STATS_FLOATS; i += 256) st_l[i] = stats_g[i];
+    for (int i = threadIdx.x; i < 3 * C2; i += 256) cf_l[i] = coef2_g[i];
+    __syncthreads();
+    const float *stats = st_l, *coef2 = cf_l;
+    const WaveLds L = carve_lds(smem + WL_SIZE + 512, wave, T);
     const float mean2 = stats[ST2 + lane], inv2 = stats[ST2 + C2 + lane], S2 = stats[ST2 + 2 * C2 + lane],
                 be2 = stats[ST2 + 3 * C2 + lane];
     float db2 = 0.f, dw2a[C1], dw2b[C1], bn1 = 0.f;
 #pragma unroll
     for (int i = 0; i < C1; ++i) { dw2a[i] = 0.f; dw2b[i] = 0.f; }
     for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        float x[CIN], m, h1[C1], p1[C1], h2[C2];
+        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
+        float x[CIN], m, h1[C1], p1[C1];
         load_row(feature, v, T, lane, x, m);
-        forward_to_h2<true>(P, stats, w2b, L, T, lane, x, m, h1, p1, h2);
+        forward_to_h2<true>(wl, stats, L, T, lane, x, m, h1, p1);
         {
             int r1, r2; float g1, g2, xh1, xh2;
             impulses(L, T, lane, mean2, S2, be2, dvw[v * 128 + lane], dvw[v * 128 + 64 + lane], r1, g1, r2, g2, xh1,
@@ -409,28 +439,23 @@ __global__ void __launch_bounds__(256) k_vfe_b2(const float *__restrict__ featur
             L.vec[V_G2 + lane] = g2;
         }
         __builtin_amdgcn_wave_barrier();
-        // row-lane: d_pre2[o] = (h2>0) * (c0*d_p2 + c1*(h2-mean) + c2)
-        float dpre[C2];
-#pragma unroll
-        for (int o = 0; o < C2; ++o) {
-            float dp = 0.f;
-            if (__float_as_int(L.vec[V_R1 + o]) == lane) dp += L.vec[V_G1 + o];
-            if (__float_as_int(L.vec[V_R2 + o]) == lane) dp += L.vec[V_G2 + o];
-            const float dh = fmaf(coef2[o], dp, fmaf(coef2[C2 + o], h2[o] - stats[ST2 + o], coef2[2 * C2 + o]));
-            dpre[o] = h2[o] > 0.f ? dh : 0.f;
-        }
-        // d_p1m[i] = sum_o dpre[o] * W2[o][i]   (i < 16)
+        // row-lane: d_pre2[o] = (h2>0) * (c0*d_p2 + c1*(h2-mean) + c2), streamed through the tile IN PLACE
+        // (h2[o] read, d_pre2[o] written back to the same slot) while d_p1m[i] = sum_o d_pre2[o]*W2[o][i] accumulates
         float dp1[C1];
 #pragma unroll
         for (int i = 0; i < C1; ++i) dp1[i] = 0.f;
+        const int trow = (lane < T ? lane : T) * TS;
+#pragma unroll VFE_O_UNROLL
+        for (int o = 0; o < C2; ++o) {
+            const float h = L.tile[trow + o];
+            float dp = 0.f;
+            if (__float_as_int(L.vec[V_R1 + o]) == lane) dp += L.vec[V_G1 + o];
+            if (__float_as_int(L.vec[V_R2 + o]) == lane) dp += L.vec[V_G2 + o];
+            const float dh = fmaf(coef2[o], dp, fmaf(coef2[C2 + o], h - stats[ST2 + o], coef2[2 * C2 + o]));
+            const float d = (h > 0.f && lane < T) ? dh : 0.f;
+            L.tile[trow + o] = d;
 #pragma unroll
-        for (int o = 0; o < C2; ++o)
-#pragma unroll
-            for (int i = 0; i < C1; ++i) dp1[i] = fmaf(dpre[o], P.w2[o * 32 + i], dp1[i]);
-        // tile <- d_pre2
-        if (lane < T) {
-#pragma unroll
-            for (int o = 0; o < C2; ++o) L.tile[lane * TS + o] = dpre[o];
+            for (int i = 0; i < C1; ++i) dp1[i] = fmaf(d, wl[WL_W2A + o * C1 + i], dp1[i]);
         }
         __builtin_amdgcn_wave_barrier();
         // lane = o: db2, s[o] = sum_t m_t dpre, dW2a[o][i] += sum_t dpre[t][o]*p1m[t][i]
@@ -449,7 +474,7 @@ __global__ void __launch_bounds__(256) k_vfe_b2(const float *__restrict__ featur
         // lane = i' < 16: d_agg1[i'] = sum_o W2[o][16+i'] * s[o]
         if (lane < C1) {
             float da = 0.f;
-            for (int o = 0; o < C2; ++o) da = fmaf(w2b[lane * C2 + o], L.vec[V_S + o], da);
+            for (int o = 0; o < C2; ++o) da = fmaf(wl[WL_W2B + lane * C2 + o], L.vec[V_S + o], da);
             L.vec[V_DAG1 + lane] = da;
         }
         __builtin_amdgcn_wave_barrier();
@@ -519,6 +544,7 @@ __global__ void __launch_bounds__(256) k_vfe_b3(const float *__restrict__ featur
     const int o1 = w1e ? e1 / CIN : e1 - C1 * CIN, i1 = w1e ? e1 - o1 * CIN : 0;
     float a0 = 0.f, a1 = 0.f;
     for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
+        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
         float x[CIN], m, h1[C1];
         load_row(feature, v, T, lane, x, m);
         layer1(P, x, h1);
@@ -576,8 +602,8 @@ Plan make_plan(int64_t K, int T) {
     if (b > VFE_BLOCKS_MAX) b = VFE_BLOCKS_MAX;
     p.blocks = (int)b;
     p.lds_small = (size_t)4 * T * TS * sizeof(float);
-    const size_t per_wave = ((size_t)T * TS + (size_t)T * 16 + V_SIZE) * sizeof(float);
-    size_t full = (size_t)C1 * C2 * sizeof(float) + 4 * per_wave;
+    const size_t per_wave = ((size_t)(T + 1) * TS + (size_t)T * 16 + V_SIZE) * sizeof(float);
+    size_t full = (size_t)(WL_SIZE + 512) * sizeof(float) + 4 * per_wave;
     const size_t red = (size_t)4 * 32 * 64 * sizeof(float);   // slab combine area of pass b2
     if (full < red) full = red;
     p.lds_full = full;
