@@ -493,7 +493,8 @@ class _DetectorFn(torch.autograd.Function):
                 _lib.call("vn_net_forward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), heads["bias"].data_ptr(),
                           dense.ptr(), coord.data_ptr(), K, ws.data_ptr(), ws_bytes, prob.data_ptr(), reg.data_ptr(),
                           E.stream())
-            ctx.saved = (feature, coord, stats, wst, vparams, (cfg, ws, ws_bytes, dense, vw_rows, heads, prob), None, None)
+            ctx.saved = (feature, coord, stats, wst, vparams, (cfg, ws, ws_bytes, dense, vw_rows, heads, prob.detach()), None, None)
+            # (prob.detach(): an alias — keeping the Function's own output on ctx would be a reference cycle)
             ctx.reducer = rpn.grad_reducer
             ctx.rpn = rpn
             ctx.native = True
@@ -606,6 +607,7 @@ def _detector_backward_native(ctx, d_prob, d_reg):
     mg += [views["middle_rpn.prob_conv.conv.weight"], views["middle_rpn.prob_conv.conv.bias"],
            views["middle_rpn.reg_conv.conv.weight"], views["middle_rpn.reg_conv.conv.bias"]]
     rpn._ws_release(ws)
+    ctx.saved = None          # drop the dense grid etc. now, not when the graph node is collected
     out = list(vg) + mg
     if accumulate:
         return (None, None, None, None, None) + tuple(g.clone() for g in out)

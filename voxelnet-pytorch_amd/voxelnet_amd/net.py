@@ -86,7 +86,8 @@ def middle_forward(dense, P, Bf, block1_stride, training, mode, sparse=None):
     st.layers["heads"] = s
     prob = E.rows_to_nchw(Rows(y.t[..., 0:2], 2), 2, sigmoid_first_n=2)
     reg = E.rows_to_nchw(Rows(y.t[..., 2:16], 14), 2)
-    st.prob = prob
+    st.prob = prob.detach()     # an alias, NOT the returned tensor: saving an autograd.Function's own output on its ctx is a
+                                # reference cycle that only the cyclic GC frees (720 MB of dense grid per step piled up)
     st.fmap = (hf, wf)
     return prob, reg, st
 
