@@ -70,18 +70,32 @@ struct GGParams {
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+#ifndef GG_PIN_SCHEDULE
+#define GG_PIN_SCHEDULE 1
+#endif
+#if GG_PIN_SCHEDULE
+#define GG_PIN() __builtin_amdgcn_sched_barrier(0)   // keep a DMA piece between its MFMA groups
+#else
+#define GG_PIN()
+#endif
 
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds_wave_base, uint32_t voffset,
                                           uint32_t soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-template <int WM, int WN, bool F32>
+// WM x WN waves, each owning a (16*SM) x 64 sub-tile; NS LDS stages (the loads run NS-1 steps ahead of the MFMAs:
+// the small late layers — 4400 rows x 2304 K — are latency-bound, not bandwidth-bound, and want a deep pipeline)
+template <int WM, int WN, int SM, int NS, bool F32>
 __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
+    static_assert(WM * WN == 4 && NS >= 2 && SM >= 1 && SM <= 8, "4 waves");
     constexpr int ESZ = F32 ? 4 : 2;          // a K step is always 128 B of every row: 64 bf16 or 32 fp32
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int BM = 16 * SM * WM, BN = 64 * WN;
+    static_assert(BM % 32 == 0, "a DMA instruction of the 4 waves covers 32 rows");
     constexpr int RA = BM / 32, RB = BN / 32;     // LDS-DMA instructions per wave per step
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int AHEAD = (NS - 2) * (RA + RB);   // DMA instructions of later stages that may still be in flight
+    static_assert(AHEAD <= 63, "vmcnt is 6 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int lane = threadIdx.x & 63;
@@ -193,8 +207,8 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         uint32_t wavebits = 0;                // OR over the wave: one ballot per validity bit
 #pragma unroll
         for (int b = 0; b < 12; ++b) wavebits |= (__builtin_amdgcn_ballot_w64((mine >> b) & 1u) != 0 ? 1u : 0u) << b;
-        // the last 16 bytes of LDS stage 1 are not written before the first loop barrier has been passed
-        uint32_t *words = reinterpret_cast<uint32_t *>(smem + 2 * STAGE - 16);
+        // the last 16 bytes of the last LDS stage are not written before the first loop barrier has been passed
+        uint32_t *words = reinterpret_cast<uint32_t *>(smem + NS * STAGE - 16);
         if (lane == 0) words[wave] = wavebits;
         __syncthreads();
         const uint32_t blockbits = __builtin_amdgcn_readfirstlane(words[0] | words[1] | words[2] | words[3]);
@@ -208,30 +222,39 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     }
     const int nsteps = __builtin_popcount(tapmask) * nk;
 
-    auto stage = [&](int tap, int kc, int buf) {
+    // One stage = RA + RB LDS-DMA pieces per wave (1 KiB each: 8 rows x 128 B).  The TA path moves ~40 B/clk/CU at
+    // best, i.e. a piece occupies it for ~25-100 clk: the pieces of stage s+NS-1 are therefore issued one by one
+    // BETWEEN the MFMA groups of step s (piece()), not in a burst in front of them.
+    struct StageCtx {
+        uint32_t tapbits, a_off, b_koff, b_soff;
+        bool k_ok;
+        char *la, *lb;
+    };
+    auto prep = [&](int tap, int kc, int buf, bool live) {
         const GGTap tp = p.taps[cl.tap_begin + tap];
-        const uint32_t tapbits = (1u << tp.id) | (16u << tp.ih) | (256u << tp.iw);
+        StageCtx c;
+        c.tapbits = (1u << tp.id) | (16u << tp.ih) | (256u << tp.iw);
         const int64_t de = (int64_t)cl.offD[tp.id] * p.sD + (int64_t)cl.offH[tp.ih] * p.sH +
                            (int64_t)cl.offW[tp.iw] * p.sW;
-        const uint32_t delta = (uint32_t)(int32_t)(de * ESZ);
         // this lane's K position inside the step; split rows wrap (k >= 2C reads the hi part again)
         const int k_lane = kc * BKE + a_chunk * EPC;
-        const bool k_ok = k_lane < p.Cs;
+        c.k_ok = live && k_lane < p.Cs;
         const int k_src = (p.src_wrap > 0 && k_lane >= p.src_wrap) ? k_lane - p.src_wrap : k_lane;
-        const uint32_t a_koff = (uint32_t)k_src * (uint32_t)ESZ;
-        const uint32_t b_koff = (uint32_t)k_lane * (uint32_t)ESZ;
-        const uint32_t b_soff = __builtin_amdgcn_readfirstlane((uint32_t)((int64_t)tp.widx * p.N * p.Cs * ESZ));
-        char *la = smem + buf * STAGE + wave * 1024;
-        char *lb = smem + buf * STAGE + A_BYTES + wave * 1024;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const bool ok = k_ok && (a_bits[i] & tapbits) == tapbits;
-            const uint32_t v = ok ? a_row[i] + delta + a_koff : GG_OOB;
-            lds_dma16(rs_a, la + i * 4096, v, 0);
+        c.a_off = (uint32_t)(int32_t)(de * ESZ) + (uint32_t)k_src * (uint32_t)ESZ;
+        c.b_koff = (uint32_t)k_lane * (uint32_t)ESZ;
+        c.b_soff = __builtin_amdgcn_readfirstlane((uint32_t)((int64_t)tp.widx * p.N * p.Cs * ESZ));
+        c.la = smem + buf * STAGE + wave * 1024;
+        c.lb = smem + buf * STAGE + A_BYTES + wave * 1024;
+        return c;
+    };
+    auto piece = [&](const StageCtx &c, int idx) {   // idx is a compile-time constant after unrolling
+        if (idx < RA) {
+            const bool ok = c.k_ok && (a_bits[idx] & c.tapbits) == c.tapbits;
+            lds_dma16(rs_a, c.la + idx * 4096, ok ? a_row[idx] + c.a_off : GG_OOB, 0);
+        } else {
+            const int i = idx - RA;
+            lds_dma16(rs_b, c.lb + i * 4096, (c.k_ok && b_row[i] != GG_OOB) ? b_row[i] + c.b_koff : GG_OOB, c.b_soff);
         }
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-            lds_dma16(rs_b, lb + i * 4096, (k_ok && b_row[i] != GG_OOB) ? b_row[i] + b_koff : GG_OOB, b_soff);
     };
     // iterator over the (valid tap, K chunk) steps, one step ahead of the compute
     uint32_t it_mask = tapmask;
@@ -244,9 +267,9 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         }
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[SM][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < SM; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
@@ -255,19 +278,28 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     const int frag_off0 = fr * 128 + (((0 + fq) ^ (fr >> 1)) << 4);
     const int frag_off1 = fr * 128 + (((4 + fq) ^ (fr >> 1)) << 4);
 
-    if (nsteps > 0) {
-        stage(it_tap, it_kc, 0);
-        advance();
+    constexpr int LPS = RA + RB;                // pieces per stage and wave
+    // every stage slot is always issued (past the last step as out-of-range pieces: zeros, no memory traffic), so
+    // exactly (NS-2)*LPS younger pieces are outstanding whenever stage s has to have landed
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j) {
+        const StageCtx c = prep(it_tap, it_kc, j, j < nsteps);
+#pragma unroll
+        for (int q = 0; q < LPS; ++q) piece(c, q);
+        if (j < nsteps) advance();
     }
+    int buf = 0, nbuf = NS - 1;                 // stage consumed by this step / stage the next loads go to
     for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (s + 1 < nsteps) {
-            stage(it_tap, it_kc, buf ^ 1);
-            advance();
-        }
-        const char *la = smem + buf * STAGE + wm * (64 * 128);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD) : "memory");
+        // bare s_barrier: __syncthreads() carries a workgroup fence, which makes hipcc drain vmcnt to 0 (the LDS-DMA
+        // loads of the stages still in flight) and so serialises the pipeline.  The explicit vmcnt above is the
+        // only ordering the LDS hand-off needs: a stage is read after ITS loads have landed in every wave.
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const bool live = s + NS - 1 < nsteps;
+        const StageCtx c = prep(it_tap, it_kc, nbuf, live);   // into the stage step s-1 has just finished with
+        if (live) advance();
+        const char *la = smem + buf * STAGE + wm * (16 * SM * 128);
         const char *lb = smem + buf * STAGE + A_BYTES + wn * (64 * 128);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -275,31 +307,42 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
             if constexpr (F32) {
                 // 16 B per lane = 4 consecutive k of one row; MFMA step t consumes element t of every lane's
                 // vector (the k <-> (lane>>4, t) assignment is the same for A and B, which is all the sum needs)
-                f32x4_t a[4], b[4];
+                f32x4_t a[SM], b[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const f32x4_t *>(la + i * 2048 + fo);
+                for (int i = 0; i < SM; ++i) a[i] = *reinterpret_cast<const f32x4_t *>(la + i * 2048 + fo);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + fo);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < SM; ++i)
 #pragma unroll
                         for (int j = 0; j < 4; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
-            } else {
-                bf16x8_t a[4], b[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const bf16x8_t *>(la + i * 2048 + fo);
+                    for (int q = 0; q < LPS; ++q)
+                        if (q * 8 / LPS == ks * 4 + t) piece(c, q);
+                }
+            } else {
+                bf16x8_t a[SM], b[4];
+#pragma unroll
+                for (int i = 0; i < SM; ++i) a[i] = *reinterpret_cast<const bf16x8_t *>(la + i * 2048 + fo);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const bf16x8_t *>(lb + j * 2048 + fo);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < SM; ++i) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < LPS; ++q)
+                        if (q * (2 * SM) / LPS == ks * SM + i) piece(c, q);
+                    GG_PIN();
+                }
             }
         }
+        buf = buf + 1 == NS ? 0 : buf + 1;
+        nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
     }
 
     // ---- epilogue ----
@@ -340,8 +383,8 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int4 offs = *reinterpret_cast<const int4 *>(otab + wm * 64 + i * 16 + fq * 4);
+    for (int i = 0; i < SM; ++i) {
+        const int4 offs = *reinterpret_cast<const int4 *>(otab + wm * (16 * SM) + i * 16 + fq * 4);
         const int32_t o4[4] = {offs.x, offs.y, offs.z, offs.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -442,14 +485,53 @@ int axis_classes(int R, int k, int mul, int tmul, int pad, int div, AxisClass *o
 }
 
 // the dynamic-LDS attribute is set once per instantiation (function-local static: not inside a stream capture)
-template <int WM, int WN, bool F32>
-int launch_gg(const GGParams &p, dim3 grid, size_t lds, hipStream_t st) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather_gemm<WM, WN, F32>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       2 * (64 * WM + 64 * WN) * 128);
+template <int WM, int WN, int SM, int NS, bool F32>
+int launch_gg(const GGParams &p, dim3 grid, hipStream_t st) {
+    constexpr size_t lds = (size_t)NS * (16 * SM * WM + 64 * WN) * 128;
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void *>(&k_gather_gemm<WM, WN, SM, NS, F32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    k_gather_gemm<WM, WN, F32><<<grid, 256, lds, st>>>(p);
+    k_gather_gemm<WM, WN, SM, NS, F32><<<grid, 256, lds, st>>>(p);
     return 0;
+}
+
+// Tile configurations.  The two big ones keep a 64x64 tile per wave (best LDS bytes per MFMA); the small ones trade
+// that for enough workgroups to cover 256 CUs and for a deep load pipeline (a layer with 4400 output rows is 70
+// 128x128 tiles: one latency-bound workgroup on a quarter of the chip).
+struct GGConfig {
+    int id, BM, BN;
+};
+constexpr GGConfig GG_CFG[5] = {{0, 256, 64}, {1, 128, 128}, {2, 64, 128}, {3, 64, 64}, {4, 160, 128}};
+
+int gg_force() {   // tuning aid: VN_GG_CONFIG=0..4 forces one configuration
+    static const int v = [] {
+        const char *e = getenv("VN_GG_CONFIG");
+        return e && *e ? atoi(e) : -1;
+    }();
+    return v;
+}
+
+GGConfig gg_config(int64_t rows, int Cr, int ncls) {
+    const int f = gg_force();
+    if (f >= 0 && f < 5) return GG_CFG[f];
+    auto blocks = [&](const GGConfig &c) { return vn_ceil_div(rows, c.BM) * vn_ceil_div(Cr, c.BN) * ncls; };
+    if (Cr <= 64) return GG_CFG[0];
+    // 128x128 and 160x128 both run two workgroups per CU (512 slots): take the one whose last round of workgroups
+    // is fuller — 70,400 rows are 550 tiles of 128 (a second round of 38) but 440 tiles of 160 (one round)
+    const int64_t b1 = blocks(GG_CFG[1]), b4 = blocks(GG_CFG[4]);
+    if (b1 < 100) return GG_CFG[2];              // a handful of long-K tiles: smaller tiles, 4-stage pipeline
+    const int64_t t1 = vn_ceil_div(b1, 512) * 128, t4 = vn_ceil_div(b4, 512) * 160;
+    return t4 < t1 ? GG_CFG[4] : GG_CFG[1];
+}
+
+int launch_cfg(const GGConfig &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
+    switch (c.id) {
+    case 0: return f32 ? launch_gg<4, 1, 4, 2, true>(p, grid, st) : launch_gg<4, 1, 4, 2, false>(p, grid, st);
+    case 1: return f32 ? launch_gg<2, 2, 4, 2, true>(p, grid, st) : launch_gg<2, 2, 4, 2, false>(p, grid, st);
+    case 2: return f32 ? launch_gg<2, 2, 2, 4, true>(p, grid, st) : launch_gg<2, 2, 2, 4, false>(p, grid, st);
+    case 3: return f32 ? launch_gg<4, 1, 1, 6, true>(p, grid, st) : launch_gg<4, 1, 1, 6, false>(p, grid, st);
+    default: return f32 ? launch_gg<2, 2, 5, 2, true>(p, grid, st) : launch_gg<2, 2, 5, 2, false>(p, grid, st);
+    }
 }
 
 // list-mode slots of one axis: every (residue r, tap t) with (r + t*tmul - pad) divisible by div
@@ -550,15 +632,11 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
                 p.taps[ntap++] = GGTap{i, j, k, (sd.tap[i] * g->kH + sh.tap[j]) * g->kW + sw.tap[k]};
     c.ntaps = ntap;
     p.nclasses = 1;
-    const bool wide = g->Cr > 64;
-    const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
-    const int64_t tiles_m = vn_ceil_div(row_cap, BM), tiles_n = vn_ceil_div(g->Cr, BN);
+    const GGConfig cfg = g->Cr > 64 ? GG_CFG[1] : GG_CFG[0];   // capacity launch: rows are not known on the host
+    const int64_t tiles_m = vn_ceil_div(row_cap, cfg.BM), tiles_n = vn_ceil_div(g->Cr, cfg.BN);
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1);
-    const size_t lds = 2u * (size_t)(BM + BN) * 128u;
     hipStream_t st = vn_stream(stream);
-    int rc;
-    if (wide) rc = f32 ? launch_gg<2, 2, true>(p, grid, lds, st) : launch_gg<2, 2, false>(p, grid, lds, st);
-    else rc = f32 ? launch_gg<4, 1, true>(p, grid, lds, st) : launch_gg<4, 1, false>(p, grid, lds, st);
+    const int rc = launch_cfg(cfg, f32, p, grid, st);
     if (rc) return rc;
     VN_LAUNCH_STATUS();
     return VN_OK;
@@ -566,8 +644,8 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
 
 extern "C" int64_t vn_conv_stats_slab_rows(const vnConv *g) {
     if (!g || g->divD != 1 || g->divH != 1 || g->divW != 1) return 0;
-    const int BM = g->Cr > 64 ? 128 : 256;
-    return vn_ceil_div((int64_t)g->B * g->Dr * g->Hr * g->Wr, BM);
+    const int64_t rows = (int64_t)g->B * g->Dr * g->Hr * g->Wr;
+    return vn_ceil_div(rows, gg_config(rows, g->Cr, 1).BM);
 }
 
 extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const float *bias, void *out,
@@ -655,8 +733,8 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
             }
     p.nclasses = ncls;
 
-    const bool wide = g->Cr > 64;   // 128x128 tile (2x2 waves) vs 256x64 (4x1)
-    const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+    const GGConfig cfg = gg_config(max_rows, g->Cr, ncls);
+    const int BM = cfg.BM, BN = cfg.BN;
     // the gather window of one workgroup: rows of at most (BM / rows_per_batch + 2) batch items
     {
         int64_t min_rows_b = (int64_t)p.cls[0].qD * p.cls[0].qH * p.cls[0].qW;
@@ -674,11 +752,8 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     const int64_t tiles_n = vn_ceil_div(g->Cr, BN);
     if (tiles_m * tiles_n > 0x7fffffffll) return VN_EUNSUPPORTED;
     const dim3 grid((unsigned)(tiles_m * tiles_n), (unsigned)ncls);
-    const size_t lds = 2u * (size_t)(BM + BN) * 128u;
     hipStream_t st = vn_stream(stream);
-    int rc;
-    if (wide) rc = f32 ? launch_gg<2, 2, true>(p, grid, lds, st) : launch_gg<2, 2, false>(p, grid, lds, st);
-    else rc = f32 ? launch_gg<4, 1, true>(p, grid, lds, st) : launch_gg<4, 1, false>(p, grid, lds, st);
+    const int rc = launch_cfg(cfg, f32, p, grid, st);
     if (rc) return rc;
     VN_LAUNCH_STATUS();
     return VN_OK;

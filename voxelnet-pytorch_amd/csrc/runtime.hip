@@ -184,7 +184,11 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         P->slab_rows[l] = 0;
         P->slab[l] = nullptr;
         if (!sp.transposed) {
-            P->slab_rows[l] = vn_ceil_div(M, sp.cout > 64 ? 128 : 256);
+            vnConv sg{};                       // the conv kernel picks its tile (= slab granularity) from these
+            sg.B = B; sg.Dr = P->odims[l][0]; sg.Hr = P->odims[l][1]; sg.Wr = P->odims[l][2]; sg.Cr = sp.cout;
+            sg.divD = sg.divH = sg.divW = 1;
+            P->slab_rows[l] = vn_conv_stats_slab_rows(&sg);
+            (void)M;
             P->slab[l] = (float *)A.take((size_t)P->slab_rows[l] * 2 * sp.cout * sizeof(float));
         }
         if (sp.transposed) {   // activation = channel slice of the concat: cat([d3,d2,d1]) (model.py:271-273)

@@ -248,7 +248,10 @@ def layer_forward(spec, x, params, buffers, training, mode, out=None, y_dtype=No
     else:
         mul, tmul, pad, div = spec.stride, (1, 1, 1), spec.pad, (1, 1, 1)
     if fuse_stats:
-        slab_rows = -(-y.M // (128 if spec.cout > 64 else 256))
+        sg = _lib.VnConv()
+        sg.B, sg.Dr, sg.Hr, sg.Wr, sg.Cr = B, odims[0], odims[1], odims[2], spec.cout
+        sg.divD = sg.divH = sg.divW = 1
+        slab_rows = _lib.load().vn_conv_stats_slab_rows(ctypes.byref(sg))      # = M / the tile height the kernel picks
         slab = torch.empty((slab_rows, 2, spec.cout), dtype=torch.float32, device=dev)
     gather_gemm(x, wp, bias, y, spec.k, spec.cin, spec.cout, mul, tmul, pad, div, odims, stats=slab)
     st = LayerState()
