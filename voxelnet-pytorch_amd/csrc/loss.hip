@@ -1,0 +1,180 @@
+// RPN loss of RPN3D.forward (model.py:309-352) and smooth_L1_loss (loss.py:3-13, its option1*option2 quirk
+// included), forward and backward, each as ONE pass over the (B, h, w) anchor sites instead of ~50 elementwise /
+// reduction launches.  One thread per site: 2 anchors x (1 score + 7 regression channels).
+//   P_b = max(1, sum pos[b]),  N_b = max(1, sum neg[b])                                    (model.py:313-322)
+//   cls_pos = -pos * log(p + 1e-6) / P_b ;  cls_neg = -neg * log(1 - p + 1e-6) / N_b       (model.py:340-341)
+//   reg     = smooth_L1(delta*posr, tgt*posr) / P_b                                         (model.py:347-349)
+//   out[5]  = [alpha*S_pos + beta*S_neg + S_reg, alpha*S_pos + beta*S_neg, S_reg, S_pos, S_neg]
+// Layouts: prob (B,2,h,w), delta (B,14,h,w) fp32 NCHW (the module's outputs); pos/neg (B,h,w,2), targets (B,h,w,14)
+// fp32 channels-last (utils.generate_targets' arrays, model.py:309).  HBM-bound: ~0.1 KB per site, 70,400 sites.
+// Sums: per-thread fp32 -> per-workgroup slab rows -> one workgroup reduces the slab in double (deterministic).
+#include "common.h"
+
+namespace {
+
+constexpr int LOSS_THREADS = 256;
+
+__global__ void __launch_bounds__(LOSS_THREADS) k_loss_norm(const float *__restrict__ pos, const float *__restrict__ neg,
+                                                            int64_t per_b, float *__restrict__ norm, int B) {
+    const int b = blockIdx.x;
+    float sp = 0.f, sn = 0.f;   // sums of 0/1 indicators: exact in fp32 far beyond these sizes
+    for (int64_t i = threadIdx.x; i < per_b; i += LOSS_THREADS) {
+        sp += pos[(int64_t)b * per_b + i];
+        sn += neg[(int64_t)b * per_b + i];
+    }
+    __shared__ float red[2][LOSS_THREADS / 64];
+    sp = vn_wave_sum(sp);
+    sn = vn_wave_sum(sn);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sp; red[1][threadIdx.x >> 6] = sn; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.f, c = 0.f;
+        for (int w = 0; w < LOSS_THREADS / 64; ++w) { a += red[0][w]; c += red[1][w]; }
+        norm[b] = fmaxf(a, 1.f);
+        norm[B + b] = fmaxf(c, 1.f);
+    }
+}
+
+struct LossGeom {
+    int32_t B, H, W;
+    float alpha, beta, sigma2;
+};
+
+__device__ __forceinline__ float smooth_l1(float diff, float sigma2, float *ddiff) {
+    const float ad = fabsf(diff);
+    const float sign = ad < 1.0f / sigma2 ? 1.f : 0.f;
+    const float o1 = diff * diff * 0.5f * sigma2;
+    const float o2 = ad - 0.5f / sigma2;
+    const float sg = diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f);     // d|x|/dx with 0 at 0, as autograd has it
+    *ddiff = sigma2 * diff * o2 + o1 * sg + sg * (1.f - sign);
+    return o1 * o2 + o2 * (1.f - sign);
+}
+
+template <bool BWD>
+__global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__ prob, const float *__restrict__ reg,
+                                                       const float *__restrict__ pos, const float *__restrict__ neg,
+                                                       const float *__restrict__ tgt, const float *__restrict__ norm,
+                                                       LossGeom g, float *__restrict__ slab /* fwd: [blocks][3] */,
+                                                       const float *__restrict__ gout /* bwd: [5] */,
+                                                       float *__restrict__ d_prob, float *__restrict__ d_reg) {
+    const int64_t hw = (int64_t)g.H * g.W, sites = hw * g.B;
+    const int64_t site = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x;
+    float s_pos = 0.f, s_neg = 0.f, s_reg = 0.f;
+    if (site < sites) {
+        const int b = (int)(site / hw);
+        const int64_t yx = site - (int64_t)b * hw;
+        const float inv_p = 1.f / norm[b], inv_n = 1.f / norm[g.B + b];
+        const float2 ps = *reinterpret_cast<const float2 *>(pos + site * 2);
+        const float2 ng = *reinterpret_cast<const float2 *>(neg + site * 2);
+        const float pa[2] = {ps.x, ps.y}, na[2] = {ng.x, ng.y};
+        float kp = 0.f, kn = 0.f, kr = 0.f;
+        if (BWD) {
+            const float gl = gout[0], gc = gout[1], gr = gout[2], gp = gout[3], gn = gout[4];
+            kp = g.alpha * (gl + gc) + gp;
+            kn = g.beta * (gl + gc) + gn;
+            kr = gl + gr;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int64_t pi = ((int64_t)b * 2 + a) * hw + yx;
+            const float p = prob[pi];
+            if (BWD) {
+                d_prob[pi] = -kp * pa[a] * inv_p / (p + 1e-6f) + kn * na[a] * inv_n / (1.f - p + 1e-6f);
+            } else {
+                s_pos += -pa[a] * logf(p + 1e-6f) * inv_p;
+                s_neg += -na[a] * logf(1.f - p + 1e-6f) * inv_n;
+            }
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const int c = a * 7 + j;
+                const int64_t ri = ((int64_t)b * 14 + c) * hw + yx;
+                const float diff = reg[ri] * pa[a] - tgt[site * 14 + c] * pa[a];
+                float dd;
+                const float l = smooth_l1(diff, g.sigma2, &dd);
+                if (BWD) d_reg[ri] = kr * dd * pa[a] * inv_p;
+                else s_reg += l * inv_p;
+            }
+        }
+    }
+    if (!BWD) {
+        __shared__ float red[3][LOSS_THREADS / 64];
+        s_pos = vn_wave_sum(s_pos); s_neg = vn_wave_sum(s_neg); s_reg = vn_wave_sum(s_reg);
+        if ((threadIdx.x & 63) == 0) {
+            red[0][threadIdx.x >> 6] = s_pos; red[1][threadIdx.x >> 6] = s_neg; red[2][threadIdx.x >> 6] = s_reg;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            float v = 0.f;
+            for (int w = 0; w < LOSS_THREADS / 64; ++w) v += red[threadIdx.x][w];
+            slab[(int64_t)blockIdx.x * 3 + threadIdx.x] = v;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(LOSS_THREADS) k_loss_finalize(const float *__restrict__ slab, int nblocks, float alpha,
+                                                                float beta, float *__restrict__ out) {
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nblocks; i += LOSS_THREADS)
+        for (int k = 0; k < 3; ++k) s[k] += (double)slab[(int64_t)i * 3 + k];
+    __shared__ double red[3][LOSS_THREADS / 64];
+    for (int k = 0; k < 3; ++k) {
+        double v = s[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t[3];
+        for (int k = 0; k < 3; ++k) { t[k] = 0.0; for (int w = 0; w < LOSS_THREADS / 64; ++w) t[k] += red[k][w]; }
+        const double cls = (double)alpha * t[0] + (double)beta * t[1];
+        out[0] = (float)(cls + t[2]);
+        out[1] = (float)cls;
+        out[2] = (float)t[2];
+        out[3] = (float)t[0];
+        out[4] = (float)t[1];
+    }
+}
+
+bool loss_args_ok(int32_t B, int32_t H, int32_t W) { return B > 0 && H > 0 && W > 0 && (int64_t)B * H * W < (1ll << 31); }
+
+}  // namespace
+
+extern "C" size_t vn_rpn_loss_workspace_bytes(int32_t B, int32_t H, int32_t W) {
+    if (!loss_args_ok(B, H, W)) return 0;
+    const int64_t blocks = vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
+    return vn_align(sizeof(float) * 2 * (size_t)B) + vn_align(sizeof(float) * 3 * (size_t)blocks);
+}
+
+extern "C" int vn_rpn_loss_fwd(const float *prob, const float *delta, const float *pos, const float *neg,
+                               const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
+                               void *workspace, size_t workspace_bytes, float *out5, vnStream stream) {
+    VN_CHECK_ARG(prob && delta && pos && neg && targets && workspace && out5 && loss_args_ok(B, H, W) && sigma > 0.f);
+    if (workspace_bytes < vn_rpn_loss_workspace_bytes(B, H, W)) return VN_EWORKSPACE;
+    hipStream_t st = vn_stream(stream);
+    float *norm = static_cast<float *>(workspace);
+    float *slab = reinterpret_cast<float *>(static_cast<char *>(workspace) + vn_align(sizeof(float) * 2 * (size_t)B));
+    const int blocks = (int)vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
+    k_loss_norm<<<B, LOSS_THREADS, 0, st>>>(pos, neg, (int64_t)H * W * 2, norm, B);
+    VN_LAUNCH_STATUS();
+    const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
+    k_loss<false><<<blocks, LOSS_THREADS, 0, st>>>(prob, delta, pos, neg, targets, norm, g, slab, nullptr, nullptr, nullptr);
+    VN_LAUNCH_STATUS();
+    k_loss_finalize<<<1, LOSS_THREADS, 0, st>>>(slab, blocks, alpha, beta, out5);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_rpn_loss_bwd(const float *prob, const float *delta, const float *pos, const float *neg,
+                               const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
+                               const void *workspace, const float *grad_out5, float *d_prob, float *d_delta,
+                               vnStream stream) {
+    VN_CHECK_ARG(prob && delta && pos && neg && targets && workspace && grad_out5 && d_prob && d_delta &&
+                 loss_args_ok(B, H, W) && sigma > 0.f);
+    const float *norm = static_cast<const float *>(workspace);   // written by vn_rpn_loss_fwd
+    const int blocks = (int)vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
+    const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
+    k_loss<true><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, nullptr, grad_out5,
+                                                                  d_prob, d_delta);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}

@@ -101,6 +101,10 @@ SIGNATURES = {
     "vn_cast_rows": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
     "vn_col_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "vn_heads_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "vn_rpn_loss_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
+    "vn_rpn_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp]),
+    "vn_rpn_loss_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp,
+                                c_vp]),
 }
 
 _lib = None

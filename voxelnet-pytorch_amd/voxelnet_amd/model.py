@@ -634,6 +634,40 @@ def smooth_L1_loss(deltas, targets, sigma=3.0):
     return torch.mul(option1, option2) + torch.mul(option2, 1 - smooth_l1_signs)
 
 
+class _LossFn(torch.autograd.Function):
+    """model.py:309-352 as two fused passes over the anchor sites (csrc/loss.hip) -> tensor [loss, cls_loss,
+    reg_loss, cls_pos_loss_rec, cls_neg_loss_rec]"""
+
+    @staticmethod
+    def forward(ctx, prob, delta, pos, neg, tgt, alpha, beta, sigma):
+        _need_cuda(prob, delta, pos, neg, tgt)
+        B, _, H, W = prob.shape
+        if tuple(delta.shape) != (B, 14, H, W) or tuple(pos.shape) != (B, H, W, 2) or tuple(neg.shape) != (B, H, W, 2) \
+                or tuple(tgt.shape) != (B, H, W, 14):
+            raise ValueError(f"loss: shapes {tuple(prob.shape)} {tuple(delta.shape)} {tuple(pos.shape)} "
+                             f"{tuple(neg.shape)} {tuple(tgt.shape)} do not belong together")
+        prob, delta = prob.detach().contiguous().float(), delta.detach().contiguous().float()
+        with torch.cuda.device(prob.device):
+            ws_bytes = _lib.load().vn_rpn_loss_workspace_bytes(B, H, W)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=prob.device)
+            out = torch.empty(5, dtype=torch.float32, device=prob.device)
+            _lib.call("vn_rpn_loss_fwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
+                      B, H, W, alpha, beta, sigma, ws.data_ptr(), ws_bytes, out.data_ptr(), E.stream())
+        ctx.saved = (prob, delta, pos, neg, tgt, ws, (B, H, W, alpha, beta, sigma))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, delta, pos, neg, tgt, ws, (B, H, W, alpha, beta, sigma) = ctx.saved
+        g = g.contiguous().float()
+        with torch.cuda.device(prob.device):
+            d_prob, d_delta = torch.empty_like(prob), torch.empty_like(delta)
+            _lib.call("vn_rpn_loss_bwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
+                      B, H, W, alpha, beta, sigma, ws.data_ptr(), g.data_ptr(), d_prob.data_ptr(), d_delta.data_ptr(),
+                      E.stream())
+        return d_prob, d_delta, None, None, None, None, None, None
+
+
 class RPN3D(nn.Module):
     """model.py:284-362.  forward(x: 7-tuple batch, device) -> 7-tuple like the reference.
     Targets: pass `targets=(pos_equal_one, neg_equal_one, targets)` (channels-last arrays as
@@ -680,22 +714,14 @@ class RPN3D(nn.Module):
         return prob, reg
 
     def loss(self, prob_out, delta_out, pos_equal_one, neg_equal_one, targets):
-        """model.py:310-352 on device (elementwise + reductions through PyTorch-ROCm ops)."""
+        """model.py:310-352 -> (loss, cls_loss, reg_loss, cls_pos_loss_rec, cls_neg_loss_rec), fused (csrc/loss.hip)."""
         dev = prob_out.device
 
         def f32(a):
-            return (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev).float()
-        pos, neg, tgt = f32(pos_equal_one), f32(neg_equal_one), f32(targets)
-        pos_reg = torch.cat([pos[..., 0:1].expand(-1, -1, -1, 7), pos[..., 1:2].expand(-1, -1, -1, 7)], -1)
-        pos_sum = pos.sum(dim=(1, 2, 3)).reshape(-1, 1, 1, 1).clamp(min=1)
-        neg_sum = neg.sum(dim=(1, 2, 3)).reshape(-1, 1, 1, 1).clamp(min=1)
-        pos_c, neg_c = pos.permute(0, 3, 1, 2), neg.permute(0, 3, 1, 2)
-        tgt_c, posr_c = tgt.permute(0, 3, 1, 2), pos_reg.permute(0, 3, 1, 2)
-        cls_pos_loss = (-pos_c * torch.log(prob_out + 1e-6)) / pos_sum
-        cls_neg_loss = (-neg_c * torch.log(1 - prob_out + 1e-6)) / neg_sum
-        cls_loss = torch.sum(self.alpha * cls_pos_loss + self.beta * cls_neg_loss)
-        reg_loss = torch.sum(smooth_L1_loss(delta_out * posr_c, tgt_c * posr_c, self.sigma) / pos_sum)
-        return cls_loss + reg_loss, cls_loss, reg_loss, torch.sum(cls_pos_loss), torch.sum(cls_neg_loss)
+            return (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev).float().contiguous()
+        out = _LossFn.apply(prob_out, delta_out, f32(pos_equal_one), f32(neg_equal_one), f32(targets),
+                            float(self.alpha), float(self.beta), float(self.sigma))
+        return tuple(out.unbind(0))
 
     def forward(self, x, device, targets=None):
         label, voxel_features, voxel_coordinates = x[1], x[2], x[4]
