@@ -192,3 +192,36 @@ def test_bev_fold_and_strided_views(mode):
     assert rel_err(g3["weight"], lv["middle_rpn.middle_layer.2.conv.weight"].grad.numpy()) < 1e-3
     assert rel_err(g3["gamma"], lv["middle_rpn.middle_layer.2.batch_norm.weight"].grad.numpy()) < 1e-3
     assert rel_err(E.rows_to_nchw(dx, 3), xs.grad.numpy()) < 1e-3
+
+
+def test_batched_pack_unpack_matches_single_calls():
+    """vn_pack_weights_batch / vn_unpack_wgrads_batch == the per-layer calls, bit for bit (all four modes, BEV fold)"""
+    from voxelnet_amd import _lib, engine as E
+    DEV = "cuda:0"
+    torch.manual_seed(5)
+    cases = [(64, 128, 27, 0, 1), (64, 128, 27, 1, 1), (256, 128, 4, 2, 1), (256, 128, 4, 3, 1), (128, 128, 9, 0, 2),
+             (128, 128, 9, 1, 2), (16, 768, 1, 0, 1)]
+    ws, singles, jobs = [], [], (_lib.VnPackJob * len(cases))()
+    batch = []
+    for i, (co, ci, taps, mode, fold) in enumerate(cases):
+        w = torch.randn(co * ci * taps, device=DEV)
+        a = torch.zeros(co * ci * taps, dtype=torch.bfloat16, device=DEV)
+        b = torch.zeros_like(a)
+        _lib.call("vn_pack_weight", w.data_ptr(), co, ci, taps, mode, 0, fold, a.data_ptr(), _lib.VN_BF16, E.stream())
+        jobs[i] = _lib.VnPackJob(w.data_ptr(), b.data_ptr(), co, ci, taps, mode, 0, fold, _lib.VN_BF16, 0)
+        ws.append(w); singles.append(a); batch.append(b)
+    _lib.call("vn_pack_weights_batch", jobs, len(cases), E.stream())
+    for a, b in zip(singles, batch):
+        assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    ucases = [c for c in cases if c[3] in (0, 2)]
+    ujobs, us, ub = (_lib.VnUnpackJob * len(ucases))(), [], []
+    keep = []
+    for i, (co, ci, taps, mode, fold) in enumerate(ucases):
+        dwp = torch.randn(co * ci * taps, device=DEV)
+        a, b = torch.zeros_like(dwp), torch.zeros_like(dwp)
+        _lib.call("vn_unpack_wgrad", dwp.data_ptr(), co, ci, taps, mode, fold, a.data_ptr(), E.stream())
+        ujobs[i] = _lib.VnUnpackJob(dwp.data_ptr(), b.data_ptr(), co, ci, taps, mode, fold, 0)
+        keep.append(dwp); us.append(a); ub.append(b)
+    _lib.call("vn_unpack_wgrads_batch", ujobs, len(ucases), E.stream())
+    for a, b in zip(us, ub):
+        assert torch.equal(a, b)

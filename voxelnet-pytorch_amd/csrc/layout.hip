@@ -57,6 +57,62 @@ __global__ void __launch_bounds__(256) k_unpack_wgrad(const float *__restrict__ 
     }
 }
 
+// ---- batched forms: every layer of the network in ONE launch (48 + 24 launches of ~5 us of dispatch each otherwise)
+constexpr int PACK_MAX_JOBS = 56;
+struct PackJobs {
+    int32_t n;
+    int32_t block_begin[PACK_MAX_JOBS + 1];
+    vnPackJob job[PACK_MAX_JOBS];
+};
+struct UnpackJobs {
+    int32_t n;
+    int32_t block_begin[PACK_MAX_JOBS + 1];
+    vnUnpackJob job[PACK_MAX_JOBS];
+};
+
+__device__ __forceinline__ int find_job(const int32_t *block_begin, int n) {
+    int j = 0;
+    while (j + 1 < n && (int)blockIdx.x >= block_begin[j + 1]) ++j;   // block-uniform (scalar) search
+    return j;
+}
+
+__global__ void __launch_bounds__(256) k_pack_weights_batch(const PackJobs t) {
+    const int j = find_job(t.block_begin, t.n);
+    const vnPackJob &q = t.job[j];
+    const int nb = t.block_begin[j + 1] - t.block_begin[j], b = blockIdx.x - t.block_begin[j];
+    const int N = (q.mode == 0 || q.mode == 2) ? q.c_out : q.c_in;
+    const int K = (q.mode == 0 || q.mode == 2) ? q.c_in : q.c_out;
+    const int Ke = q.split3 ? 3 * K : K;
+    const int64_t total = (int64_t)q.taps * N * Ke;
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < total; i += (int64_t)nb * 256) {
+        const int ke = (int)(i % Ke);
+        const int n = (int)((i / Ke) % N);
+        const int tap = (int)(i / ((int64_t)Ke * N));
+        const int k = ke % K, part = ke / K;
+        const float v = q.w[torch_index(q.mode, q.c_out, q.c_in, q.taps, tap, n, k, q.cin_fold)];
+        if (q.packed_dtype == VN_F32) {
+            static_cast<float *>(q.packed)[i] = v;
+        } else {
+            bf16_t hi, lo;
+            vn_split_bf16(v, hi, lo);
+            static_cast<bf16_t *>(q.packed)[i] = part == 2 ? lo : hi;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_unpack_wgrads_batch(const UnpackJobs t) {
+    const int j = find_job(t.block_begin, t.n);
+    const vnUnpackJob &q = t.job[j];
+    const int nb = t.block_begin[j + 1] - t.block_begin[j], b = blockIdx.x - t.block_begin[j];
+    const int64_t total = (int64_t)q.taps * q.c_out * q.c_in;
+    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < total; i += (int64_t)nb * 256) {
+        const int k = (int)(i % q.c_in);
+        const int n = (int)((i / q.c_in) % q.c_out);
+        const int tap = (int)(i / ((int64_t)q.c_in * q.c_out));
+        q.dw[torch_index(q.mode, q.c_out, q.c_in, q.taps, tap, n, k, q.cin_fold)] = q.dw_packed[i];
+    }
+}
+
 __device__ __forceinline__ void store_elem(void *dst, int dtype, int64_t lo_off, int64_t row_off, int c, float v) {
     if (dtype == VN_F32) {
         static_cast<float *>(dst)[row_off + c] = v;
@@ -234,6 +290,54 @@ extern "C" int vn_unpack_wgrad(const float *dw_packed, int32_t c_out, int32_t c_
     const int64_t total = (int64_t)taps * c_out * c_in;
     k_unpack_wgrad<<<gs_blocks(total), 256, 0, vn_stream(stream)>>>(dw_packed, c_out, c_in, taps, mode, cin_fold, dw);
     VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_pack_weights_batch(const vnPackJob *jobs, int32_t n, vnStream stream) {
+    VN_CHECK_ARG(n >= 0 && (jobs || n == 0));
+    for (int32_t base = 0; base < n; base += PACK_MAX_JOBS) {
+        PackJobs t{};
+        t.n = n - base < PACK_MAX_JOBS ? n - base : PACK_MAX_JOBS;
+        int blocks = 0;
+        for (int j = 0; j < t.n; ++j) {
+            const vnPackJob &q = jobs[base + j];
+            VN_CHECK_ARG(q.w && q.packed && q.c_out > 0 && q.c_in > 0 && q.taps > 0 && q.mode >= 0 && q.mode <= 3);
+            VN_CHECK_ARG(q.packed_dtype == VN_BF16 || (q.packed_dtype == VN_F32 && !q.split3));
+            VN_CHECK_ARG(q.cin_fold >= 1 && q.c_in % q.cin_fold == 0);
+            const int64_t total = (int64_t)q.taps * q.c_out * q.c_in * (q.split3 ? 3 : 1);
+            int64_t nb = vn_ceil_div(total, 256 * 8);          // 8 elements per thread
+            if (nb > 256) nb = 256;
+            t.job[j] = q;
+            t.block_begin[j] = blocks;
+            blocks += (int)nb;
+        }
+        t.block_begin[t.n] = blocks;
+        k_pack_weights_batch<<<blocks, 256, 0, vn_stream(stream)>>>(t);
+        VN_LAUNCH_STATUS();
+    }
+    return VN_OK;
+}
+
+extern "C" int vn_unpack_wgrads_batch(const vnUnpackJob *jobs, int32_t n, vnStream stream) {
+    VN_CHECK_ARG(n >= 0 && (jobs || n == 0));
+    for (int32_t base = 0; base < n; base += PACK_MAX_JOBS) {
+        UnpackJobs t{};
+        t.n = n - base < PACK_MAX_JOBS ? n - base : PACK_MAX_JOBS;
+        int blocks = 0;
+        for (int j = 0; j < t.n; ++j) {
+            const vnUnpackJob &q = jobs[base + j];
+            VN_CHECK_ARG(q.dw_packed && q.dw && q.c_out > 0 && q.c_in > 0 && q.taps > 0 && (q.mode == 0 || q.mode == 2));
+            VN_CHECK_ARG(q.cin_fold >= 1 && q.c_in % q.cin_fold == 0);
+            int64_t nb = vn_ceil_div((int64_t)q.taps * q.c_out * q.c_in, 256 * 8);
+            if (nb > 256) nb = 256;
+            t.job[j] = q;
+            t.block_begin[j] = blocks;
+            blocks += (int)nb;
+        }
+        t.block_begin[t.n] = blocks;
+        k_unpack_wgrads_batch<<<blocks, 256, 0, vn_stream(stream)>>>(t);
+        VN_LAUNCH_STATUS();
+    }
     return VN_OK;
 }
 

@@ -284,16 +284,30 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
     const int training = cfg->training;
     const float mom = 0.1f, eps = 1e-5f;
     if (P.zf_end > P.zf_begin) VN_HIP(hipMemsetAsync(P.zf_begin, 0, (size_t)(P.zf_end - P.zf_begin), hs));
+    {   // every layer's weights -> MFMA operand layout, forward and (training) data-gradient orientation: one launch
+        vnPackJob jobs[2 * NL + 2];
+        int nj = 0;
+        for (int l = 0; l < NL; ++l) {
+            const Spec &sp = P.spec[l];
+            const int taps = sp.k[0] * sp.k[1] * sp.k[2];
+            jobs[nj++] = vnPackJob{L[l].weight, P.wp_f[l], sp.cout, sp.cin, taps, sp.transposed ? 2 : 0, 0, sp.cin_fold, P.adt, 0};
+            if (training) {
+                const bool first_sparse = l == 0 && cfg->sparse_first;
+                jobs[nj++] = vnPackJob{L[l].weight, P.wp_d[l], sp.cout, sp.cin, taps, sp.transposed ? 3 : 1, 0,
+                                       first_sparse ? 1 : sp.cin_fold, P.adt, 0};
+            }
+        }
+        jobs[nj++] = vnPackJob{heads_w, P.hwp_f, 16, 768, 1, 0, 0, 1, P.adt, 0};
+        if (training) jobs[nj++] = vnPackJob{heads_w, P.hwp_d, 16, 768, 1, 1, 0, 1, P.adt, 0};
+        RT(vn_pack_weights_batch(jobs, nj, stream));
+    }
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
     Rows x1{}, x2{};
     for (int l = 0; l < NL; ++l) {
         const Spec &sp = P.spec[l];
-        const int taps = sp.k[0] * sp.k[1] * sp.k[2];
         if (l == L_D1) x = x1;                 // deconv1 and block2 both read the block1 output
         if (l == L_B2) x = x1;
         if (l == L_D2 || l == L_B3) x = x2;
-        RT(vn_pack_weight(L[l].weight, sp.cout, sp.cin, taps, sp.transposed ? 2 : 0, 0, sp.cin_fold, P.wp_f[l],
-                          (vnDtype)P.adt, stream));
         const Rows &y = P.y[l];
         const int64_t M = y.M();
         vnConv g = fwd_geom(sp, x, P.odims[l], y);
@@ -333,7 +347,6 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
     // heads: one N=16 GEMM over the 768-channel concat + sigmoid on the first two channels (model.py:276-281)
     {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
-        RT(vn_pack_weight(heads_w, 16, 768, 1, 0, 0, 1, P.hwp_f, (vnDtype)P.adt, stream));
         const int od[3] = {1, P.hf, P.wf};
         vnConv g = fwd_geom(hs16, P.cat, od, P.hy);
         RT(vn_conv_gather_gemm(P.cat.ptr, P.hwp_f, heads_b, P.hy.ptr, VN_F32, &g, 0, nullptr, stream));
@@ -360,6 +373,10 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     if (seg_begin == 0) VN_HIP(hipMemsetAsync(P.zb_begin, 0, (size_t)(P.zb_end - P.zb_begin), hs));
     const int B = cfg->B;
     const int64_t S = (int64_t)P.hf * P.wf;
+    // packed fp32 weight gradients -> torch layouts: collected here, one launch at the end of the segment.
+    // (the data-gradient operand packs were made by vn_net_forward, cfg->training)
+    vnUnpackJob unpack[NL + 1];
+    int nu = 0;
     // ---- heads
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
@@ -370,8 +387,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
         RT(vn_conv_wgrad(P.cat.ptr, P.d_rows.ptr, P.hdwp, &gw, 0, stream));
-        RT(vn_unpack_wgrad(P.hdwp, 16, 768, 1, 0, 1, d_heads_w, stream));
-        RT(vn_pack_weight(heads_w, 16, 768, 1, 1, 0, 1, P.hwp_d, (vnDtype)P.adt, stream));
+        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, 0};
         const int64_t os[4] = {P.d_cat.sB, P.d_cat.sD, P.d_cat.sH, P.d_cat.sW};
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
         RT(vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.pdt, &gd, 0, nullptr, stream));
@@ -443,8 +459,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
             RT(vn_conv_wgrad_rows(dy.ptr, vw_rows, P.dwp[l], &gw, coord, K, stream));
-            RT(vn_unpack_wgrad(P.dwp[l], sp.cin, C, taps, 2, 1, G[l].weight, stream));
-            RT(vn_pack_weight(L[l].weight, sp.cout, sp.cin, taps, 1, 0, 1, P.wp_d[l], (vnDtype)P.adt, stream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, 0};
             RT(vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr,
                                         stream));
             continue;
@@ -454,12 +469,12 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
             const int64_t rs[4] = {x.sB, x.sD, x.sH, x.sW};
             vnConv gw = geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, rs);
             RT(vn_conv_wgrad(dy.ptr, x.ptr, P.dwp[l], &gw, 0, stream));
-            RT(vn_unpack_wgrad(P.dwp[l], sp.cin, C, taps, 0, 1, G[l].weight, stream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, 0};
         } else {
             const int64_t rs[4] = {dy.sB, dy.sD, dy.sH, dy.sW};
             vnConv gw = geom(x, P.odims[l], sp.cin, C, sp.k, sp.s, ONE, sp.p, ONE, rs);
             RT(vn_conv_wgrad(x.ptr, dy.ptr, P.dwp[l], &gw, 0, stream));
-            RT(vn_unpack_wgrad(P.dwp[l], C, sp.cin, taps, 0, sp.cin_fold, G[l].weight, stream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, 0};
         }
         // data gradient
         Rows dx = P.dx[l];
@@ -468,13 +483,12 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
             dx = dense_rows(d_input, P.pdt, B, cfg->D, cfg->H, cfg->W, 128);
         }
         const bool accumulate = (l == L_D1 || l == L_D2);
-        RT(vn_pack_weight(L[l].weight, sp.cout, sp.cin, taps, sp.transposed ? 3 : 1, 0, sp.cin_fold, P.wp_d[l],
-                          (vnDtype)P.adt, stream));
         const int64_t os[4] = {dx.sB, dx.sD, dx.sH, dx.sW};
         vnConv gd = sp.transposed ? geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, os)
                                   : geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, os);
         RT(vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr,
                                stream));
     }
+    RT(vn_unpack_wgrads_batch(unpack, nu, stream));
     return VN_OK;
 }

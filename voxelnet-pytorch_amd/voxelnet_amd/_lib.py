@@ -55,6 +55,15 @@ class VnLayerGrads(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in ("weight", "bias", "gamma", "beta")]
 
 
+class VnPackJob(ctypes.Structure):
+    _fields_ = [("w", c_vp), ("packed", c_vp)] + [(n, c_i32) for n in ("c_out", "c_in", "taps", "mode", "split3", "cin_fold",
+                                                                       "packed_dtype", "pad_")]
+
+
+class VnUnpackJob(ctypes.Structure):
+    _fields_ = [("dw_packed", c_vp), ("dw", c_vp)] + [(n, c_i32) for n in ("c_out", "c_in", "taps", "mode", "cin_fold", "pad_")]
+
+
 # name -> (restype, argtypes); mirrors include/voxelnet_hip.h one to one
 _P = ctypes.POINTER
 SIGNATURES = {
@@ -101,6 +110,8 @@ SIGNATURES = {
     "vn_cast_rows": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
     "vn_col_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp]),
     "vn_heads_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp]),
+    "vn_pack_weights_batch": (c_i32, [c_vp, c_i32, c_vp]),
+    "vn_unpack_wgrads_batch": (c_i32, [c_vp, c_i32, c_vp]),
     "vn_rpn_loss_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "vn_rpn_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp]),
     "vn_rpn_loss_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp,
