@@ -174,13 +174,17 @@ int vn_conv_gather_gemm(const void *src, const void *w_packed /*[taps][Cr][Cs]*/
                         vnStream stream);
 
 /* Weight-gradient: dw[tap][n][k] += sum_m src[site(m,tap), k] * rows[m, n]
- * fp32, packed [taps][Cr][C] orientation, C = real source channels; split over m
- * with fp32 atomics — the caller zeroes dw first.  rows_* strides address the
- * (B,Dr,Hr,Wr,Cr) gradient.  split != 0: src rows are [hi|lo] 2C wide and rows
+ * fp32, packed [taps][Cr][C] orientation, C = real source channels — the caller zeroes dw first.
+ * The sum over m is split into row chunks whose partial tiles go to `workspace`
+ * (vn_conv_wgrad_workspace_bytes; n_rows = 0 for the dense form) and are then added in a fixed order: no
+ * atomics, bit-reproducible.  A NULL / smaller workspace only means fewer chunks (less parallelism).
+ * rows_* strides address the (B,Dr,Hr,Wr,Cr) gradient.  split != 0: src rows are [hi|lo] 2C wide and rows
  * are [hi|lo] 2Cr wide; the three bf16x3 products are accumulated.
  * geom->Cs is the real C here and geom->src_wrap is ignored. */
+size_t vn_conv_wgrad_workspace_bytes(const vnConv *geom, int32_t split, int64_t n_rows);
 int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16*/, float *dw_packed,
-                  const vnConv *geom, int32_t split, vnStream stream);
+                  const vnConv *geom, int32_t split, void *workspace, size_t workspace_bytes,
+                  vnStream stream);
 
 /* Row-list ("sparse rows") variants for the first middle layer, whose input grid is ~99 % empty:
  * the produced rows are an explicit list of (b,d,h,w) int64 coordinates instead of the dense
@@ -194,7 +198,8 @@ int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, const float 
                              int64_t row_cap, const int32_t *row_count, int32_t out_linear,
                              float *stats_slab, vnStream stream);
 int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_packed, const vnConv *geom,
-                       const int64_t *row_list, int64_t n_rows, vnStream stream);
+                       const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes,
+                       vnStream stream);
 /* Active output sites of a forward conv over a sparse input: the ordered (b,d,h,w) list of the sites
  * whose receptive field contains at least one of the K occupied voxel coordinates (coord (K,4) int64
  * [b,z,y,x]).  geom = the conv's forward geometry.  list holds up to cap rows; *count = min(n, cap).

@@ -52,9 +52,11 @@ for name in names:
     if sp.transposed:
         dwp = torch.zeros((taps, sp.cin, sp.cout), device=dev)
         g = E._geom(B, dy, dims, sp.cout, 0, sp.cin, sp.k, sp.stride, (1, 1, 1), sp.pad, (1, 1, 1), x.strides)
-        t_w = timeit(lambda: _lib.call("vn_conv_wgrad", dy.ptr(), x.ptr(), dwp.data_ptr(), ctypes.byref(g), 0, E.stream()))
+        ws, wsb = E.wgrad_workspace(g, 0, 0, dev)
+        t_w = timeit(lambda: _lib.call("vn_conv_wgrad", dy.ptr(), x.ptr(), dwp.data_ptr(), ctypes.byref(g), 0, ws.data_ptr(), wsb, E.stream()))
     else:
         dwp = torch.zeros((taps, sp.cout, sp.cin), device=dev)
         g = E._geom(B, x, od, sp.cin, 0, sp.cout, sp.k, sp.stride, (1, 1, 1), sp.pad, (1, 1, 1), dy.strides)
-        t_w = timeit(lambda: _lib.call("vn_conv_wgrad", x.ptr(), dy.ptr(), dwp.data_ptr(), ctypes.byref(g), 0, E.stream()))
+        ws, wsb = E.wgrad_workspace(g, 0, 0, dev)
+        t_w = timeit(lambda: _lib.call("vn_conv_wgrad", x.ptr(), dy.ptr(), dwp.data_ptr(), ctypes.byref(g), 0, ws.data_ptr(), wsb, E.stream()))
     print(f"{name:16s} {flops/1e9:7.1f} GF  fwd {t_f*1e3:7.1f} us {flops/t_f/1e9:6.0f} TF | dgrad {t_d*1e3:7.1f} us {flops/t_d/1e9:6.0f} TF | wgrad {t_w*1e3:7.1f} us {flops/t_w/1e9:6.0f} TF")

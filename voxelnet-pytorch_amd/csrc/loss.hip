@@ -14,11 +14,14 @@ namespace {
 
 constexpr int LOSS_THREADS = 256;
 
+constexpr int NORM_CHUNKS = 64;   // workgroups per sample in the normaliser reduction
+
+// part[(b*NORM_CHUNKS + chunk)*2 + {0,1}] = partial sums of pos / neg ; combined in fixed order by k_loss_norm_final
 __global__ void __launch_bounds__(LOSS_THREADS) k_loss_norm(const float *__restrict__ pos, const float *__restrict__ neg,
-                                                            int64_t per_b, float *__restrict__ norm, int B) {
-    const int b = blockIdx.x;
-    float sp = 0.f, sn = 0.f;   // sums of 0/1 indicators: exact in fp32 far beyond these sizes
-    for (int64_t i = threadIdx.x; i < per_b; i += LOSS_THREADS) {
+                                                            int64_t per_b, float *__restrict__ part) {
+    const int b = blockIdx.x / NORM_CHUNKS, chunk = blockIdx.x % NORM_CHUNKS;
+    float sp = 0.f, sn = 0.f;
+    for (int64_t i = (int64_t)chunk * LOSS_THREADS + threadIdx.x; i < per_b; i += (int64_t)NORM_CHUNKS * LOSS_THREADS) {
         sp += pos[(int64_t)b * per_b + i];
         sn += neg[(int64_t)b * per_b + i];
     }
@@ -30,6 +33,16 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss_norm(const float *__restr
     if (threadIdx.x == 0) {
         float a = 0.f, c = 0.f;
         for (int w = 0; w < LOSS_THREADS / 64; ++w) { a += red[0][w]; c += red[1][w]; }
+        part[(int64_t)blockIdx.x * 2] = a;
+        part[(int64_t)blockIdx.x * 2 + 1] = c;
+    }
+}
+
+__global__ void __launch_bounds__(64) k_loss_norm_final(const float *__restrict__ part, float *__restrict__ norm, int B) {
+    const int b = blockIdx.x, lane = threadIdx.x;   // NORM_CHUNKS == 64 == one wave
+    const float a = vn_wave_sum(part[((int64_t)b * NORM_CHUNKS + lane) * 2]);
+    const float c = vn_wave_sum(part[((int64_t)b * NORM_CHUNKS + lane) * 2 + 1]);
+    if (lane == 0) {
         norm[b] = fmaxf(a, 1.f);
         norm[B + b] = fmaxf(c, 1.f);
     }
@@ -142,7 +155,8 @@ bool loss_args_ok(int32_t B, int32_t H, int32_t W) { return B > 0 && H > 0 && W 
 extern "C" size_t vn_rpn_loss_workspace_bytes(int32_t B, int32_t H, int32_t W) {
     if (!loss_args_ok(B, H, W)) return 0;
     const int64_t blocks = vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
-    return vn_align(sizeof(float) * 2 * (size_t)B) + vn_align(sizeof(float) * 3 * (size_t)blocks);
+    size_t slab = sizeof(float) * 3 * (size_t)blocks, part = sizeof(float) * 2 * NORM_CHUNKS * (size_t)B;
+    return vn_align(sizeof(float) * 2 * (size_t)B) + vn_align(slab > part ? slab : part);
 }
 
 extern "C" int vn_rpn_loss_fwd(const float *prob, const float *delta, const float *pos, const float *neg,
@@ -154,7 +168,9 @@ extern "C" int vn_rpn_loss_fwd(const float *prob, const float *delta, const floa
     float *norm = static_cast<float *>(workspace);
     float *slab = reinterpret_cast<float *>(static_cast<char *>(workspace) + vn_align(sizeof(float) * 2 * (size_t)B));
     const int blocks = (int)vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
-    k_loss_norm<<<B, LOSS_THREADS, 0, st>>>(pos, neg, (int64_t)H * W * 2, norm, B);
+    k_loss_norm<<<B * NORM_CHUNKS, LOSS_THREADS, 0, st>>>(pos, neg, (int64_t)H * W * 2, slab);   // slab: scratch here
+    VN_LAUNCH_STATUS();
+    k_loss_norm_final<<<B, 64, 0, st>>>(slab, norm, B);
     VN_LAUNCH_STATUS();
     const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
     k_loss<false><<<blocks, LOSS_THREADS, 0, st>>>(prob, delta, pos, neg, targets, norm, g, slab, nullptr, nullptr, nullptr);

@@ -86,9 +86,10 @@ SIGNATURES = {
                                 c_vp, c_sz, _P(VnLayerGrads), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
     "vn_conv_stats_slab_rows": (c_i64, [_P(VnConv)]),
     "vn_bn_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
-    "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp]),
+    "vn_conv_wgrad_workspace_bytes": (c_sz, [_P(VnConv), c_i32, c_i64]),
+    "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_sz, c_vp]),
     "vn_conv_gather_gemm_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
-    "vn_conv_wgrad_rows": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_vp, c_i64, c_vp]),
+    "vn_conv_wgrad_rows": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_vp, c_i64, c_vp, c_sz, c_vp]),
     "vn_active_sites_workspace_bytes": (c_sz, [_P(VnConv)]),
     "vn_active_sites": (c_i32, [c_vp, c_i64, _P(VnConv), c_vp, c_sz, c_vp, c_i64, c_vp, c_vp]),
     "vn_fill_rows": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_vp]),

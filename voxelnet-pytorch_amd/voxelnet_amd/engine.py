@@ -293,6 +293,13 @@ def layer_forward(spec, x, params, buffers, training, mode, out=None, y_dtype=No
     return a, st
 
 
+def wgrad_workspace(g, split, n_rows, dev):
+    """partial-sum slab of vn_conv_wgrad (row chunks are summed in a fixed order: no atomics)"""
+    nbytes = _lib.load().vn_conv_wgrad_workspace_bytes(ctypes.byref(g), int(split), int(n_rows))
+    ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+    return ws, nbytes
+
+
 def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=False, bev_da=False):
     """da: Rows-like gradient w.r.t. the layer output activation (plain rows, f32 or bf16,
     any row stride) — or, for a layer without BN, w.r.t. the conv output as [hi|lo] Rows.
@@ -348,16 +355,20 @@ def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=Fa
         dwp = torch.zeros((taps, spec.cin, spec.cout), dtype=torch.float32, device=dev)
         g = _geom(B, dy, st.in_dims, spec.cout, 0, spec.cin, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1),
                   x.strides)
+        ws, ws_bytes = wgrad_workspace(g, split, 0, dev)
         with _timed("k_wgrad", 2.0 * x.M * spec.cin * spec.cout * taps):
-            _lib.call("vn_conv_wgrad", dy.ptr(), x.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), stream())
+            _lib.call("vn_conv_wgrad", dy.ptr(), x.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), ws.data_ptr(),
+                      ws_bytes, stream())
         dw = torch.empty_like(params["weight"])
         _lib.call("vn_unpack_wgrad", dwp.data_ptr(), spec.cin, spec.cout, taps, 0, 1, dw.data_ptr(), stream())
     else:
         dwp = torch.zeros((taps, spec.cout, spec.cin), dtype=torch.float32, device=dev)
         g = _geom(B, x, st.out_dims, spec.cin, 0, spec.cout, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1),
                   dy.strides)
+        ws, ws_bytes = wgrad_workspace(g, split, 0, dev)
         with _timed("k_wgrad", 2.0 * dy.M * spec.cin * spec.cout * taps):
-            _lib.call("vn_conv_wgrad", x.ptr(), dy.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), stream())
+            _lib.call("vn_conv_wgrad", x.ptr(), dy.ptr(), dwp.data_ptr(), ctypes.byref(g), int(split), ws.data_ptr(),
+                      ws_bytes, stream())
         dw = torch.empty_like(params["weight"])
         _lib.call("vn_unpack_wgrad", dwp.data_ptr(), spec.cout, spec.cin, taps, 0, spec.cin_fold, dw.data_ptr(),
                   stream())
@@ -461,9 +472,10 @@ def first_layer_backward_sparse(st, da, params, mode, coord, vw_rows):
     g = _geom(B, dy, st.in_dims, C, 0, spec.cin, spec.k, (1, 1, 1), (-1, -1, -1), neg_pad, spec.stride,
               (0, 0, 0, vw_rows.shape[1]))
     dwp = torch.zeros((taps, spec.cin, C), dtype=torch.float32, device=dev)
+    ws, ws_bytes = wgrad_workspace(g, 0, K, dev)
     with _timed("k_wgrad_rows", 2.0 * K * spec.cin * C * taps):
         _lib.call("vn_conv_wgrad_rows", dy.ptr(), vw_rows.data_ptr(), dwp.data_ptr(), ctypes.byref(g),
-                  coord.data_ptr(), K, stream())
+                  coord.data_ptr(), K, ws.data_ptr(), ws_bytes, stream())
     dw = torch.empty_like(params["weight"])
     _lib.call("vn_unpack_wgrad", dwp.data_ptr(), spec.cin, C, taps, 2, 1, dw.data_ptr(), stream())
     grads["weight"] = dw
