@@ -42,7 +42,7 @@ for name in names:
     else:
         a = (sp.stride, (1, 1, 1), sp.pad, (1, 1, 1))
         b = ((1, 1, 1), (-1, -1, -1), tuple(-p for p in sp.pad), sp.stride)
-    slab = torch.empty((-(-y.M // 64), 2, sp.cout), device=dev) if not sp.transposed else None
+    slab = torch.empty((-(-y.M // 32), 2, sp.cout), device=dev) if not sp.transposed else None
     t_f = timeit(lambda: E.gather_gemm(x, wp, bias, y, sp.k, sp.cin, sp.cout, *a, od, stats=slab))
     dx = E.Rows(torch.empty((B,) + dims + (sp.cin,), dtype=torch.bfloat16, device=dev), sp.cin)
     dy = E.Rows(torch.randn((B,) + od + (sp.cout,), device=dev).to(torch.bfloat16), sp.cout)

@@ -84,6 +84,88 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
+// Store one workgroup's accumulators (+bias, optional accumulate) through the per-row offset table otab (LDS, -1 =
+// row not stored) and, if asked, its per-channel sum / sum of squares into stats slab row `tile`.
+template <int WM, int WN, int SM>
+__device__ __forceinline__ void gg_store(const GGParams &p, f32x4_t (&acc)[SM][4], char *smem, const int32_t *otab, int64_t tile,
+                                         int n0, int wm, int wn, int lane) {
+    constexpr int BN = 64 * WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int64_t tile_m = tile;
+    const int ncol = n0 + wn * 64 + fr * 4;   // this lane's 4 consecutive output channels
+    const bool col_ok = ncol < p.N;
+    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && col_ok) {
+        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + ncol);
+        bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
+    }
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+        const int4 offs = *reinterpret_cast<const int4 *>(otab + wm * (16 * SM) + i * 16 + fq * 4);
+        const int32_t o4[4] = {offs.x, offs.y, offs.z, offs.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (o4[e] < 0 || !col_ok) continue;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float a = acc[i][j][e];
+                s1[j] += a;
+                s2[j] += a * a;
+                v[j] = a + bias4[j];
+            }
+            if (p.out_f32) {
+                float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + (int64_t)o4[e] + ncol);
+                if (p.accumulate) {
+                    const float4 old = *dst;
+                    v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+                }
+                *dst = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                bf16x4_t *dst = reinterpret_cast<bf16x4_t *>(reinterpret_cast<bf16_t *>(p.out) + (int64_t)o4[e] + ncol);
+                if (p.accumulate) {
+                    const bf16x4_t old = *dst;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
+                }
+                bf16x4_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
+                *dst = o;
+            }
+        }
+    }
+    if (p.stats) {
+        // per-workgroup partial sums -> slab[tile_m][2][N] (plain stores, no atomics: thousands of waves adding
+        // into the same 2N addresses serialise at the memory side; vn_bn_finalize reduces the slab in double)
+        __syncthreads();                                  // otab reads done; reuse LDS
+        float *red = reinterpret_cast<float *>(smem);     // [2][BN] per M-wave group
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s1[j] += __shfl_xor(s1[j], 16, 64);
+            s1[j] += __shfl_xor(s1[j], 32, 64);
+            s2[j] += __shfl_xor(s2[j], 16, 64);
+            s2[j] += __shfl_xor(s2[j], 32, 64);
+        }
+        if (fq == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                red[(wm * 2 + 0) * BN + wn * 64 + fr * 4 + j] = s1[j];
+                red[(wm * 2 + 1) * BN + wn * 64 + fr * 4 + j] = s2[j];
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+            const int which = i / BN, c = i - which * BN;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BN + c];
+            if (n0 + c < p.N) p.stats[((int64_t)tile_m * 2 + which) * p.N + n0 + c] = v;
+        }
+    }
+}
+
 // WM x WN waves, each owning a (16*SM) x 64 sub-tile; NS LDS stages (the loads run NS-1 steps ahead of the MFMAs:
 // the small late layers — 4400 rows x 2304 K — are latency-bound, not bandwidth-bound, and want a deep pipeline)
 template <int WM, int WN, int SM, int NS, bool F32>
@@ -374,78 +456,203 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     }
     __syncthreads();
 
-    const int ncol = n0 + wn * 64 + fr * 4;   // this lane's 4 consecutive output channels
-    const bool col_ok = ncol < p.N;
-    float bias4[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && col_ok) {
-        const float4 bv = *reinterpret_cast<const float4 *>(p.bias + ncol);
-        bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
+    gg_store<WM, WN, SM>(p, acc, smem, otab, tile_m, n0, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// 3x3 (x kD), stride-1-in-H/W convolutions with the im2col done INSIDE LDS ("patch" kernel).
+// In k_gather_gemm every tap re-stages its A rows: 9 (27) x the source bytes through LDS-DMA, and the step time of
+// that kernel is the DMA issue time (measured by an s_memtime trace: ~110-130 clk per 1-KiB piece and wave, not
+// overlappable with the same wave's MFMAs).  Here a workgroup owns a TH x TW rectangle of output pixels of one
+// (batch, depth) plane; per source plane and K chunk it stages the (TH+2) x (TW+2) halo patch ONCE and the nine
+// (kh,kw) taps read their A fragments from it with shifted LDS row addresses.  Image borders are patch rows that
+// were never in range: LDS-DMA wrote zeros there.  Only the 64-row weight tile is staged per tap.
+// A pieces per tap step: (TH+2)(TW+2)/(8*9*4) per wave (~0.8) instead of BM/32 (5-8).
+template <int WM, int WN, int SM, int TW, bool F32>
+__global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
+    constexpr int ESZ = F32 ? 4 : 2;
+    constexpr int BM = 16 * SM * WM, BN = 64 * WN, TH = BM / TW;
+    static_assert(WM * WN == 4 && BM % TW == 0, "4 waves; whole patch lines");
+    constexpr int PW = TW + 2, PH = TH + 2, PROWS = PH * PW;
+    constexpr int PPIECES = (PROWS + 7) / 8;                 // 1-KiB pieces of the patch
+    constexpr int PA = (PPIECES + 3) / 4;                    // per wave
+    constexpr int PATCH_BYTES = PA * 4 * 1024;
+    constexpr int RB = BN / 32;                              // weight pieces per wave and tap
+    constexpr int B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *patch = smem;
+    char *bst = smem + PATCH_BYTES;                          // two weight stages
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const GGClass &cl = p.cls[blockIdx.y];
+    const int ntn = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     }
-    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tile = bid / ntn, tile_n = bid - tile * ntn;
+    const int n0 = tile_n * BN;
+    const int tiles_x = (cl.qW + TW - 1) / TW, tiles_y = (cl.qH + TH - 1) / TH;
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int qd = t % cl.qD;
+    const int b = t / cl.qD;
+    if (b >= p.B) return;                                    // (a residue class with fewer planes than the largest)
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- loader state: patch rows of this lane (fixed over the planes and K chunks) and its weight rows
+    const int a_chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    uint32_t a_row[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int q = (i * 4 + wave) * 8 + (lane >> 3);       // patch row
+        const int qy = q / PW, qx = q - qy * PW;
+        const int sy = y0 - 1 + qy, sx = x0 - 1 + qx;          // H/W: stride 1, offsets -1..1 (checked on the host)
+        a_row[i] = (q < PROWS && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+                       ? (uint32_t)(((int64_t)sy * p.sH + (int64_t)sx * p.sW) * ESZ)
+                       : GG_OOB;
+    }
+    uint32_t b_row[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int rho = (i * 4 + wave) * 8 + (lane >> 3);
+        const int rl = rho & 63;
+        const int n = n0 + (rho & ~63) + (rl & 15) * 4 + (rl >> 4);
+        b_row[i] = n < p.N ? (uint32_t)((int64_t)n * p.Cs * ESZ) : GG_OOB;
+    }
+    const char *src_base = p.src + (int64_t)b * p.sB * ESZ;
+    int64_t src_bytes = p.src_batch_extent * ESZ;
+    if (src_bytes > (int64_t)GG_MAX_WINDOW) src_bytes = GG_MAX_WINDOW;
+    const __amdgpu_buffer_rsrc_t rs_a = vn_uniform_rsrc(src_base, (uint32_t)src_bytes);
+    const __amdgpu_buffer_rsrc_t rs_b = vn_uniform_rsrc(p.w, p.w_bytes);
+    constexpr int BKE = 128 / ESZ, EPC = 16 / ESZ;
+    const int nk = (p.Cs + BKE - 1) / BKE;
+    const int k_lane0 = a_chunk * EPC;
+
+    // ---- fragment geometry: MFMA row (lane & 15) of sub-tile i is output pixel (py, px) -> patch row of tap (0,0)
+    const int fr = lane & 15, fq = lane >> 4;
+    int q0[SM];
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
-        const int4 offs = *reinterpret_cast<const int4 *>(otab + wm * (16 * SM) + i * 16 + fq * 4);
-        const int32_t o4[4] = {offs.x, offs.y, offs.z, offs.w};
+        const int r = wm * (16 * SM) + i * 16 + fr;
+        const int py = r / TW, px = r - py * TW;
+        q0[i] = (py + 1) * PW + (px + 1);
+    }
+    const int bfrag0 = fr * 128 + (((0 + fq) ^ (fr >> 1)) << 4);
+    const int bfrag1 = fr * 128 + (((4 + fq) ^ (fr >> 1)) << 4);
+
+    f32x4_t acc[SM][4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (o4[e] < 0 || !col_ok) continue;
-            float v[4];
+    for (int i = 0; i < SM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float a = acc[i][j][e];
-                s1[j] += a;
-                s2[j] += a * a;
-                v[j] = a + bias4[j];
-            }
-            if (p.out_f32) {
-                float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + (int64_t)o4[e] + ncol);
-                if (p.accumulate) {
-                    const float4 old = *dst;
-                    v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    auto stage_b = [&](int id, int ih, int iw, int kc, int buf) {
+        const GGTap tp = p.taps[cl.tap_begin + (id * cl.nH + ih) * cl.nW + iw];
+        const int k_lane = kc * BKE + k_lane0;
+        const bool k_ok = k_lane < p.Cs;
+        const uint32_t b_koff = (uint32_t)k_lane * (uint32_t)ESZ;
+        const uint32_t b_soff = __builtin_amdgcn_readfirstlane((uint32_t)((int64_t)tp.widx * p.N * p.Cs * ESZ));
+        char *lb = bst + buf * B_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            lds_dma16(rs_b, lb + i * 4096, (k_ok && b_row[i] != GG_OOB) ? b_row[i] + b_koff : GG_OOB, b_soff);
+    };
+    auto stage_patch = [&](int sd, int kc) {
+        const int k_lane = kc * BKE + k_lane0;
+        const bool k_ok = k_lane < p.Cs;
+        const int k_src = (p.src_wrap > 0 && k_lane >= p.src_wrap) ? k_lane - p.src_wrap : k_lane;
+        const uint32_t off = (uint32_t)(((int64_t)sd * p.sD + k_src) * ESZ);
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            lds_dma16(rs_a, patch + (i * 4 + wave) * 1024, (k_ok && a_row[i] != GG_OOB) ? a_row[i] + off : GG_OOB, 0);
+    };
+
+    int bbuf = 0;
+    bool first = true;
+    for (int id = 0; id < cl.nD; ++id) {
+        const int sd = qd * p.mulD + cl.offD[id];
+        if ((unsigned)sd >= (unsigned)p.Ds) continue;          // a padding plane: block-uniform skip
+        for (int kc = 0; kc < nk; ++kc) {
+            // everyone is done with the previous patch (and the weight stage the first tap's loads go to)
+            __syncthreads();
+            stage_patch(sd, kc);
+            if (first) { stage_b(id, 0, 0, kc, bbuf); first = false; }
+            for (int tap = 0; tap < 9; ++tap) {
+                const int ih = tap / 3, iw = tap - ih * 3;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                // next weight tile: next tap, or the first tap of the next (plane, chunk)
+                if (tap < 8) {
+                    stage_b(id, (tap + 1) / 3, (tap + 1) % 3, kc, bbuf ^ 1);
+                } else {
+                    int nid = id, nkc = kc + 1;
+                    if (nkc == nk) {
+                        nkc = 0;
+                        for (nid = id + 1; nid < cl.nD; ++nid)
+                            if ((unsigned)(qd * p.mulD + cl.offD[nid]) < (unsigned)p.Ds) break;
+                    }
+                    if (nid < cl.nD) stage_b(nid, 0, 0, nkc, bbuf ^ 1);
                 }
-                *dst = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                bf16x4_t *dst = reinterpret_cast<bf16x4_t *>(reinterpret_cast<bf16_t *>(p.out) + (int64_t)o4[e] + ncol);
-                if (p.accumulate) {
-                    const bf16x4_t old = *dst;
+                const int shift = cl.offH[ih] * PW + cl.offW[iw];
+                const char *lb = bst + bbuf * B_BYTES + wn * (64 * 128);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)old[j];
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int fo = ks ? bfrag1 : bfrag0;
+                    if constexpr (F32) {
+                        f32x4_t bq[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + fo);
+#pragma unroll
+                        for (int i = 0; i < SM; ++i) {
+                            const int q = q0[i] + shift;
+                            const f32x4_t a = *reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((ks * 4 + fq) ^ ((q >> 1) & 7)) << 4));
+#pragma unroll
+                            for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t4], bq[j][t4], acc[i][j], 0, 0, 0);
+                        }
+                    } else {
+                        bf16x8_t bq[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bf16x8_t *>(lb + j * 2048 + fo);
+#pragma unroll
+                        for (int i = 0; i < SM; ++i) {
+                            const int q = q0[i] + shift;
+                            const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((ks * 4 + fq) ^ ((q >> 1) & 7)) << 4));
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[j], acc[i][j], 0, 0, 0);
+                        }
+                    }
                 }
-                bf16x4_t o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (bf16_t)v[j];
-                *dst = o;
+                bbuf ^= 1;
             }
         }
     }
-    if (p.stats) {
-        // per-workgroup partial sums -> slab[tile_m][2][N] (plain stores, no atomics: thousands of waves adding
-        // into the same 2N addresses serialise at the memory side; vn_bn_finalize reduces the slab in double)
-        __syncthreads();                                  // otab reads done; reuse LDS
-        float *red = reinterpret_cast<float *>(smem);     // [2][BN] per M-wave group
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s1[j] += __shfl_xor(s1[j], 16, 64);
-            s1[j] += __shfl_xor(s1[j], 32, 64);
-            s2[j] += __shfl_xor(s2[j], 16, 64);
-            s2[j] += __shfl_xor(s2[j], 32, 64);
+
+    // ---- epilogue: row -> output offset table, then the shared store / statistics code
+    __syncthreads();
+    int32_t *otab = reinterpret_cast<int32_t *>(smem);
+    for (int r = threadIdx.x; r < BM; r += 256) {
+        const int py = r / TW, px = r - py * TW;
+        const int qh = y0 + py, qw = x0 + px;
+        int32_t off = -1;
+        if (qh < cl.qH && qw < cl.qW) {
+            const int od = qd * p.omulD + cl.ooffD, oh = qh * p.omulH + cl.ooffH, ow = qw * p.omulW + cl.ooffW;
+            if (od < p.Do && oh < p.Ho && ow < p.Wo)
+                off = (int32_t)((int64_t)b * p.oB + (int64_t)od * p.oD + (int64_t)oh * p.oH + (int64_t)ow * p.oW);
         }
-        if (fq == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                red[(wm * 2 + 0) * BN + wn * 64 + fr * 4 + j] = s1[j];
-                red[(wm * 2 + 1) * BN + wn * 64 + fr * 4 + j] = s2[j];
-            }
-        }
-        __syncthreads();
-        for (int i = threadIdx.x; i < 2 * BN; i += 256) {
-            const int which = i / BN, c = i - which * BN;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BN + c];
-            if (n0 + c < p.N) p.stats[((int64_t)tile_m * 2 + which) * p.N + n0 + c] = v;
-        }
+        otab[r] = off;
     }
+    __syncthreads();
+    gg_store<WM, WN, SM>(p, acc, smem, otab, tile, n0, wm, wn, lane);
 }
 
 inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -522,6 +729,50 @@ GGConfig gg_config(int64_t rows, int Cr, int ncls) {
     if (b1 < 100) return GG_CFG[2];              // a handful of long-K tiles: smaller tiles, 4-stage pipeline
     const int64_t t1 = vn_ceil_div(b1, 512) * 128, t4 = vn_ceil_div(b4, 512) * 160;
     return t4 < t1 ? GG_CFG[4] : GG_CFG[1];
+}
+
+// ---- patch kernel (k_conv_patch) eligibility and tiling
+struct PatchCfg {
+    int id, BM, BN, TW;   // id < 0: not eligible
+};
+int patch_enabled() {     // tuning aid: VN_PATCH=0 keeps every layer on k_gather_gemm, 2 = also small images
+    static const int v = [] {
+        const char *e = getenv("VN_PATCH");
+        return e && *e ? atoi(e) : 1;
+    }();
+    return v;
+}
+PatchCfg patch_config(const vnConv *g) {
+    PatchCfg none{-1, 0, 0, 0};
+    if (!patch_enabled()) return none;
+    if (g->kH != 3 || g->kW != 3 || g->mulH != 1 || g->mulW != 1 || g->divH != 1 || g->divW != 1) return none;
+    // source offsets t*tmul - pad of the three taps must be {-1, 0, 1}
+    if (!((g->tmulH == 1 && g->padH == 1) || (g->tmulH == -1 && g->padH == -1))) return none;
+    if (!((g->tmulW == 1 && g->padW == 1) || (g->tmulW == -1 && g->padW == -1))) return none;
+    if (g->src_wrap != 0 || (g->Cr & 63)) return none;
+    // small images: too few tiles, k_gather_gemm's small configs win (VN_PATCH=2: take every eligible layer, for tests)
+    if (patch_enabled() < 2 && (g->Hr < 128 || g->Wr < 128)) return none;
+    if (g->Hs != g->Hr || g->Ws != g->Wr) return none;
+    if (g->Cr == 64) return PatchCfg{1, 256, 64, 32};        // 8 x 32 pixels
+    return PatchCfg{0, 160, 128, 16};                        // 10 x 16 pixels
+}
+int64_t patch_tiles(const PatchCfg &c, int B, int qD, int qH, int qW) {
+    const int TH = c.BM / c.TW;
+    return (int64_t)B * qD * vn_ceil_div(qH, TH) * vn_ceil_div(qW, c.TW);
+}
+template <int WM, int WN, int SM, int TW, bool F32>
+int launch_patch(const GGParams &p, dim3 grid, hipStream_t st) {
+    constexpr int BM = 16 * SM * WM, TH = BM / TW, PROWS = (TH + 2) * (TW + 2);
+    constexpr size_t lds = (size_t)((PROWS + 7) / 8 + 3) / 4 * 4096 + 2 * (size_t)(64 * WN) * 128;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch<WM, WN, SM, TW, F32>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return (int)attr;
+    k_conv_patch<WM, WN, SM, TW, F32><<<grid, 256, lds, st>>>(p);
+    return 0;
+}
+int launch_patch_cfg(const PatchCfg &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
+    if (c.id == 1) return f32 ? launch_patch<4, 1, 4, 32, true>(p, grid, st) : launch_patch<4, 1, 4, 32, false>(p, grid, st);
+    return f32 ? launch_patch<2, 2, 5, 16, true>(p, grid, st) : launch_patch<2, 2, 5, 16, false>(p, grid, st);
 }
 
 int launch_cfg(const GGConfig &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
@@ -644,6 +895,8 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
 
 extern "C" int64_t vn_conv_stats_slab_rows(const vnConv *g) {
     if (!g || g->divD != 1 || g->divH != 1 || g->divW != 1) return 0;
+    const PatchCfg pc = patch_config(g);
+    if (pc.id >= 0) return patch_tiles(pc, g->B, g->Dr, g->Hr, g->Wr);
     const int64_t rows = (int64_t)g->B * g->Dr * g->Hr * g->Wr;
     return vn_ceil_div(rows, gg_config(rows, g->Cr, 1).BM);
 }
@@ -733,6 +986,23 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
             }
     p.nclasses = ncls;
 
+    const PatchCfg pc = patch_config(g);
+    if (pc.id >= 0) {
+        // every class shares the H/W geometry (div 1 there); classes differ in depth only
+        int64_t tiles = 0;
+        for (int c = 0; c < ncls; ++c) {
+            const int64_t t = patch_tiles(pc, g->B, p.cls[c].qD, p.cls[c].qH, p.cls[c].qW);
+            if (t > tiles) tiles = t;
+        }
+        if (p.src_batch_extent * esz > (int64_t)GG_MAX_WINDOW - 4096) return VN_EUNSUPPORTED;
+        const int64_t nblk = tiles * vn_ceil_div(g->Cr, pc.BN);
+        if (nblk > 0x7fffffffll) return VN_EUNSUPPORTED;
+        const dim3 pgrid((unsigned)nblk, (unsigned)ncls);
+        const int prc = launch_patch_cfg(pc, f32, p, pgrid, vn_stream(stream));
+        if (prc) return prc;
+        VN_LAUNCH_STATUS();
+        return VN_OK;
+    }
     const GGConfig cfg = gg_config(max_rows, g->Cr, ncls);
     const int BM = cfg.BM, BN = cfg.BN;
     // the gather window of one workgroup: rows of at most (BM / rows_per_batch + 2) batch items

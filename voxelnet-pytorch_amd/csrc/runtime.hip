@@ -185,9 +185,9 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         P->slab_rows[l] = 0;
         P->slab[l] = nullptr;
         if (!sp.transposed) {
-            vnConv sg{};                       // the conv kernel picks its tile (= slab granularity) from these
-            sg.B = B; sg.Dr = P->odims[l][0]; sg.Hr = P->odims[l][1]; sg.Wr = P->odims[l][2]; sg.Cr = sp.cout;
-            sg.divD = sg.divH = sg.divW = 1;
+            // the conv kernel picks its tiling (= slab granularity) from the launch geometry
+            const Rows xin = dense_rows(nullptr, P->adt, B, P->in_dims[l][0], P->in_dims[l][1], P->in_dims[l][2], sp.cin);
+            const vnConv sg = fwd_geom(sp, xin, P->odims[l], P->y[l]);
             P->slab_rows[l] = vn_conv_stats_slab_rows(&sg);
             (void)M;
             P->slab[l] = (float *)A.take((size_t)P->slab_rows[l] * 2 * sp.cout * sizeof(float));

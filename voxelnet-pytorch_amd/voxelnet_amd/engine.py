@@ -201,13 +201,18 @@ def _timed(kernel, flops):
     return TIMER.time(kernel, flops) if TIMER is not None else _NoCtx()
 
 
-def gather_gemm(src, wp, bias, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dims, accumulate=False, stats=None):
-    """out rows <- gather-GEMM of src rows (vn_conv_gather_gemm)."""
+def gather_geometry(src, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dims):
+    """the vnConv of a gather-GEMM launch"""
     split = src.lo_off != 0
     if split:
         assert src.lo_off == src.C, "gather source must be [hi|lo] contiguous"
-    g = _geom(src.B, src, row_dims, Cs * (3 if split else 1), 2 * Cs if split else 0, Cr, spec_k, mul, tmul, pad,
-              div, out.strides)
+    return _geom(src.B, src, row_dims, Cs * (3 if split else 1), 2 * Cs if split else 0, Cr, spec_k, mul, tmul, pad,
+                 div, out.strides)
+
+
+def gather_gemm(src, wp, bias, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dims, accumulate=False, stats=None):
+    """out rows <- gather-GEMM of src rows (vn_conv_gather_gemm)."""
+    g = gather_geometry(src, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dims)
     rows = src.B * row_dims[0] * row_dims[1] * row_dims[2]
     # dense-equivalent model FLOPs of this launch (SURVEY.md §8d): 2*MACs; a residue-class gather visits
     # taps/prod(div) taps per row
@@ -248,10 +253,8 @@ def layer_forward(spec, x, params, buffers, training, mode, out=None, y_dtype=No
     else:
         mul, tmul, pad, div = spec.stride, (1, 1, 1), spec.pad, (1, 1, 1)
     if fuse_stats:
-        sg = _lib.VnConv()
-        sg.B, sg.Dr, sg.Hr, sg.Wr, sg.Cr = B, odims[0], odims[1], odims[2], spec.cout
-        sg.divD = sg.divH = sg.divW = 1
-        slab_rows = _lib.load().vn_conv_stats_slab_rows(ctypes.byref(sg))      # = M / the tile height the kernel picks
+        sg = gather_geometry(x, y, spec.k, spec.cin, spec.cout, mul, tmul, pad, div, odims)
+        slab_rows = _lib.load().vn_conv_stats_slab_rows(ctypes.byref(sg))      # one slab row per tile the kernel will use
         slab = torch.empty((slab_rows, 2, spec.cout), dtype=torch.float32, device=dev)
     gather_gemm(x, wp, bias, y, spec.k, spec.cin, spec.cout, mul, tmul, pad, div, odims, stats=slab)
     st = LayerState()
