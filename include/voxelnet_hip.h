@@ -185,6 +185,13 @@ size_t vn_conv_wgrad_workspace_bytes(const vnConv *geom, int32_t split, int64_t 
 int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16*/, float *dw_packed,
                   const vnConv *geom, int32_t split, void *workspace, size_t workspace_bytes,
                   vnStream stream);
+/* Same products, but the row-chunk partials are left in the workspace: chunk c at workspace + c * (taps*Cr*C) floats,
+ * *chunks (host) = their number.  vn_unpack_wgrads_batch sums them (vnUnpackJob.chunks) while it converts the layout,
+ * so a backward pass needs no per-layer reduction launch and no zeroed accumulator.  row_list != NULL: the
+ * row-list form (vn_conv_wgrad_rows' operands).  The workspace must hold vn_conv_wgrad_workspace_bytes. */
+int vn_conv_wgrad_partials(const void *src, const void *rows, const vnConv *geom, int32_t split,
+                           const int64_t *row_list, int64_t n_rows, void *workspace,
+                           size_t workspace_bytes, int32_t *chunks, vnStream stream);
 
 /* Row-list ("sparse rows") variants for the first middle layer, whose input grid is ~99 % empty:
  * the produced rows are an explicit list of (b,d,h,w) int64 coordinates instead of the dense
@@ -238,7 +245,8 @@ typedef struct vnUnpackJob {
     const float *dw_packed;
     float *dw;
     int32_t c_out, c_in, taps, mode, cin_fold;
-    int32_t pad_;
+    int32_t chunks;          /* > 1: dw = sum over c < chunks (in order) of dw_packed[c * chunk_stride + i] */
+    int64_t chunk_stride;    /* elements; the chunk partials of vn_conv_wgrad_partials */
 } vnUnpackJob;
 int vn_pack_weights_batch(const vnPackJob *jobs /* host array */, int32_t n, vnStream stream);
 int vn_unpack_wgrads_batch(const vnUnpackJob *jobs /* host array */, int32_t n, vnStream stream);

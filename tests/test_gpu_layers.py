@@ -225,3 +225,23 @@ def test_batched_pack_unpack_matches_single_calls():
     _lib.call("vn_unpack_wgrads_batch", ujobs, len(ucases), E.stream())
     for a, b in zip(us, ub):
         assert torch.equal(a, b)
+
+
+def test_unpack_sums_chunk_partials():
+    """vnUnpackJob.chunks: dw = sum over the row-chunk partials (vn_conv_wgrad_partials' layout), fixed order"""
+    from voxelnet_amd import _lib, engine as E
+    DEV = "cuda:0"
+    torch.manual_seed(6)
+    co, ci, taps, chunks = 128, 64, 9, 5
+    n = co * ci * taps
+    part = torch.randn(chunks, n, device=DEV)
+    out = torch.zeros(n, device=DEV)
+    jobs = (_lib.VnUnpackJob * 1)()
+    jobs[0] = _lib.VnUnpackJob(part.data_ptr(), out.data_ptr(), co, ci, taps, 0, 1, chunks, n)
+    _lib.call("vn_unpack_wgrads_batch", jobs, 1, E.stream())
+    ref = torch.zeros(n, device=DEV)
+    acc = part[0].clone()
+    for c in range(1, chunks):
+        acc = acc + part[c]
+    _lib.call("vn_unpack_wgrad", acc.data_ptr(), co, ci, taps, 0, 1, ref.data_ptr(), E.stream())
+    assert torch.equal(out, ref)

@@ -104,12 +104,22 @@ __global__ void __launch_bounds__(256) k_unpack_wgrads_batch(const UnpackJobs t)
     const int j = find_job(t.block_begin, t.n);
     const vnUnpackJob &q = t.job[j];
     const int nb = t.block_begin[j + 1] - t.block_begin[j], b = blockIdx.x - t.block_begin[j];
-    const int64_t total = (int64_t)q.taps * q.c_out * q.c_in;
-    for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < total; i += (int64_t)nb * 256) {
+    const int chunks = q.chunks > 1 ? q.chunks : 1;
+    const int64_t total4 = (int64_t)q.taps * q.c_out * q.c_in / 4;      // c_in % 4 == 0 (checked on the host)
+    for (int64_t i4 = (int64_t)b * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)nb * 256) {
+        const int64_t i = i4 * 4;
         const int k = (int)(i % q.c_in);
         const int n = (int)((i / q.c_in) % q.c_out);
         const int tap = (int)(i / ((int64_t)q.c_in * q.c_out));
-        q.dw[torch_index(q.mode, q.c_out, q.c_in, q.taps, tap, n, k, q.cin_fold)] = q.dw_packed[i];
+        float4 v = *reinterpret_cast<const float4 *>(q.dw_packed + i);
+        for (int c = 1; c < chunks; ++c) {                                // fixed order
+            const float4 u = *reinterpret_cast<const float4 *>(q.dw_packed + (int64_t)c * q.chunk_stride + i);
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d)
+            q.dw[torch_index(q.mode, q.c_out, q.c_in, q.taps, tap, n, k + d, q.cin_fold)] = e[d];
     }
 }
 
@@ -328,8 +338,10 @@ extern "C" int vn_unpack_wgrads_batch(const vnUnpackJob *jobs, int32_t n, vnStre
             const vnUnpackJob &q = jobs[base + j];
             VN_CHECK_ARG(q.dw_packed && q.dw && q.c_out > 0 && q.c_in > 0 && q.taps > 0 && (q.mode == 0 || q.mode == 2));
             VN_CHECK_ARG(q.cin_fold >= 1 && q.c_in % q.cin_fold == 0);
-            int64_t nb = vn_ceil_div((int64_t)q.taps * q.c_out * q.c_in, 256 * 8);
-            if (nb > 256) nb = 256;
+            VN_CHECK_ARG(q.chunks <= 1 || q.chunk_stride >= (int64_t)q.taps * q.c_out * q.c_in);
+            VN_CHECK_ARG((q.c_in & 3) == 0 && (q.chunk_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(q.dw_packed) & 15) == 0);
+            int64_t nb = vn_ceil_div((int64_t)q.taps * q.c_out * q.c_in, 256 * 4);   // one float4 per thread
+            if (nb > 2048) nb = 2048;
             t.job[j] = q;
             t.block_begin[j] = blocks;
             blocks += (int)nb;

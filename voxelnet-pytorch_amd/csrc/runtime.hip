@@ -85,10 +85,9 @@ struct Plan {
     float *bslab[NL]; int64_t bslab_rows[NL];
     float *coef[NL];
     Rows dy[NL], dx[NL];
-    float *dwp[NL];
-    void *wgws; size_t wgws_bytes;   // partial-sum slab of the weight-gradient kernel (largest layer)
+    float *dwp[NL]; size_t dwp_bytes[NL];   // row-chunk partials of the weight gradient (vn_conv_wgrad_partials)
     // heads
-    void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs;
+    void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes;
     // sparse first layer
     int64_t *alist; int32_t *acount; int64_t acap; void *aws; size_t aws_bytes;
     // zeroed regions
@@ -227,12 +226,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     }
     // ---- backward buffers
     P->zb_begin = base ? base + A.off : nullptr;
-    for (int l = 0; l < NL; ++l) {
-        const Spec &sp = P->spec[l];
-        P->bsums[l] = (double *)A.take(2 * 256 * sizeof(double));
-        P->dwp[l] = (float *)A.take((size_t)sp.k[0] * sp.k[1] * sp.k[2] * sp.cin * sp.cout * sizeof(float));
-    }
-    P->hdwp = (float *)A.take((size_t)16 * 768 * sizeof(float));
+    for (int l = 0; l < NL; ++l) P->bsums[l] = (double *)A.take(2 * 256 * sizeof(double));
     P->hcs = (float *)A.take(64 * sizeof(float));
     P->zb_end = base ? base + A.off : nullptr;
     for (int l = 0; l < NL; ++l) {
@@ -255,25 +249,25 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     if (!c->sparse_first) P->dx[0] = rows_new(P->pdt, P->in_dims[0], 128);
     P->d_rows = rows_new(P->adt, fm, 16);
     P->d_cat = rows_new(P->pdt, fm, 768);
-    {   // weight-gradient partial sums: the launches are stream-ordered, one slab of the largest size serves all
-        size_t need = 0;
+    {   // weight-gradient partials: one slab per layer, summed by the batched unpack at the end of a segment
         auto ask = [&](const int rd[3], int Cs, int Cr, const int k[3], int64_t n_rows) {
             vnConv q{};
             q.dtype = P->adt; q.B = B; q.Dr = rd[0]; q.Hr = rd[1]; q.Wr = rd[2]; q.Cs = Cs; q.Cr = Cr;
             q.kD = k[0]; q.kH = k[1]; q.kW = k[2];
-            const size_t b = vn_conv_wgrad_workspace_bytes(&q, 0, n_rows);
-            if (b > need) need = b;
+            return vn_conv_wgrad_workspace_bytes(&q, 0, n_rows);
         };
         for (int l = 0; l < NL; ++l) {
             const Spec &sp = P->spec[l];
-            if (l == 0 && c->sparse_first) ask(P->in_dims[0], sp.cout, sp.cin, sp.k, K > 0 ? K : 1);
-            else if (sp.transposed) ask(P->in_dims[l], sp.cout, sp.cin, sp.k, 0);
-            else ask(P->odims[l], sp.cin, sp.cout, sp.k, 0);
+            size_t b;
+            if (l == 0 && c->sparse_first) b = ask(P->in_dims[0], sp.cout, sp.cin, sp.k, K > 0 ? K : 1);
+            else if (sp.transposed) b = ask(P->in_dims[l], sp.cout, sp.cin, sp.k, 0);
+            else b = ask(P->odims[l], sp.cin, sp.cout, sp.k, 0);
+            P->dwp_bytes[l] = b;
+            P->dwp[l] = (float *)A.take(b);
         }
         const int k1[3] = {1, 1, 1};
-        ask(fm, 768, 16, k1, 0);
-        P->wgws_bytes = need;
-        P->wgws = A.take(need ? need : 16);
+        P->hdwp_bytes = ask(fm, 768, 16, k1, 0);
+        P->hdwp = (float *)A.take(P->hdwp_bytes);
     }
     P->bytes = A.off;
     return true;
@@ -407,8 +401,9 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         const int od[3] = {1, P.hf, P.wf};
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
-        RT(vn_conv_wgrad(P.cat.ptr, P.d_rows.ptr, P.hdwp, &gw, 0, P.wgws, P.wgws_bytes, stream));
-        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, 0};
+        int32_t hch = 1;
+        RT(vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, &gw, 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, stream));
+        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
         const int64_t os[4] = {P.d_cat.sB, P.d_cat.sD, P.d_cat.sH, P.d_cat.sW};
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
         RT(vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.pdt, &gd, 0, nullptr, stream));
@@ -474,13 +469,15 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                                P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, stream));
         }
         VN_HIP(hipMemsetAsync(G[l].bias, 0, C * sizeof(float), hs));   // bias before a train-mode BN: exactly 0
+        int32_t wch = 1;
+        const int64_t dw_elems = (int64_t)taps * sp.cin * sp.cout;
         const Rows x = input_of(l);
         const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
-            RT(vn_conv_wgrad_rows(dy.ptr, vw_rows, P.dwp[l], &gw, coord, K, P.wgws, P.wgws_bytes, stream));
-            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, 0};
+            RT(vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, stream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
             RT(vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr,
                                         stream));
             continue;
@@ -489,13 +486,13 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         if (sp.transposed) {
             const int64_t rs[4] = {x.sB, x.sD, x.sH, x.sW};
             vnConv gw = geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, rs);
-            RT(vn_conv_wgrad(dy.ptr, x.ptr, P.dwp[l], &gw, 0, P.wgws, P.wgws_bytes, stream));
-            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, 0};
+            RT(vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, stream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, wch, dw_elems};
         } else {
             const int64_t rs[4] = {dy.sB, dy.sD, dy.sH, dy.sW};
             vnConv gw = geom(x, P.odims[l], sp.cin, C, sp.k, sp.s, ONE, sp.p, ONE, rs);
-            RT(vn_conv_wgrad(x.ptr, dy.ptr, P.dwp[l], &gw, 0, P.wgws, P.wgws_bytes, stream));
-            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, 0};
+            RT(vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, stream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, wch, dw_elems};
         }
         // data gradient
         Rows dx = P.dx[l];

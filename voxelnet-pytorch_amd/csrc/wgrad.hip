@@ -340,7 +340,8 @@ int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
 }  // namespace
 
 static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
-                      const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes, vnStream stream);
+                      const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes, vnStream stream,
+                      int32_t *chunks_out = nullptr);
 
 // tiling of one weight-gradient problem (shared by the launcher and the workspace query)
 struct WGPlan {
@@ -379,12 +380,27 @@ extern "C" size_t vn_conv_wgrad_workspace_bytes(const vnConv *g, int32_t split, 
     if (g->kD < 1 || g->kH < 1 || g->kW < 1) return 0;
     const int64_t M = n_rows > 0 ? n_rows : (int64_t)g->B * g->Dr * g->Hr * g->Wr;
     const WGPlan w = wgrad_plan(g, split, M);
-    return w.chunks > 1 ? (size_t)w.chunks * (size_t)w.dw_elems * sizeof(float) : 0;
+    return (size_t)w.chunks * (size_t)w.dw_elems * sizeof(float);   // (>= one chunk: vn_conv_wgrad_partials always uses it)
 }
 
 extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
                              void *workspace, size_t workspace_bytes, vnStream stream) {
     return wgrad_impl(src, rows, dw_packed, g, split, nullptr, 0, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vn_conv_wgrad_partials(const void *src, const void *rows, const vnConv *g, int32_t split,
+                                      const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes,
+                                      int32_t *chunks, vnStream stream) {
+    VN_CHECK_ARG(chunks && workspace && (row_list || n_rows == 0));
+    if (row_list && n_rows == 0) {     // no rows: one all-zero partial
+        const size_t bytes = (size_t)g->kD * g->kH * g->kW * g->Cr * g->Cs * sizeof(float);
+        if (workspace_bytes < bytes) return VN_EWORKSPACE;
+        VN_HIP(hipMemsetAsync(workspace, 0, bytes, vn_stream(stream)));
+        *chunks = 1;
+        return VN_OK;
+    }
+    return wgrad_impl(src, rows, static_cast<float *>(workspace), g, row_list ? 0 : split, row_list, n_rows, workspace,
+                      workspace_bytes, stream, chunks);
 }
 
 extern "C" int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_packed, const vnConv *g,
@@ -396,7 +412,10 @@ extern "C" int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_p
 }
 
 static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
-                      const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes, vnStream stream) {
+                      const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes, vnStream stream,
+                      int32_t *chunks_out) {
+    const bool partial_only = chunks_out != nullptr;   // leave the chunk partials in the workspace, no reduction
+    if (partial_only) dw_packed = static_cast<float *>(workspace);
     VN_CHECK_ARG(src && rows && dw_packed && g);
     VN_CHECK_ARG(g->B > 0 && g->Ds > 0 && g->Hs > 0 && g->Ws > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0);
     VN_CHECK_ARG(g->kD >= 1 && g->kH >= 1 && g->kW >= 1 && g->kD * g->kH * g->kW <= 65535);
@@ -452,7 +471,11 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     if (rpc > (1 << 30)) return VN_EUNSUPPORTED;
     p.rows_per_chunk = (int32_t)rpc;
     chunks = vn_ceil_div(M, rpc);
-    p.part = chunks > 1 ? static_cast<float *>(workspace) : nullptr;
+    p.part = (chunks > 1 || partial_only) ? static_cast<float *>(workspace) : nullptr;
+    if (partial_only) {
+        if (!workspace || (int64_t)(workspace_bytes / ((size_t)w.dw_elems * sizeof(float))) < chunks) return VN_EWORKSPACE;
+        *chunks_out = (int32_t)chunks;
+    }
     p.part_stride = w.dw_elems;
     const dim3 grid((unsigned)chunks, (unsigned)groups, (unsigned)(tiles_n * tiles_k));
     hipStream_t st = vn_stream(stream);
@@ -470,7 +493,7 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
         else rc = launch_wgrad<2, 2, false, 1>(p, grid, st);
     }
     if (rc != VN_OK) return rc;
-    if (chunks > 1) {
+    if (chunks > 1 && !partial_only) {
         const int64_t n4 = w.dw_elems / 4;
         int64_t blocks = vn_ceil_div(n4, 256);
         if (blocks > 2048) blocks = 2048;

@@ -61,7 +61,8 @@ class VnPackJob(ctypes.Structure):
 
 
 class VnUnpackJob(ctypes.Structure):
-    _fields_ = [("dw_packed", c_vp), ("dw", c_vp)] + [(n, c_i32) for n in ("c_out", "c_in", "taps", "mode", "cin_fold", "pad_")]
+    _fields_ = [("dw_packed", c_vp), ("dw", c_vp)] + [(n, c_i32) for n in ("c_out", "c_in", "taps", "mode", "cin_fold", "chunks")] + \
+               [("chunk_stride", c_i64)]
 
 
 # name -> (restype, argtypes); mirrors include/voxelnet_hip.h one to one
@@ -89,6 +90,7 @@ SIGNATURES = {
     "vn_conv_wgrad_workspace_bytes": (c_sz, [_P(VnConv), c_i32, c_i64]),
     "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_sz, c_vp]),
     "vn_conv_gather_gemm_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
+    "vn_conv_wgrad_partials": (c_i32, [c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp]),
     "vn_conv_wgrad_rows": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_vp, c_i64, c_vp, c_sz, c_vp]),
     "vn_active_sites_workspace_bytes": (c_sz, [_P(VnConv)]),
     "vn_active_sites": (c_i32, [c_vp, c_i64, _P(VnConv), c_vp, c_sz, c_vp, c_i64, c_vp, c_vp]),
