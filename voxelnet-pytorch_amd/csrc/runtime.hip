@@ -124,6 +124,18 @@ vnConv fwd_geom(const Spec &sp, const Rows &x, const int od[3], const Rows &out)
     return geom(x, od, sp.cin, sp.cout, sp.k, sp.s, ONE, sp.p, ONE, os);
 }
 
+// weight-gradient launch geometry of layer l (dense form): x = the layer's input activation rows
+vnConv wgrad_geom(const Plan &P, int l, const Rows &x) {
+    const Spec &sp = P.spec[l];
+    const Rows &dy = P.dy[l];
+    if (sp.transposed) {
+        const int64_t rs[4] = {x.sB, x.sD, x.sH, x.sW};
+        return geom(dy, P.in_dims[l], sp.cout, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, rs);
+    }
+    const int64_t rs[4] = {dy.sB, dy.sD, dy.sH, dy.sW};
+    return geom(x, P.odims[l], sp.cin, sp.cout, sp.k, sp.s, ONE, sp.p, ONE, rs);
+}
+
 bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     if (!c || c->B <= 0 || c->D != 10 || c->H <= 0 || c->W <= 0 || (c->H & 7) || (c->W & 7)) return false;
     if (c->mode != 0 && c->mode != 1) return false;
@@ -259,9 +271,13 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         for (int l = 0; l < NL; ++l) {
             const Spec &sp = P->spec[l];
             size_t b;
-            if (l == 0 && c->sparse_first) b = ask(P->in_dims[0], sp.cout, sp.cin, sp.k, K > 0 ? K : 1);
-            else if (sp.transposed) b = ask(P->in_dims[l], sp.cout, sp.cin, sp.k, 0);
-            else b = ask(P->odims[l], sp.cin, sp.cout, sp.k, 0);
+            if (l == 0 && c->sparse_first) {
+                b = ask(P->in_dims[0], sp.cout, sp.cin, sp.k, K > 0 ? K : 1);
+            } else {   // the real launch geometry: the kernel variant (and its chunking) is chosen from it
+                const Rows xin = dense_rows(nullptr, P->adt, B, P->in_dims[l][0], P->in_dims[l][1], P->in_dims[l][2], sp.cin);
+                const vnConv gw = wgrad_geom(*P, l, xin);
+                b = vn_conv_wgrad_workspace_bytes(&gw, 0, 0);
+            }
             P->dwp_bytes[l] = b;
             P->dwp[l] = (float *)A.take(b);
         }
@@ -483,14 +499,11 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
             continue;
         }
         // weight gradient
+        const vnConv gw = wgrad_geom(P, l, x);
         if (sp.transposed) {
-            const int64_t rs[4] = {x.sB, x.sD, x.sH, x.sW};
-            vnConv gw = geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, rs);
             RT(vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, stream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, wch, dw_elems};
         } else {
-            const int64_t rs[4] = {dy.sB, dy.sD, dy.sH, dy.sW};
-            vnConv gw = geom(x, P.odims[l], sp.cin, C, sp.k, sp.s, ONE, sp.p, ONE, rs);
             RT(vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, stream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, wch, dw_elems};
         }

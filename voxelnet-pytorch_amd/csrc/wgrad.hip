@@ -324,6 +324,181 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of 3x3 (x kD), stride-1-in-H/W convolutions with the shifted source rows read from an LDS halo
+// patch ("patch" form, cf. k_conv_patch): a stage is a 4 x 16 rectangle of sites of one (batch, depth) plane — its
+// 64 `rows` vectors and the 6 x 18 source patch around it — and all nine (kh,kw) taps of one kd are accumulated
+// from it.  DMA pieces per stage: (64 + 108)/32 per wave for 72 MFMAs per wave, against 8 pieces for 24 MFMAs in
+// the three-tap row form above, whose step time is the DMA issue time.  Zero padding = patch rows that were out of
+// range (LDS-DMA wrote zeros).  bf16, 64 x 64 channel tiles, 2 x 2 waves of 32 x 32.
+struct WPParams {
+    const char *src, *rows;
+    float *part;                 // chunk partials: part + chunk * part_stride
+    int64_t part_stride;
+    int64_t sB, sD, sH, sW, rB, rD, rH, rW;   // elements
+    int32_t B, Ds, Hs, Ws, Dr, Hr, Wr;
+    int32_t mulD, padD, kD;      // source plane = d * mulD + kd - padD
+    int32_t C, N, tiles_k;
+    int32_t tiles_x, tiles_y;    // 4 x 16 tiles per plane
+    int32_t tiles_per_chunk;
+    uint32_t src_bytes, rows_bytes;
+};
+
+__global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
+    // LDS patch: 6 lines of 32 rows (18 used: 16 sites + halo) x 128 B.  The line pitch of 32 rows keeps the bank
+    // swizzle (a function of row bits 1 and 3) independent of the line, so a tap shift (th lines, tw rows) changes a
+    // lane's read address by a compile-time immediate (th) plus one of three precomputed per-lane offsets (tw): the
+    // 72 transposed reads of a stage need no address arithmetic.
+    constexpr int TH = 4, TW = 16, PH = TH + 2, LP = 32;      // 64 sites
+    constexpr int RB = 128;                                  // LDS row bytes: 64 bf16 channels
+    constexpr int TILE_N = 64 * RB;                          // 8 KiB
+    constexpr int PATCH = PH * LP * RB;                      // 24 KiB (6 x 18 rows of it loaded)
+    constexpr int STAGE = TILE_N + PATCH;
+    constexpr int IN = TILE_N / 4096;                        // DMA instructions per wave: rows tile (2)
+    constexpr int NPP = PH * 3;                              // patch pieces: 3 per line (rows 0-7, 8-15, 16-23)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wn = wave >> 1, wk = wave & 1;
+    const int tile = blockIdx.z;
+    const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
+    const int n0 = tn * 64, k0 = tk * 64;
+    const int kd = blockIdx.y;
+    const int64_t ntiles = (int64_t)p.B * p.Dr * p.tiles_y * p.tiles_x;
+    const int64_t tbeg = (int64_t)blockIdx.x * p.tiles_per_chunk;
+    int64_t tend = tbeg + p.tiles_per_chunk;
+    if (tend > ntiles) tend = ntiles;
+    const int nst = (int)(tend - tbeg);                      // >= 1 by the grid size
+
+    const __amdgpu_buffer_rsrc_t rs_s = vn_uniform_rsrc(p.src, p.src_bytes);
+    const __amdgpu_buffer_rsrc_t rs_r = vn_uniform_rsrc(p.rows, p.rows_bytes);
+    const uint32_t s_col = (uint32_t)(k0 * 2), r_col = (uint32_t)(n0 * 2);
+
+    // stage = spatial tile tbeg + s
+    auto stage = [&](int sidx, int buf) {
+        int64_t t = tbeg + sidx;
+        const int tx = (int)(t % p.tiles_x); t /= p.tiles_x;
+        const int ty = (int)(t % p.tiles_y); t /= p.tiles_y;
+        const int d = (int)(t % p.Dr);
+        const int b = (int)(t / p.Dr);
+        const int y0 = ty * TH, x0 = tx * TW;
+        const int sd = d * p.mulD + kd - p.padD;
+        const bool plane_ok = (unsigned)sd < (unsigned)p.Ds;  // block-uniform
+        char *ln = smem + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < IN; ++i) {
+            const int r = (i * 4 + wave) * 8 + lane / 8;                     // site 0..63
+            const int c = (lane % 8) ^ chunk_swz<RB, false>(r);
+            const int oy = y0 + (r >> 4), ox = x0 + (r & 15);
+            const bool ok = plane_ok && oy < p.Hr && ox < p.Wr && (n0 + c * 8) < p.N;
+            const uint32_t ro = (uint32_t)(((int64_t)b * p.rB + (int64_t)d * p.rD + (int64_t)oy * p.rH + (int64_t)ox * p.rW) * 2);
+            lds_dma16(rs_r, ln + i * 4096, ok ? ro + (uint32_t)c * 16u : WG_OOB, r_col);
+        }
+        char *lp = smem + buf * STAGE + TILE_N;
+#pragma unroll
+        for (int i = 0; i < (NPP + 3) / 4; ++i) {
+            const int piece = i * 4 + wave;
+            if (piece >= NPP) break;
+            const int ql = piece / 3, cg = piece - ql * 3;
+            const int qx = cg * 8 + lane / 8;                                // column inside the line (0..23; 18.. unused)
+            const int prow = ql * LP + qx;
+            const int c = (lane % 8) ^ chunk_swz<RB, false>(prow);
+            const int sy = y0 - 1 + ql, sx = x0 - 1 + qx;
+            const bool ok = plane_ok && qx < TW + 2 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws &&
+                            (k0 + c * 8) < p.C;
+            const uint32_t so = (uint32_t)(((int64_t)b * p.sB + (int64_t)sd * p.sD + (int64_t)sy * p.sH + (int64_t)sx * p.sW) * 2);
+            lds_dma16(rs_s, lp + (ql * LP + cg * 8) * RB, ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
+        }
+    };
+
+    f32x4_t acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // transposed-read lane geometry: lane = 16g + 4q + pp -> site (ks*32 + 8g + q [+4]), 8-B piece pp of a 16-column tile
+    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
+    typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+    // rows tile: sites r0 = ks*32 + 8g + q and r0 + 4 (ks*32 rows = ks*4096 B: an immediate)
+    int aoff[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int col = (wn * 2 + i) * 16 + pp * 4, c16 = col >> 3, half = (col >> 2) & 1;
+        const int r0 = g * 8 + q;
+        aoff[i][0] = r0 * RB + ((c16 ^ chunk_swz<RB, false>(r0)) << 4) + half * 8;
+        aoff[i][1] = (r0 + 4) * RB + ((c16 ^ chunk_swz<RB, false>(r0 + 4)) << 4) + half * 8;
+    }
+    // patch: site (line ks*2 + (g>>1), column (g&1)*8 + q [+4]) shifted by tap (th, tw) -> patch row (line + th)*32 + col + tw
+    int boff[3][2][2];
+#pragma unroll
+    for (int tw = 0; tw < 3; ++tw)
+#pragma unroll
+        for (int wq = 0; wq < 2; ++wq) {
+            const int colw = (g & 1) * 8 + q + tw + 4 * wq;
+            const int sw = chunk_swz<RB, false>(colw);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = (wk * 2 + j) * 16 + pp * 4, c16 = col >> 3, half = (col >> 2) & 1;
+                boff[tw][wq][j] = ((g >> 1) * LP + colw) * RB + ((c16 ^ sw) << 4) + half * 8;
+            }
+        }
+
+    stage(0, 0);
+    for (int s = 0; s < nst; ++s) {
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nst) stage(s + 1, buf ^ 1);
+        const char *ln = smem + buf * STAGE;
+        const char *lp = ln + TILE_N;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t a[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ln + ks * 32 * RB + aoff[i][0]));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ln + ks * 32 * RB + aoff[i][1]));
+                a[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int th = t / 3, tw = t % 3;
+                const char *lt = lp + (ks * 2 + th) * LP * RB;               // compile-time offset
+                bf16x8_t bq[2];
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(lt + boff[tw][0][j]));
+                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(lt + boff[tw][1][j]));
+                    bq[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[t][i][j], 0, 0, 0);
+            }
+        }
+    }
+    // D[n][k]: n = (lane>>4)*4 + e, k = lane&15 ; tap index kd*9 + t
+    float *dst = p.part + (int64_t)blockIdx.x * p.part_stride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int k = k0 + (wk * 2 + j) * 16 + (lane & 15);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int n = n0 + (wn * 2 + i) * 16 + (lane >> 4) * 4 + e;
+                    if (n < p.N && k < p.C) dst[((int64_t)(kd * 9 + t) * p.N + n) * p.C + k] = acc[t][i][j][e];
+                }
+            }
+}
+
 template <int TN, int TK, bool F32, int TPB>
 int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
     constexpr int DN = 32 * TN, DK = 32 * TK;
@@ -375,12 +550,52 @@ static WGPlan wgrad_plan(const vnConv *g, int32_t split, int64_t M) {
     return w;
 }
 
+// ---- patch form (k_wgrad_patch): eligibility and chunking
+struct WPPlan {
+    bool ok;
+    int tiles_x, tiles_y, tiles_n, tiles_k;
+    int64_t ntiles, chunks;
+};
+static int wgrad_patch_enabled() {   // tuning aid: VN_WGRAD_PATCH=0 keeps the row form, 2 = also small images
+    static const int v = [] {
+        const char *e = getenv("VN_WGRAD_PATCH");
+        return e && *e ? atoi(e) : 1;
+    }();
+    return v;
+}
+static WPPlan wgrad_patch_plan(const vnConv *g, int32_t split, bool list) {
+    WPPlan w{};
+    if (!wgrad_patch_enabled() || list || split || g->dtype != VN_BF16) return w;
+    if (g->kH != 3 || g->kW != 3 || g->mulH != 1 || g->mulW != 1 || g->tmulH != 1 || g->tmulW != 1 || g->padH != 1 ||
+        g->padW != 1 || g->tmulD != 1 || g->divD != 1 || g->divH != 1 || g->divW != 1)
+        return w;
+    if (g->Hs != g->Hr || g->Ws != g->Wr) return w;
+    // measured: a win for the 64-channel Conv3d layers (1.3-1.4x); on the 128-channel 200 x 176 layers the four 64 x 64
+    // channel tiles need 2.4x the row chunks (partial-sum traffic) and only tie with the 128 x 128 row form
+    if (wgrad_patch_enabled() < 2 && (g->Hr < 128 || g->Wr < 128 || g->Cr > 64 || g->Cs > 64)) return w;
+    w.tiles_x = (int)vn_ceil_div(g->Wr, 16);
+    w.tiles_y = (int)vn_ceil_div(g->Hr, 4);
+    w.tiles_n = (int)vn_ceil_div(g->Cr, 64);
+    w.tiles_k = (int)vn_ceil_div(g->Cs, 64);
+    w.ntiles = (int64_t)g->B * g->Dr * w.tiles_y * w.tiles_x;
+    int64_t chunks = 512 / ((int64_t)g->kD * w.tiles_n * w.tiles_k);
+    if (chunks > w.ntiles / 8) chunks = w.ntiles / 8;
+    if (chunks > 256) chunks = 256;
+    if (chunks < 1) chunks = 1;
+    w.chunks = chunks;
+    w.ok = true;
+    return w;
+}
+
 extern "C" size_t vn_conv_wgrad_workspace_bytes(const vnConv *g, int32_t split, int64_t n_rows) {
     if (!g || g->B <= 0 || g->Dr <= 0 || g->Hr <= 0 || g->Wr <= 0 || g->Cs <= 0 || g->Cr <= 0) return 0;
     if (g->kD < 1 || g->kH < 1 || g->kW < 1) return 0;
     const int64_t M = n_rows > 0 ? n_rows : (int64_t)g->B * g->Dr * g->Hr * g->Wr;
     const WGPlan w = wgrad_plan(g, split, M);
-    return (size_t)w.chunks * (size_t)w.dw_elems * sizeof(float);   // (>= one chunk: vn_conv_wgrad_partials always uses it)
+    int64_t chunks = w.chunks;
+    const WPPlan wp = wgrad_patch_plan(g, split, n_rows > 0);
+    if (wp.ok && wp.chunks > chunks) chunks = wp.chunks;
+    return (size_t)chunks * (size_t)w.dw_elems * sizeof(float);   // (>= one chunk: vn_conv_wgrad_partials always uses it)
 }
 
 extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
@@ -459,6 +674,44 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     p.row_list = row_list;
     p.n_rows = n_rows;
     p.divD = g->divD; p.divH = g->divH; p.divW = g->divW;
+    const WPPlan wp = wgrad_patch_plan(g, split, row_list != nullptr);
+    if (wp.ok && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 15) && !(w.dw_elems & 3) &&
+        (int64_t)(workspace_bytes / ((size_t)w.dw_elems * sizeof(float))) >= 1) {
+        int64_t pchunks = wp.chunks;
+        const int64_t room = (int64_t)(workspace_bytes / ((size_t)w.dw_elems * sizeof(float)));
+        if (pchunks > room) pchunks = room;
+        WPParams q{};
+        q.src = p.src; q.rows = p.rows;
+        q.part = static_cast<float *>(workspace);
+        q.part_stride = w.dw_elems;
+        q.sB = p.sB; q.sD = p.sD; q.sH = p.sH; q.sW = p.sW;
+        q.rB = p.rB; q.rD = p.rD; q.rH = p.rH; q.rW = p.rW;
+        q.B = p.B; q.Ds = p.Ds; q.Hs = p.Hs; q.Ws = p.Ws; q.Dr = p.Dr; q.Hr = p.Hr; q.Wr = p.Wr;
+        q.mulD = p.mulD; q.padD = p.padD; q.kD = p.kD;
+        q.C = p.C; q.N = p.N; q.tiles_k = wp.tiles_k;
+        q.tiles_x = wp.tiles_x; q.tiles_y = wp.tiles_y;
+        q.tiles_per_chunk = (int32_t)vn_ceil_div(wp.ntiles, pchunks);
+        pchunks = vn_ceil_div(wp.ntiles, q.tiles_per_chunk);
+        q.src_bytes = p.src_bytes; q.rows_bytes = p.rows_bytes;
+        constexpr size_t lds = 2 * (64 * 128 + 6 * 32 * 128);
+        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_patch),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (attr != hipSuccess) return (int)attr;
+        hipStream_t pst = vn_stream(stream);
+        const dim3 pgrid((unsigned)pchunks, (unsigned)g->kD, (unsigned)(wp.tiles_n * wp.tiles_k));
+        k_wgrad_patch<<<pgrid, 256, lds, pst>>>(q);
+        VN_LAUNCH_STATUS();
+        if (partial_only) {
+            *chunks_out = (int32_t)pchunks;
+        } else {
+            const int64_t n4 = w.dw_elems / 4;
+            int64_t blocks = vn_ceil_div(n4, 256);
+            if (blocks > 2048) blocks = 2048;
+            k_wgrad_reduce<<<(unsigned)blocks, 256, 0, pst>>>(q.part, (int)pchunks, n4, dw_packed);
+            VN_LAUNCH_STATUS();
+        }
+        return VN_OK;
+    }
     // as many row chunks as the workspace has room for partial sums (none: one chunk, accumulated in place)
     int64_t chunks = w.chunks;
     const int64_t room = workspace ? (int64_t)(workspace_bytes / ((size_t)w.dw_elems * sizeof(float))) : 0;
