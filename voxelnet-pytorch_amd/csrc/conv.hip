@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         if (p.stats)    // capacity launch: the slab rows of empty tiles must read as zero
             for (int i = threadIdx.x; i < 2 * BN; i += 256) {
                 const int which = i / BN, c = i - which * BN;
-                if (n0 + c < p.N) p.stats[((int64_t)tile_m * 2 + which) * p.N + n0 + c] = 0.f;
+                if (n0 + c < p.N) p.stats[(((int64_t)blockIdx.y * (gridDim.x / ntn) + tile_m) * 2 + which) * p.N + n0 + c] = 0.f;
             }
         return;
     }
@@ -456,7 +456,8 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     }
     __syncthreads();
 
-    gg_store<WM, WN, SM>(p, acc, smem, otab, tile_m, n0, wm, wn, lane);
+    // slab row: residue classes (blockIdx.y) one after the other, gridDim.x / ntn rows each
+    gg_store<WM, WN, SM>(p, acc, smem, otab, (int64_t)blockIdx.y * (gridDim.x / ntn) + tile_m, n0, wm, wn, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -894,7 +895,15 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
 }
 
 extern "C" int64_t vn_conv_stats_slab_rows(const vnConv *g) {
-    if (!g || g->divD != 1 || g->divH != 1 || g->divW != 1) return 0;
+    if (!g || g->divD < 1 || g->divH < 1 || g->divW < 1) return 0;
+    if (g->divD * g->divH * g->divW > 1) {
+        // residue classes (strided transposed gathers): every class launches the tiles of the largest one
+        const int64_t qd = vn_ceil_div(g->Dr, g->divD), qh = vn_ceil_div(g->Hr, g->divH), qw = vn_ceil_div(g->Wr, g->divW);
+        const int nd = g->divD < g->Dr ? g->divD : g->Dr, nh = g->divH < g->Hr ? g->divH : g->Hr, nw = g->divW < g->Wr ? g->divW : g->Wr;
+        const int64_t rows = (int64_t)g->B * qd * qh * qw;
+        const int ncls = nd * nh * nw;
+        return (int64_t)ncls * vn_ceil_div(rows, gg_config(rows, g->Cr, ncls).BM);
+    }
     const PatchCfg pc = patch_config(g);
     if (pc.id >= 0) return patch_tiles(pc, g->B, g->Dr, g->Hr, g->Wr);
     const int64_t rows = (int64_t)g->B * g->Dr * g->Hr * g->Wr;
@@ -913,7 +922,7 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     VN_CHECK_ARG(g->divH == 1 || g->mulH == 1);
     VN_CHECK_ARG(g->divW == 1 || g->mulW == 1);
     VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
-    VN_CHECK_ARG(!stats_slab || (g->divD == 1 && g->divH == 1 && g->divW == 1));
+    VN_CHECK_ARG(!stats_slab || g->divD * g->divH * g->divW <= GG_MAX_CLASSES);
     VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32);
     const bool f32 = g->dtype == VN_F32;
     const int esz = f32 ? 4 : 2, bke = 128 / esz, align_e = 16 / esz;

@@ -195,7 +195,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         const int64_t M = P->y[l].M();
         P->slab_rows[l] = 0;
         P->slab[l] = nullptr;
-        if (!sp.transposed) {
+        {
             // the conv kernel picks its tiling (= slab granularity) from the launch geometry
             const Rows xin = dense_rows(nullptr, P->adt, B, P->in_dims[l][0], P->in_dims[l][1], P->in_dims[l][2], sp.cin);
             const vnConv sg = fwd_geom(sp, xin, P->odims[l], P->y[l]);
@@ -342,7 +342,7 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
         const Rows &y = P.y[l];
         const int64_t M = y.M();
         vnConv g = fwd_geom(sp, x, P.odims[l], y);
-        float *slab = (training && !sp.transposed) ? P.slab[l] : nullptr;
+        float *slab = training ? P.slab[l] : nullptr;
         if (l == 0 && cfg->sparse_first) {
             RT(vn_fill_rows(y.ptr, (vnDtype)y.dtype, M, sp.cout, sp.cout, L[l].bias, stream));
             RT(vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
