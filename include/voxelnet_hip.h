@@ -346,6 +346,14 @@ int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int64_t da_stride, const v
                     vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
                     const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
                     int64_t lo_off, vnStream stream);
+/* Row-flag variant for the first middle layer: row_flags = the uint8 site flags vn_active_sites leaves at the head
+ * of its workspace ((B,Dr,Hr,Wr) order, 1 = some occupied voxel in the receptive field).  Rows with flag 0 are
+ * skipped: that layer's weight- and data-gradient (the row-list kernels) only gather dy at flagged sites. */
+int vn_bn_bwd_apply_flagged(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y,
+                            vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                            const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
+                            const uint8_t *row_flags, vnStream stream);
+
 
 /* ------------------------------------------------------------------------
  * Layout / dtype helpers at the nn.Module boundary (the reference's modules

@@ -481,8 +481,13 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                                      P.bslab[l], stream));
             RT(vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
                                        G[l].beta, stream));
-            RT(vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
-                               P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, stream));
+            if (l == 0 && cfg->sparse_first)   // dy is only gathered at the active sites (flags: the forward's vn_active_sites)
+                RT(vn_bn_bwd_apply_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
+                                           P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW,
+                                           static_cast<const uint8_t *>(P.aws), stream));
+            else
+                RT(vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
+                                   P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, stream));
         }
         VN_HIP(hipMemsetAsync(G[l].bias, 0, C * sizeof(float), hs));   // bias before a train-mode BN: exactly 0
         int32_t wch = 1;

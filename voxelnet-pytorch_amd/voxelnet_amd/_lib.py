@@ -108,6 +108,8 @@ SIGNATURES = {
     "vn_bn_bwd_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vn_bn_bwd_apply": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp,
                                 c_i32, c_i64, c_i64, c_vp]),
+    "vn_bn_bwd_apply_flagged": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32,
+                                        c_i64, c_vp, c_vp]),
     "vn_nchw_to_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_vp]),
     "vn_rows_to_nchw": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i64, c_vp, c_i32, c_vp]),
     "vn_cast_rows": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_i64, c_i64, c_vp]),
