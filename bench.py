@@ -307,8 +307,15 @@ def main():
             n, fl, ms = summ[dom]
             ach = fl / (ms * 1e-3) / 1e12
             peak = PEAK_BF16_DENSE_TFLOPS if args.precision != "fp32" else 157.3
+            # HBM-side bytes per launch of the convolution family: NOT measurable here (PMC counters need rocprofv3);
+            # taken from the committed counter passes on this same command (profiles/, tools/pmc_family.py), bf16/B=2 only
+            traffic = None
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+            if dom == "k_gather_gemm" and args.precision == "bf16" and args.batch == 2 and os.path.exists(pmc):
+                with open(pmc) as fh:
+                    traffic = json.load(fh).get("traffic_bytes_per_launch")
             res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None,
+                               "frac": ach / peak, "traffic": traffic,
                                "avg_launch_us": 1e3 * ms / n, "launches": n,
                                "note": "algorithmic (dense-equivalent) FLOPs of all launches / summed HIP-event time, "
                                        "%d eager steps on the same inputs right after the timed region" % args.timer_steps}
