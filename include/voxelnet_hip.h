@@ -292,7 +292,8 @@ int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *layers, const f
                     const int64_t *coord, const void *vw_rows, int64_t K, void *workspace,
                     size_t workspace_bytes, const vnLayerGrads *grads /*[23]*/, float *d_heads_w,
                     float *d_heads_b, void *d_input, int32_t seg_begin, int32_t seg_end,
-                    vnStream stream);
+                    vnStream stream, vnStream side_stream /* NULL, or a second stream the weight-gradient
+                    launches run on beside the data-gradient ones; joined back before the call returns */);
 
 /* ------------------------------------------------------------------------
  * BatchNorm(+ReLU) over channels-last rows — nn.BatchNorm{1,2,3}d defaults

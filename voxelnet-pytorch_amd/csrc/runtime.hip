@@ -12,6 +12,8 @@
 // The per-layer call sequences are exactly those of voxelnet_amd/engine.py (the Python reference
 // orchestration, still used by the per-layer tests and the bf16x3 mode).
 #include "common.h"
+#include <atomic>
+#include <mutex>
 #include <string.h>
 
 namespace {
@@ -291,6 +293,24 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
 
 #define RT(call) do { int rc_ = (call); if (rc_ != VN_OK) return rc_; } while (0)
 
+// a small ring of timing-less events for the fork/join of the side stream (re-recording an event that an earlier
+// hipStreamWaitEvent has consumed is well defined: the wait captured the record that preceded it)
+hipEvent_t next_event() {
+    static hipEvent_t ring[64];
+    static std::atomic<unsigned> made{0}, next{0};
+    static std::mutex mu;
+    if (made.load() < 64) {
+        std::lock_guard<std::mutex> g(mu);
+        while (made.load() < 64) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            ring[made.load()] = e;
+            made.fetch_add(1);
+        }
+    }
+    return ring[next.fetch_add(1) % 64];
+}
+
 int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, vnStream st) {
     return vn_bn_apply(y.ptr, (vnDtype)y.dtype, y.sW, y.M(), C, stats, 1, a.ptr, (vnDtype)a.dtype, a.sW, 0, st);
 }
@@ -392,7 +412,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                                const float *d_reg, const float *prob, const void *dense, const int64_t *coord,
                                const void *vw_rows, int64_t K, void *workspace, size_t workspace_bytes,
                                const vnLayerGrads *G, float *d_heads_w, float *d_heads_b, void *d_input,
-                               int32_t seg_begin, int32_t seg_end, vnStream stream) {
+                               int32_t seg_begin, int32_t seg_end, vnStream stream, vnStream side_stream) {
     VN_CHECK_ARG(cfg && L && heads_w && d_prob && d_reg && prob && dense && workspace && G && d_heads_w && d_heads_b);
     VN_CHECK_ARG(!cfg->sparse_first || (coord && vw_rows && d_input));
     Plan P;
@@ -408,6 +428,19 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     // (the data-gradient operand packs were made by vn_net_forward, cfg->training)
     vnUnpackJob unpack[NL + 1];
     int nu = 0;
+    // The weight gradient of a layer and its data gradient are independent; on the small late layers either one is
+    // 60-140 workgroups on 256 CUs.  With a side stream the weight-gradient launches run beside the main stream's
+    // data-gradient / BatchNorm-backward launches: fork when dy exists, join before the segment's unpack.
+    hipStream_t ws = side_stream ? vn_stream(side_stream) : hs;
+    const vnStream wstream = side_stream ? side_stream : stream;
+    auto fork = [&]() -> int {
+        if (ws == hs) return VN_OK;
+        hipEvent_t e = next_event();
+        if (!e) return VN_EINVAL;
+        VN_HIP(hipEventRecord(e, hs));
+        VN_HIP(hipStreamWaitEvent(ws, e, 0));
+        return VN_OK;
+    };
     // ---- heads
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
@@ -418,7 +451,8 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
         int32_t hch = 1;
-        RT(vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, &gw, 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, stream));
+        RT(fork());
+        RT(vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, &gw, 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
         unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
         const int64_t os[4] = {P.d_cat.sB, P.d_cat.sD, P.d_cat.sH, P.d_cat.sW};
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
@@ -497,7 +531,8 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
-            RT(vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, stream));
+            RT(fork());
+            RT(vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
             RT(vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr,
                                         stream));
@@ -505,11 +540,12 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         }
         // weight gradient
         const vnConv gw = wgrad_geom(P, l, x);
+        RT(fork());
         if (sp.transposed) {
-            RT(vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, stream));
+            RT(vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, wch, dw_elems};
         } else {
-            RT(vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, stream));
+            RT(vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, wch, dw_elems};
         }
         // data gradient
@@ -524,6 +560,12 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                                   : geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, os);
         RT(vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr,
                                stream));
+    }
+    if (ws != hs) {   // join: the segment's weight-gradient partials are complete before they are summed / unpacked
+        hipEvent_t e = next_event();
+        if (!e) return VN_EINVAL;
+        VN_HIP(hipEventRecord(e, ws));
+        VN_HIP(hipStreamWaitEvent(hs, e, 0));
     }
     RT(vn_unpack_wgrads_batch(unpack, nu, stream));
     return VN_OK;

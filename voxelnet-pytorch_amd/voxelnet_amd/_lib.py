@@ -84,7 +84,7 @@ SIGNATURES = {
     "vn_net_forward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
                                c_vp, c_vp]),
     "vn_net_backward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
-                                c_vp, c_sz, _P(VnLayerGrads), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+                                c_vp, c_sz, _P(VnLayerGrads), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "vn_conv_stats_slab_rows": (c_i64, [_P(VnConv)]),
     "vn_bn_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
     "vn_conv_wgrad_workspace_bytes": (c_sz, [_P(VnConv), c_i32, c_i64]),

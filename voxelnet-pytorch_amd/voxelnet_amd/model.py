@@ -568,10 +568,11 @@ def _detector_backward_native(ctx, d_prob, d_reg):
         d_in = d_vw if cfg.sparse_first else torch.empty_like(dense.t)
         table = N.layer_table(mid._block1_stride)
         order = [22] + list(range(21, 15, -1)) + [15] + list(range(14, 8, -1)) + [8] + list(range(7, 2, -1)) + [2, 1, 0]
+        side = rpn._side_stream(dev) if rpn.overlap_wgrad else None
         for sb, se in NATIVE_SEGMENTS:
             _lib.call("vn_net_backward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
                       prob.data_ptr(), dense.ptr(), coord.data_ptr(), vw_rows.data_ptr(), K, ws.data_ptr(), ws_bytes, garr,
-                      dhw.data_ptr(), dhb.data_ptr(), d_in.data_ptr(), sb, se, E.stream())
+                      dhw.data_ptr(), dhb.data_ptr(), d_in.data_ptr(), sb, se, E.stream(), side)
             if sb == 0:
                 views["middle_rpn.prob_conv.conv.weight"].copy_(dhw[:2])
                 views["middle_rpn.prob_conv.conv.bias"].copy_(dhb[:2])
@@ -686,6 +687,15 @@ class RPN3D(nn.Module):
         #                                  set False to accumulate gradients over several backward() calls
         self.native_executor = True      # C++ step executor (csrc/runtime.hip) instead of per-launch Python calls
         self.grad_reducer = None  # parallel.GradAllReducer: bucketed all-reduce overlapped with backward
+        self.overlap_wgrad = True # native path: weight-gradient launches on a side stream beside the data-gradient ones
+
+    def _side_stream(self, device):
+        """HIP stream handle (ctypes) of the module-owned side stream for the native backward"""
+        st = self.__dict__.get("_side")
+        if st is None or st.device != torch.device(device):
+            st = torch.cuda.Stream(device=device)
+            self.__dict__["_side"] = st
+        return ctypes.c_void_p(st.cuda_stream)
 
     # The native executor's workspace arena (~1.5 GB for the car grid at batch 2) is kept in a small pool owned by
     # the module: handing a buffer of that size back to the caching allocator every step makes it re-hipMalloc
