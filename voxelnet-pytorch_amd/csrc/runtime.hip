@@ -293,6 +293,17 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
 
 #define RT(call) do { int rc_ = (call); if (rc_ != VN_OK) return rc_; } while (0)
 
+// zero up to NL small fp32 vectors in one launch (the conv-bias gradients: exactly 0 before a train-mode BatchNorm)
+struct ZeroJobs {
+    int32_t n;
+    int32_t len[NL];
+    float *ptr[NL];
+};
+__global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
+    float *p = z.ptr[blockIdx.x];
+    for (int i = threadIdx.x; i < z.len[blockIdx.x]; i += 256) p[i] = 0.f;
+}
+
 // a small ring of timing-less events for the fork/join of the side stream (re-recording an event that an earlier
 // hipStreamWaitEvent has consumed is well defined: the wait captured the record that preceded it)
 hipEvent_t next_event() {
@@ -428,6 +439,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     // (the data-gradient operand packs were made by vn_net_forward, cfg->training)
     vnUnpackJob unpack[NL + 1];
     int nu = 0;
+    ZeroJobs zj{};
     // The weight gradient of a layer and its data gradient are independent; on the small late layers either one is
     // 60-140 workgroups on 256 CUs.  With a side stream the weight-gradient launches run beside the main stream's
     // data-gradient / BatchNorm-backward launches: fork when dy exists, join before the segment's unpack.
@@ -523,7 +535,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                 RT(vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
                                    P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, stream));
         }
-        VN_HIP(hipMemsetAsync(G[l].bias, 0, C * sizeof(float), hs));   // bias before a train-mode BN: exactly 0
+        zj.ptr[zj.n] = G[l].bias; zj.len[zj.n] = C; ++zj.n;          // bias before a train-mode BN: gradient exactly 0
         int32_t wch = 1;
         const int64_t dw_elems = (int64_t)taps * sp.cin * sp.cout;
         const Rows x = input_of(l);
@@ -568,5 +580,9 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         VN_HIP(hipStreamWaitEvent(hs, e, 0));
     }
     RT(vn_unpack_wgrads_batch(unpack, nu, stream));
+    if (zj.n > 0) {
+        k_zero_many<<<zj.n, 256, 0, hs>>>(zj);
+        VN_LAUNCH_STATUS();
+    }
     return VN_OK;
 }
