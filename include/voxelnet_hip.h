@@ -117,6 +117,13 @@ int vn_scatter_dense_fwd(const float *voxelwise /*[K,C]*/, const int64_t *coord 
                          int64_t K, int32_t C, int32_t B, int32_t D, int32_t H, int32_t W,
                          void *dense, vnDtype dense_dtype, int32_t dense_channels,
                          int32_t split, vnStream stream);
+/* The same scatter WITHOUT the zero fill, for a dense buffer the caller keeps all-zero between steps: writes the K
+ * voxel rows, or — voxelwise == NULL — zeros at those rows (undoing the previous call).  A persistent grid then costs
+ * 2 x K rows of writes per step instead of a 721 MB fill. */
+int vn_scatter_dense_update(const float *voxelwise /* (K,C) or NULL */, const int64_t *coord, int64_t K,
+                            int32_t C, int32_t B, int32_t D, int32_t H, int32_t W, void *dense,
+                            vnDtype dense_dtype, int32_t dense_channels, int32_t split, vnStream stream);
+
 int vn_scatter_dense_bwd(const void *d_dense, vnDtype dtype, const int64_t *coord,
                          int64_t K, int32_t C, int32_t B, int32_t D, int32_t H, int32_t W,
                          float *d_voxelwise /*[K,C]*/, vnStream stream);

@@ -240,3 +240,24 @@ def test_car_full_forward(golden):
     assert prob.shape == (1, 2, 200, 176) and reg.shape == (1, 14, 200, 176)
     assert rel_err(prob[:, :, ::8, ::8], g["prob_lattice"]) < 1e-3
     assert rel_err(reg[:, :, ::8, ::8], g["reg_lattice"]) < 1e-3
+
+
+def test_persistent_grid_is_clean_between_steps(golden):
+    """The sparse first layer reads a module-owned dense grid that is kept all-zero between steps (K rows written,
+    then zeroed again).  A different cloud in between must leave no trace: detect(A), detect(B), detect(A) gives
+    bit-identical maps for A (train mode: batch statistics only)."""
+    feats, coords = split(golden("middle_tiny_car"))
+    feats, coords = [f.to(DEV) for f in feats], [c.to(DEV) for c in coords]
+    m = make_model("Car", 16, 24, "bf16")
+    m.train()
+    with torch.no_grad():
+        p1, r1 = m.detect(feats, coords)
+        # B: the same voxels moved by one cell along x, and fewer of them
+        feats_b = [f[: max(1, f.shape[0] // 2)] for f in feats]
+        coords_b = [c[: max(1, c.shape[0] // 2)].clone() for c in coords]
+        for c in coords_b:
+            c[:, 3] = (c[:, 3] + 1) % 24
+        m.detect(feats_b, coords_b)
+        p3, r3 = m.detect(feats, coords)
+    assert torch.equal(p1, p3) and torch.equal(r1, r3)
+    assert m.__dict__.get("_dense_pool"), "the pooled path was not taken"

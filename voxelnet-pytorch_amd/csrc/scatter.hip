@@ -34,7 +34,7 @@ __global__ void __launch_bounds__(256) k_scatter(const float *__restrict__ vw, c
     const int cg = (int)(i - k * groups) << 2;
     const int64_t site = site_of(coord + 4 * k, B, D, H, W);
     if (site < 0) return;
-    const float4 v = *reinterpret_cast<const float4 *>(vw + k * C + cg);
+    const float4 v = vw ? *reinterpret_cast<const float4 *>(vw + k * C + cg) : make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == 0) {
         *reinterpret_cast<float4 *>(static_cast<float *>(dense) + site * dense_channels + cg) = v;
     } else {
@@ -88,6 +88,26 @@ extern "C" int vn_scatter_dense_fwd(const float *voxelwise, const int64_t *coord
     k_zero<<<dim3(256 * 8), dim3(256), 0, st>>>(static_cast<uint4 *>(dense), bytes >> 4);
     VN_LAUNCH_STATUS();
     if (K == 0) return VN_OK;
+    const unsigned blocks = (unsigned)vn_ceil_div(K * (C >> 2), 256);
+    if (dense_dtype == VN_F32)
+        k_scatter<0><<<blocks, 256, 0, st>>>(voxelwise, coord, K, C, B, D, H, W, dense, dense_channels);
+    else if (!split)
+        k_scatter<1><<<blocks, 256, 0, st>>>(voxelwise, coord, K, C, B, D, H, W, dense, dense_channels);
+    else
+        k_scatter<2><<<blocks, 256, 0, st>>>(voxelwise, coord, K, C, B, D, H, W, dense, dense_channels);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_scatter_dense_update(const float *voxelwise, const int64_t *coord, int64_t K, int32_t C, int32_t B,
+                                       int32_t D, int32_t H, int32_t W, void *dense, vnDtype dense_dtype,
+                                       int32_t dense_channels, int32_t split, vnStream stream) {
+    VN_CHECK_ARG(dense && K >= 0 && C > 0 && (C & 3) == 0 && B > 0 && D > 0 && H > 0 && W > 0);
+    VN_CHECK_ARG(K == 0 || coord);
+    VN_CHECK_ARG(dense_channels == (split ? 2 * C : C));
+    VN_CHECK_ARG(!split || dense_dtype == VN_BF16);
+    if (K == 0) return VN_OK;
+    hipStream_t st = vn_stream(stream);
     const unsigned blocks = (unsigned)vn_ceil_div(K * (C >> 2), 256);
     if (dense_dtype == VN_F32)
         k_scatter<0><<<blocks, 256, 0, st>>>(voxelwise, coord, K, C, B, D, H, W, dense, dense_channels);

@@ -78,6 +78,8 @@ SIGNATURES = {
     "vn_vfe_bwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_vp, c_vp, _P(VnVfeGrads), c_vp, c_sz, c_vp]),
     "vn_scatter_dense_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,
                                      c_i32, c_vp]),
+    "vn_scatter_dense_update": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,
+                                        c_i32, c_vp]),
     "vn_scatter_dense_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vn_conv_gather_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_i32, c_vp, c_vp]),
     "vn_net_workspace_bytes": (c_sz, [_P(VnNetConfig), c_i64]),
