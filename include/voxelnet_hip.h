@@ -293,7 +293,8 @@ int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,
                    const float *heads_w /*[16,768]*/, const float *heads_b /*[16]*/,
                    const void *dense, const int64_t *coord, int64_t K, void *workspace,
                    size_t workspace_bytes, float *prob /*(B,2,h,w)*/, float *reg /*(B,14,h,w)*/,
-                   vnStream stream);
+                   vnStream stream,
+                   vnStream side_stream /* NULL, or a second stream deconv1 / deconv2 run on beside block2 / block3 */);
 int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
                     const float *d_prob, const float *d_reg, const float *prob, const void *dense,
                     const int64_t *coord, const void *vw_rows, int64_t K, void *workspace,

@@ -336,7 +336,7 @@ extern "C" size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K) {
 
 extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const float *heads_b,
                               const void *dense, const int64_t *coord, int64_t K, void *workspace,
-                              size_t workspace_bytes, float *prob, float *reg, vnStream stream) {
+                              size_t workspace_bytes, float *prob, float *reg, vnStream stream, vnStream side_stream) {
     VN_CHECK_ARG(cfg && L && heads_w && heads_b && dense && workspace && prob && reg && K >= 0);
     VN_CHECK_ARG(!cfg->sparse_first || coord);
     Plan P;
@@ -365,8 +365,20 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
     }
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
     Rows x1{}, x2{};
+    // deconv1 / deconv2 only feed the concat: with a side stream they run beside block2 / block3 (whose 100x88 and
+    // 50x44 images leave most CUs idle) and are joined before the heads
+    hipStream_t ss = side_stream ? vn_stream(side_stream) : hs;
+    const vnStream main_stream = stream;
     for (int l = 0; l < NL; ++l) {
         const Spec &sp = P.spec[l];
+        const bool on_side = ss != hs && (l == L_D1 || l == L_D2);
+        if (on_side) {   // fork: the block output this deconv reads exists at this point of the main stream
+            hipEvent_t e = next_event();
+            if (!e) return VN_EINVAL;
+            VN_HIP(hipEventRecord(e, hs));
+            VN_HIP(hipStreamWaitEvent(ss, e, 0));
+        }
+        const vnStream stream = on_side ? side_stream : main_stream;   // (shadows the parameter inside the loop body)
         if (l == L_D1) x = x1;                 // deconv1 and block2 both read the block1 output
         if (l == L_B2) x = x1;
         if (l == L_D2 || l == L_B3) x = x2;
@@ -405,6 +417,12 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
         if (!sp.transposed) x = a;
         if (l == L_D1 - 1) x1 = a;
         if (l == L_D2 - 1) x2 = a;
+    }
+    if (ss != hs) {   // join before the heads read the concat
+        hipEvent_t e = next_event();
+        if (!e) return VN_EINVAL;
+        VN_HIP(hipEventRecord(e, ss));
+        VN_HIP(hipStreamWaitEvent(hs, e, 0));
     }
     // heads: one N=16 GEMM over the 768-channel concat + sigmoid on the first two channels (model.py:276-281)
     {

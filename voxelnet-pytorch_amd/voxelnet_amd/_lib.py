@@ -84,7 +84,7 @@ SIGNATURES = {
     "vn_conv_gather_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_i32, c_vp, c_vp]),
     "vn_net_workspace_bytes": (c_sz, [_P(VnNetConfig), c_i64]),
     "vn_net_forward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
-                               c_vp, c_vp]),
+                               c_vp, c_vp, c_vp]),
     "vn_net_backward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                 c_vp, c_sz, _P(VnLayerGrads), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "vn_conv_stats_slab_rows": (c_i64, [_P(VnConv)]),

@@ -501,7 +501,7 @@ class _DetectorFn(torch.autograd.Function):
                 reg = torch.empty((B, 14, hf, wf), dtype=torch.float32, device=vw.device)
                 _lib.call("vn_net_forward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), heads["bias"].data_ptr(),
                           dense.ptr(), coord.data_ptr(), K, ws.data_ptr(), ws_bytes, prob.data_ptr(), reg.data_ptr(),
-                          E.stream())
+                          E.stream(), rpn._side_stream(vw.device) if rpn.overlap_wgrad else None)
                 if pooled:   # the backward of the sparse first layer never reads the grid: zero the K rows, hand it back
                     _lib.call("vn_scatter_dense_update", None, coord.data_ptr(), K, 128, B, *fn._grid.dims, dense.ptr(),
                               E._dt(dense.t), 128, 0, E.stream())
