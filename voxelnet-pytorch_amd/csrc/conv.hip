@@ -751,9 +751,13 @@ PatchCfg patch_config(const vnConv *g) {
     if (!((g->tmulH == 1 && g->padH == 1) || (g->tmulH == -1 && g->padH == -1))) return none;
     if (!((g->tmulW == 1 && g->padW == 1) || (g->tmulW == -1 && g->padW == -1))) return none;
     if (g->src_wrap != 0 || (g->Cr & 63)) return none;
-    // small images: too few tiles, k_gather_gemm's small configs win (VN_PATCH=2: take every eligible layer, for tests)
-    if (patch_enabled() < 2 && (g->Hr < 128 || g->Wr < 128)) return none;
     if (g->Hs != g->Hr || g->Ws != g->Wr) return none;
+    if (g->Hr < 128 || g->Wr < 128) {
+        // small images (100 x 88, 50 x 44): 4 x 16-pixel tiles so that there are enough workgroups for 256 CUs
+        // (VN_PATCH=2: every eligible layer, for tests; VN_PATCH=3: small images on k_gather_gemm as before)
+        if (patch_enabled() == 3 || g->Cr == 64) return none;
+        return PatchCfg{2, 64, 128, 16};
+    }
     if (g->Cr == 64) return PatchCfg{1, 256, 64, 32};        // 8 x 32 pixels
     return PatchCfg{0, 160, 128, 16};                        // 10 x 16 pixels
 }
@@ -773,6 +777,7 @@ int launch_patch(const GGParams &p, dim3 grid, hipStream_t st) {
 }
 int launch_patch_cfg(const PatchCfg &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
     if (c.id == 1) return f32 ? launch_patch<4, 1, 4, 32, true>(p, grid, st) : launch_patch<4, 1, 4, 32, false>(p, grid, st);
+    if (c.id == 2) return f32 ? launch_patch<2, 2, 2, 16, true>(p, grid, st) : launch_patch<2, 2, 2, 16, false>(p, grid, st);
     return f32 ? launch_patch<2, 2, 5, 16, true>(p, grid, st) : launch_patch<2, 2, 5, 16, false>(p, grid, st);
 }
 
