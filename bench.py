@@ -84,11 +84,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
+    # rehearsal aid (NOT a benchmark configuration): VN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, so
+    # the N>1 code path (broadcast, bucketed all-reduce overlapped with the segmented backward, MAX over ranks) can be
+    # exercised on a one-GPU box
+    share = os.environ.get("VN_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if share:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from voxelnet_amd import engine as E
