@@ -245,3 +245,47 @@ def test_unpack_sums_chunk_partials():
         acc = acc + part[c]
     _lib.call("vn_unpack_wgrad", acc.data_ptr(), co, ci, taps, 0, 1, ref.data_ptr(), E.stream())
     assert torch.equal(out, ref)
+
+
+def test_scatter_update_and_clear_keep_the_grid_zero():
+    """vn_scatter_dense_update == vn_scatter_dense_fwd on an all-zero grid, and update(NULL) restores all-zero"""
+    from voxelnet_amd import _lib, engine as E
+    DEV = "cuda:0"
+    torch.manual_seed(7)
+    B, D, H, W, C, K = 2, 3, 8, 8, 128, 40
+    cells = torch.randperm(B * D * H * W)[:K]
+    coord = torch.stack([cells // (D * H * W), (cells // (H * W)) % D, (cells // W) % H, cells % W], 1).to(DEV)
+    vw = torch.randn(K, C, device=DEV)
+    ref = torch.full((B, D, H, W, C), 7.0, dtype=torch.bfloat16, device=DEV)          # fwd overwrites everything
+    _lib.call("vn_scatter_dense_fwd", vw.data_ptr(), coord.data_ptr(), K, C, B, D, H, W, ref.data_ptr(), _lib.VN_BF16, C, 0,
+              E.stream())
+    grid = torch.zeros((B, D, H, W, C), dtype=torch.bfloat16, device=DEV)
+    _lib.call("vn_scatter_dense_update", vw.data_ptr(), coord.data_ptr(), K, C, B, D, H, W, grid.data_ptr(), _lib.VN_BF16, C, 0,
+              E.stream())
+    assert torch.equal(grid.view(torch.int16), ref.view(torch.int16))
+    _lib.call("vn_scatter_dense_update", None, coord.data_ptr(), K, C, B, D, H, W, grid.data_ptr(), _lib.VN_BF16, C, 0,
+              E.stream())
+    assert int(grid.view(torch.int16).ne(0).sum()) == 0
+
+
+def test_bn_bwd_apply_flagged_skips_unflagged_rows():
+    """rows with flag 0 are left untouched, flagged rows equal vn_bn_bwd_apply"""
+    from voxelnet_amd import _lib, engine as E
+    DEV = "cuda:0"
+    torch.manual_seed(8)
+    M, C = 1000, 64
+    da = torch.randn(M, C, device=DEV).to(torch.bfloat16)
+    y = torch.randn(M, C, device=DEV).to(torch.bfloat16)
+    stats = torch.randn(4 * C, device=DEV)
+    stats[C:2 * C].abs_()
+    coef = torch.randn(3 * C, device=DEV)
+    flags = (torch.rand(M, device=DEV) < 0.3).to(torch.uint8)
+    full = torch.empty(M, C, dtype=torch.bfloat16, device=DEV)
+    _lib.call("vn_bn_bwd_apply", da.data_ptr(), _lib.VN_BF16, C, y.data_ptr(), _lib.VN_BF16, C, M, C, stats.data_ptr(),
+              coef.data_ptr(), 1, full.data_ptr(), _lib.VN_BF16, C, 0, E.stream())
+    part = torch.full((M, C), 5.0, dtype=torch.bfloat16, device=DEV)
+    _lib.call("vn_bn_bwd_apply_flagged", da.data_ptr(), _lib.VN_BF16, C, y.data_ptr(), _lib.VN_BF16, C, M, C,
+              stats.data_ptr(), coef.data_ptr(), 1, part.data_ptr(), _lib.VN_BF16, C, flags.data_ptr(), E.stream())
+    f = flags.bool()
+    assert torch.equal(part[f].view(torch.int16), full[f].view(torch.int16))
+    assert bool((part[~f] == 5.0).all())
