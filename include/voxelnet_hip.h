@@ -221,6 +221,18 @@ int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_packed, cons
 size_t vn_active_sites_workspace_bytes(const vnConv *geom);
 int vn_active_sites(const int64_t *coord, int64_t K, const vnConv *geom, void *workspace,
                     size_t workspace_bytes, int64_t *list, int64_t cap, int32_t *count, vnStream stream);
+/* "Rulebook" evaluation of a conv over a sparse input (the first middle layer, model.py:207 over model.py:102-106),
+ * in three calls: (1) vn_voxel_index_grid: int32 grid over the INPUT cells, voxel row index or -1;
+ * (2) P[v][t][:] = W[t] . x[v] for every voxel and tap = ONE dense vn_conv_gather_gemm of the (K,Cin) voxel rows
+ * against the packed [taps*Cout][Cin] weights (fp32 output, row stride taps*Cout); (3) vn_rulebook_combine: every
+ * listed (active) output site adds the P rows of the taps whose source cell is occupied, in tap order, + bias ->
+ * y at the site (dense addressing) and, optionally, per-workgroup sum / sum of squares (slab rows of 256 list rows,
+ * the layout of vn_conv_gather_gemm_rows' stats_slab).  Work ~ K*taps instead of sites*taps.  Cout must be 64. */
+int vn_voxel_index_grid(const int64_t *coord, int64_t K, int32_t B, int32_t D, int32_t H, int32_t W,
+                        int32_t *grid /* (B,D,H,W) */, vnStream stream);
+int vn_rulebook_combine(const float *P, const int32_t *index_grid, const int64_t *list, int64_t cap,
+                        const int32_t *count, const vnConv *geom, const float *bias, void *y,
+                        vnDtype y_dtype, float *stats_slab, vnStream stream);
 /* y[m][0:C] = values[0:C] for M rows (the conv output at inactive sites is the bias) */
 int vn_fill_rows(void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stride, const float *values,
                  vnStream stream);
@@ -291,7 +303,7 @@ typedef struct {
 size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K);
 int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,
                    const float *heads_w /*[16,768]*/, const float *heads_b /*[16]*/,
-                   const void *dense, const int64_t *coord, int64_t K, void *workspace,
+                   const void *dense, const int64_t *coord, const void *vw_rows /* (K,128) voxel rows in the operand dtype, sparse_first only */, int64_t K, void *workspace,
                    size_t workspace_bytes, float *prob /*(B,2,h,w)*/, float *reg /*(B,14,h,w)*/,
                    vnStream stream,
                    vnStream side_stream /* NULL, or a second stream deconv1 / deconv2 run on beside block2 / block3 */);

@@ -242,10 +242,10 @@ def test_car_full_forward(golden):
     assert rel_err(reg[:, :, ::8, ::8], g["reg_lattice"]) < 1e-3
 
 
-def test_persistent_grid_is_clean_between_steps(golden):
-    """The sparse first layer reads a module-owned dense grid that is kept all-zero between steps (K rows written,
-    then zeroed again).  A different cloud in between must leave no trace: detect(A), detect(B), detect(A) gives
-    bit-identical maps for A (train mode: batch statistics only)."""
+def test_sparse_first_layer_has_no_state_between_steps(golden):
+    """The rulebook first layer works from per-step buffers in the workspace (voxel index grid, P rows): a different
+    cloud in between must leave no trace: detect(A), detect(B), detect(A) gives bit-identical maps for A (train
+    mode: batch statistics only)."""
     feats, coords = split(golden("middle_tiny_car"))
     feats, coords = [f.to(DEV) for f in feats], [c.to(DEV) for c in coords]
     m = make_model("Car", 16, 24, "bf16")
@@ -260,4 +260,3 @@ def test_persistent_grid_is_clean_between_steps(golden):
         m.detect(feats_b, coords_b)
         p3, r3 = m.detect(feats, coords)
     assert torch.equal(p1, p3) and torch.equal(r1, r3)
-    assert m.__dict__.get("_dense_pool"), "the pooled path was not taken"

@@ -92,6 +92,7 @@ struct Plan {
     void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes;
     // sparse first layer
     int64_t *alist; int32_t *acount; int64_t acap; void *aws; size_t aws_bytes;
+    int32_t *igrid; float *rbP;   // rulebook: voxel index grid over the input cells, P[v][tap][64]
     // zeroed regions
     char *zf_begin, *zf_end, *zb_begin, *zb_end;
     size_t bytes;
@@ -236,6 +237,8 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         vnConv g = fwd_geom(P->spec[0], dummy, od, P->y[0]);
         P->aws_bytes = vn_active_sites_workspace_bytes(&g);
         P->aws = A.take(P->aws_bytes);
+        P->igrid = (int32_t *)A.take(sizeof(int32_t) * (size_t)B * c->D * c->H * c->W);
+        P->rbP = (float *)A.take(sizeof(float) * (size_t)(K > 0 ? K : 1) * 27 * 64);
         P->slab_rows[0] = vn_ceil_div(cap, 256);
     }
     // ---- backward buffers
@@ -335,10 +338,10 @@ extern "C" size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K) {
 }
 
 extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const float *heads_b,
-                              const void *dense, const int64_t *coord, int64_t K, void *workspace,
+                              const void *dense, const int64_t *coord, const void *vw_rows, int64_t K, void *workspace,
                               size_t workspace_bytes, float *prob, float *reg, vnStream stream, vnStream side_stream) {
-    VN_CHECK_ARG(cfg && L && heads_w && heads_b && dense && workspace && prob && reg && K >= 0);
-    VN_CHECK_ARG(!cfg->sparse_first || coord);
+    VN_CHECK_ARG(cfg && L && heads_w && heads_b && workspace && prob && reg && K >= 0);
+    VN_CHECK_ARG(cfg->sparse_first ? (coord && vw_rows) : dense != nullptr);
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
     if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
@@ -389,8 +392,22 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
         if (l == 0 && cfg->sparse_first) {
             RT(vn_fill_rows(y.ptr, (vnDtype)y.dtype, M, sp.cout, sp.cout, L[l].bias, stream));
             RT(vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
-            RT(vn_conv_gather_gemm_rows(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, &g, P.alist, P.acap,
-                                        P.acount, 0, slab, stream));
+            // rulebook: P[v][tap] = W[tap] . x[v] as ONE dense GEMM over the K voxel rows ([27*64][128] packed weights),
+            // then every active site adds the P rows of its occupied source cells (no dense grid, no zero work)
+            RT(vn_voxel_index_grid(coord, K, cfg->B, cfg->D, cfg->H, cfg->W, P.igrid, stream));
+            if (K > 0) {
+                vnConv q;
+                memset(&q, 0, sizeof(q));
+                q.dtype = P.adt; q.B = 1; q.Ds = q.Hs = 1; q.Ws = (int32_t)K; q.Dr = q.Hr = 1; q.Wr = (int32_t)K;
+                q.Cs = sp.cin; q.Cr = 27 * sp.cout;
+                q.kD = q.kH = q.kW = 1; q.mulD = q.mulH = q.mulW = 1; q.tmulD = q.tmulH = q.tmulW = 1;
+                q.divD = q.divH = q.divW = 1;
+                q.src_sB = q.src_sD = q.src_sH = K * sp.cin; q.src_sW = sp.cin;
+                q.out_sB = q.out_sD = q.out_sH = K * q.Cr; q.out_sW = q.Cr;
+                RT(vn_conv_gather_gemm(vw_rows, P.wp_f[l], nullptr, P.rbP, VN_F32, &q, 0, nullptr, stream));
+            }
+            RT(vn_rulebook_combine(P.rbP, P.igrid, P.alist, P.acap, P.acount, &g, L[l].bias, y.ptr, (vnDtype)y.dtype, slab,
+                                   stream));
         } else {
             RT(vn_conv_gather_gemm(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, &g, 0, slab, stream));
         }
@@ -442,8 +459,8 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                                const void *vw_rows, int64_t K, void *workspace, size_t workspace_bytes,
                                const vnLayerGrads *G, float *d_heads_w, float *d_heads_b, void *d_input,
                                int32_t seg_begin, int32_t seg_end, vnStream stream, vnStream side_stream) {
-    VN_CHECK_ARG(cfg && L && heads_w && d_prob && d_reg && prob && dense && workspace && G && d_heads_w && d_heads_b);
-    VN_CHECK_ARG(!cfg->sparse_first || (coord && vw_rows && d_input));
+    VN_CHECK_ARG(cfg && L && heads_w && d_prob && d_reg && prob && workspace && G && d_heads_w && d_heads_b);
+    VN_CHECK_ARG(cfg->sparse_first ? (coord && vw_rows && d_input) : dense != nullptr);
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
     if (workspace_bytes < P.bytes) return VN_EWORKSPACE;

@@ -132,6 +132,76 @@ __global__ void __launch_bounds__(256) k_fill_rows(void *__restrict__ y, int f32
     }
 }
 
+// ---- "rulebook" evaluation of the first Conv3d ---------------------------------------------------------------------
+// out[site] = bias + sum over the taps t whose source cell holds an occupied voxel v of  W[t] . x[v].
+// Step 1 (a plain dense GEMM, vn_conv_gather_gemm on the (K,128) voxel rows against the [taps*Cout][Cin] packed
+// weights): P[v][t][:] = W[t] . x[v] for every voxel and tap — 2*K*27*128*64 FLOP instead of the
+// dense-equivalent 2*sites*27*128*64 over the ~10x more numerous active sites.
+// Step 2 (here): every active site looks its <= 27 source cells up in an int32 voxel-index grid and adds the
+// matching P rows in tap order (deterministic), writes y and the per-workgroup BatchNorm partial sums.
+__global__ void __launch_bounds__(256) k_index_scatter(const int64_t *__restrict__ coord, int64_t K, int B, int D, int H,
+                                                       int W, int32_t *__restrict__ grid) {
+    const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= K) return;
+    const int64_t *c = coord + v * 4;
+    const int64_t b = c[0], z = c[1], y = c[2], x = c[3];
+    if (b < 0 || b >= B || z < 0 || z >= D || y < 0 || y >= H || x < 0 || x >= W) return;
+    grid[((b * D + z) * H + y) * W + x] = (int32_t)v;
+}
+
+template <bool OUT_F32>
+__global__ void __launch_bounds__(256) k_rulebook_combine(const float *__restrict__ P, const int32_t *__restrict__ grid,
+                                                          const int64_t *__restrict__ list,
+                                                          const int32_t *__restrict__ count, ASGeom g, int Di, int Hi,
+                                                          int Wi, int C, const float *__restrict__ bias,
+                                                          void *__restrict__ y, float *__restrict__ slab) {
+    // workgroup = 256 list rows (the slab granularity of the row-list conv kernel); wave w takes rows w, w+4, ...;
+    // lane = output channel (C == 64)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int taps = g.kD * g.kH * g.kW;
+    const int64_t n = count[0];
+    const float bv = bias ? bias[lane] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = wave; r < 256; r += 4) {
+        const int64_t m = (int64_t)blockIdx.x * 256 + r;
+        if (m >= n) break;
+        const int64_t *rc = list + m * 4;
+        const int b = (int)rc[0], od = (int)rc[1], oh = (int)rc[2], ow = (int)rc[3];
+        // lane t < taps: voxel index of tap t's source cell (or -1)
+        int idx = -1;
+        if (lane < taps) {
+            const int kd = lane / (g.kH * g.kW), kh = (lane / g.kW) % g.kH, kw = lane % g.kW;
+            const int sd = od * g.sD + kd - g.pD, sh = oh * g.sH + kh - g.pH, sw = ow * g.sW + kw - g.pW;
+            if ((unsigned)sd < (unsigned)Di && (unsigned)sh < (unsigned)Hi && (unsigned)sw < (unsigned)Wi)
+                idx = grid[(((int64_t)b * Di + sd) * Hi + sh) * Wi + sw];
+        }
+        uint64_t live = __builtin_amdgcn_ballot_w64(idx >= 0);
+        float acc = 0.f;
+        while (live) {                       // ascending tap order: a fixed summation order
+            const int t = __builtin_ctzll(live);
+            live &= live - 1;
+            const int v = __builtin_amdgcn_readlane(idx, t);
+            acc += P[((int64_t)v * taps + t) * C + lane];
+        }
+        s1 += acc;
+        s2 += acc * acc;
+        const int64_t o = ((((int64_t)b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * C + lane;
+        if (OUT_F32) static_cast<float *>(y)[o] = acc + bv;
+        else static_cast<bf16_t *>(y)[o] = (bf16_t)(acc + bv);
+    }
+    if (slab) {
+        __shared__ float red[2][4][64];
+        red[0][wave][lane] = s1;
+        red[1][wave][lane] = s2;
+        __syncthreads();
+        if (threadIdx.x < 128) {
+            const int which = threadIdx.x >> 6;
+            slab[((int64_t)blockIdx.x * 2 + which) * C + lane] =
+                red[which][0][lane] + red[which][1][lane] + red[which][2][lane] + red[which][3][lane];
+        }
+    }
+}
+
 struct ASPlan {
     int64_t sites, nb;
     size_t off_flags, off_blk, bytes;
@@ -192,6 +262,38 @@ extern "C" int vn_fill_rows(void *y, vnDtype dtype, int64_t M, int32_t C, int64_
     int64_t blocks = vn_ceil_div(M * (C >> 2), 256);
     if (blocks > 8192) blocks = 8192;
     k_fill_rows<<<(unsigned)blocks, 256, 0, vn_stream(stream)>>>(y, dtype == VN_F32, M, C, stride, values);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_voxel_index_grid(const int64_t *coord, int64_t K, int32_t B, int32_t D, int32_t H, int32_t W,
+                                   int32_t *grid, vnStream stream) {
+    VN_CHECK_ARG(grid && K >= 0 && B > 0 && D > 0 && H > 0 && W > 0 && (coord || K == 0) && K < (1ll << 31));
+    hipStream_t st = vn_stream(stream);
+    VN_HIP(hipMemsetAsync(grid, 0xFF, sizeof(int32_t) * (size_t)B * D * H * W, st));   // -1 everywhere
+    if (K > 0) {
+        k_index_scatter<<<(unsigned)vn_ceil_div(K, 256), 256, 0, st>>>(coord, K, B, D, H, W, grid);
+        VN_LAUNCH_STATUS();
+    }
+    return VN_OK;
+}
+
+extern "C" int vn_rulebook_combine(const float *P, const int32_t *index_grid, const int64_t *list, int64_t cap,
+                                   const int32_t *count, const vnConv *geom, const float *bias, void *y,
+                                   vnDtype y_dtype, float *stats_slab, vnStream stream) {
+    VN_CHECK_ARG(P && index_grid && list && count && y && as_geom_ok(geom) && cap >= 0);
+    VN_CHECK_ARG(geom->Cr == 64 && geom->kD * geom->kH * geom->kW <= 64);   // lane = channel / lane = tap
+    VN_CHECK_ARG(y_dtype == VN_F32 || y_dtype == VN_BF16);
+    if (cap == 0) return VN_OK;
+    const ASGeom g{geom->B, geom->Dr, geom->Hr, geom->Wr, geom->kD, geom->kH, geom->kW,
+                   geom->mulD, geom->mulH, geom->mulW, geom->padD, geom->padH, geom->padW};
+    const unsigned blocks = (unsigned)vn_ceil_div(cap, 256);
+    if (y_dtype == VN_F32)
+        k_rulebook_combine<true><<<blocks, 256, 0, vn_stream(stream)>>>(P, index_grid, list, count, g, geom->Ds, geom->Hs,
+                                                                        geom->Ws, geom->Cr, bias, y, stats_slab);
+    else
+        k_rulebook_combine<false><<<blocks, 256, 0, vn_stream(stream)>>>(P, index_grid, list, count, g, geom->Ds, geom->Hs,
+                                                                         geom->Ws, geom->Cr, bias, y, stats_slab);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

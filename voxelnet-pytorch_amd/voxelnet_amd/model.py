@@ -469,16 +469,10 @@ class _DetectorFn(torch.autograd.Function):
         if native:
             with torch.cuda.device(feature.device):
                 vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
-                # With the sparse first Conv3d the dense grid is read by that layer's forward gather only: it lives in
-                # a module-owned buffer that is kept all-zero between steps (write the K rows, run, zero them again)
-                # instead of being allocated and zero-filled (721 MB) every step.
-                pooled = bool(rpn.sparse_first_layer)
-                if pooled:
-                    dense, clean = rpn._dense_acquire(B, fn._grid.dims, mode, vw.device)
-                    _lib.call("vn_scatter_dense_update" if clean else "vn_scatter_dense_fwd", vw.data_ptr(), coord.data_ptr(),
-                              vw.shape[0], 128, B, *fn._grid.dims, dense.ptr(), E._dt(dense.t), 128, 0, E.stream())
-                else:
-                    dense = scatter_rows(vw, coord, B, fn._grid.dims, mode)
+                # With the sparse first Conv3d (rulebook evaluation: voxel rows x packed weights, then a gather-sum per
+                # active site) the dense (B,10,400,352,128) grid of model.py:102-106 is never built.
+                sparse = bool(rpn.sparse_first_layer)
+                dense = None if sparse else scatter_rows(vw, coord, B, fn._grid.dims, mode)
                 if mode == "fp32":
                     vw_rows = vw
                 else:
@@ -500,12 +494,9 @@ class _DetectorFn(torch.autograd.Function):
                 prob = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=vw.device)
                 reg = torch.empty((B, 14, hf, wf), dtype=torch.float32, device=vw.device)
                 _lib.call("vn_net_forward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), heads["bias"].data_ptr(),
-                          dense.ptr(), coord.data_ptr(), K, ws.data_ptr(), ws_bytes, prob.data_ptr(), reg.data_ptr(),
-                          E.stream(), rpn._side_stream(vw.device) if rpn.overlap_wgrad else None)
-                if pooled:   # the backward of the sparse first layer never reads the grid: zero the K rows, hand it back
-                    _lib.call("vn_scatter_dense_update", None, coord.data_ptr(), K, 128, B, *fn._grid.dims, dense.ptr(),
-                              E._dt(dense.t), 128, 0, E.stream())
-                    rpn._dense_release(dense)
+                          dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K, ws.data_ptr(),
+                          ws_bytes, prob.data_ptr(), reg.data_ptr(), E.stream(),
+                          rpn._side_stream(vw.device) if rpn.overlap_wgrad else None)
             ctx.saved = (feature, coord, stats, wst, vparams, (cfg, ws, ws_bytes, dense, vw_rows, heads, prob.detach()), None, None)
             # (prob.detach(): an alias — keeping the Function's own output on ctx would be a reference cycle)
             ctx.reducer = rpn.grad_reducer
@@ -584,7 +575,8 @@ def _detector_backward_native(ctx, d_prob, d_reg):
         side = rpn._side_stream(dev) if rpn.overlap_wgrad else None
         for sb, se in NATIVE_SEGMENTS:
             _lib.call("vn_net_backward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
-                      prob.data_ptr(), dense.ptr(), coord.data_ptr(), vw_rows.data_ptr(), K, ws.data_ptr(), ws_bytes, garr,
+                      prob.data_ptr(), dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K,
+                      ws.data_ptr(), ws_bytes, garr,
                       dhw.data_ptr(), dhb.data_ptr(), d_in.data_ptr(), sb, se, E.stream(), side)
             if sb == 0:
                 views["middle_rpn.prob_conv.conv.weight"].copy_(dhw[:2])
@@ -719,22 +711,6 @@ class RPN3D(nn.Module):
             if t.numel() >= nbytes and t.device == device:
                 return pool.pop(i)
         return torch.empty(nbytes, dtype=torch.uint8, device=device)
-
-    def _dense_acquire(self, B, dims, mode, device):
-        """-> (Rows of the (B,D,H,W,128) grid, is_all_zero).  A released buffer is all-zero by contract; a new one is not."""
-        key = (B, tuple(dims), mode, str(device))
-        pool = self.__dict__.setdefault("_dense_pool", {})
-        t = pool.pop(key, None)
-        if t is not None:
-            return Rows(t, 128, 0), True
-        D, H, W = dims
-        return Rows(torch.empty((B, D, H, W, 128), dtype=E.act_dtype_of(mode), device=device), 128, 0), False
-
-    def _dense_release(self, dense):
-        pool = self.__dict__.setdefault("_dense_pool", {})
-        t = dense.t
-        key = (t.shape[0], tuple(t.shape[1:4]), "fp32" if t.dtype == torch.float32 else "bf16", str(t.device))
-        pool[key] = t
 
     def _ws_release(self, ws):
         pool = self.__dict__.setdefault("_ws_pool", [])
