@@ -226,10 +226,11 @@ int vn_active_sites(const int64_t *coord, int64_t K, const vnConv *geom, void *w
  * (2) P[v][t][:] = W[t] . x[v] for every voxel and tap = ONE dense vn_conv_gather_gemm of the (K,Cin) voxel rows
  * against the packed [taps*Cout][Cin] weights (fp32 output, row stride taps*Cout); (3) vn_rulebook_combine: every
  * listed (active) output site adds the P rows of the taps whose source cell is occupied, in tap order, + bias ->
- * y at the site (dense addressing) and, optionally, per-workgroup sum / sum of squares (slab rows of 256 list rows,
- * the layout of vn_conv_gather_gemm_rows' stats_slab).  Work ~ K*taps instead of sites*taps.  Cout must be 64. */
+ * y at the site (dense addressing) and, optionally, per-workgroup sum / sum of squares (stats_slab
+ * [vn_rulebook_slab_rows(cap)][2][Cout], the layout vn_bn_finalize_slab reads).  Work ~ K*taps instead of sites*taps.  Cout must be 64. */
 int vn_voxel_index_grid(const int64_t *coord, int64_t K, int32_t B, int32_t D, int32_t H, int32_t W,
                         int32_t *grid /* (B,D,H,W) */, vnStream stream);
+int64_t vn_rulebook_slab_rows(int64_t cap);   /* rows of vn_rulebook_combine's stats_slab for a list capacity */
 int vn_rulebook_combine(const float *P, const int32_t *index_grid, const int64_t *list, int64_t cap,
                         const int32_t *count, const vnConv *geom, const float *bias, void *y,
                         vnDtype y_dtype, float *stats_slab, vnStream stream);

@@ -239,7 +239,8 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         P->aws = A.take(P->aws_bytes);
         P->igrid = (int32_t *)A.take(sizeof(int32_t) * (size_t)B * c->D * c->H * c->W);
         P->rbP = (float *)A.take(sizeof(float) * (size_t)(K > 0 ? K : 1) * 27 * 64);
-        P->slab_rows[0] = vn_ceil_div(cap, 256);
+        P->slab_rows[0] = vn_rulebook_slab_rows(cap);
+        P->slab[0] = (float *)A.take((size_t)P->slab_rows[0] * 2 * P->spec[0].cout * sizeof(float));   // (its own size)
     }
     // ---- backward buffers
     P->zb_begin = base ? base + A.off : nullptr;

@@ -149,21 +149,23 @@ __global__ void __launch_bounds__(256) k_index_scatter(const int64_t *__restrict
     grid[((b * D + z) * H + y) * W + x] = (int32_t)v;
 }
 
+constexpr int RB_ROWS = 64;   // list rows per workgroup of k_rulebook_combine (and per row of its statistics slab)
+
 template <bool OUT_F32>
 __global__ void __launch_bounds__(256) k_rulebook_combine(const float *__restrict__ P, const int32_t *__restrict__ grid,
                                                           const int64_t *__restrict__ list,
                                                           const int32_t *__restrict__ count, ASGeom g, int Di, int Hi,
                                                           int Wi, int C, const float *__restrict__ bias,
                                                           void *__restrict__ y, float *__restrict__ slab) {
-    // workgroup = 256 list rows (the slab granularity of the row-list conv kernel); wave w takes rows w, w+4, ...;
-    // lane = output channel (C == 64)
+    // workgroup = RB_ROWS list rows (= one slab row); wave w takes rows w, w+4, ...; lane = output channel (C == 64).
+    // The per-site chain (coordinates -> 27 index lookups -> P rows) is latency-bound: many short workgroups.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int taps = g.kD * g.kH * g.kW;
     const int64_t n = count[0];
     const float bv = bias ? bias[lane] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    for (int r = wave; r < 256; r += 4) {
-        const int64_t m = (int64_t)blockIdx.x * 256 + r;
+    for (int r = wave; r < RB_ROWS; r += 4) {
+        const int64_t m = (int64_t)blockIdx.x * RB_ROWS + r;
         if (m >= n) break;
         const int64_t *rc = list + m * 4;
         const int b = (int)rc[0], od = (int)rc[1], oh = (int)rc[2], ow = (int)rc[3];
@@ -287,7 +289,7 @@ extern "C" int vn_rulebook_combine(const float *P, const int32_t *index_grid, co
     if (cap == 0) return VN_OK;
     const ASGeom g{geom->B, geom->Dr, geom->Hr, geom->Wr, geom->kD, geom->kH, geom->kW,
                    geom->mulD, geom->mulH, geom->mulW, geom->padD, geom->padH, geom->padW};
-    const unsigned blocks = (unsigned)vn_ceil_div(cap, 256);
+    const unsigned blocks = (unsigned)vn_ceil_div(cap, RB_ROWS);
     if (y_dtype == VN_F32)
         k_rulebook_combine<true><<<blocks, 256, 0, vn_stream(stream)>>>(P, index_grid, list, count, g, geom->Ds, geom->Hs,
                                                                         geom->Ws, geom->Cr, bias, y, stats_slab);
@@ -297,3 +299,5 @@ extern "C" int vn_rulebook_combine(const float *P, const int32_t *index_grid, co
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
+
+extern "C" int64_t vn_rulebook_slab_rows(int64_t cap) { return cap > 0 ? vn_ceil_div(cap, RB_ROWS) : 0; }

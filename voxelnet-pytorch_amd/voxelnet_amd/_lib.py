@@ -86,6 +86,7 @@ SIGNATURES = {
     "vn_net_forward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
                                c_vp, c_vp, c_vp]),
     "vn_voxel_index_grid": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "vn_rulebook_slab_rows": (c_i64, [c_i64]),
     "vn_rulebook_combine": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, _P(VnConv), c_vp, c_vp, c_i32, c_vp, c_vp]),
     "vn_net_backward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                 c_vp, c_sz, _P(VnLayerGrads), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
