@@ -359,7 +359,10 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
+    // wave w owns all 64 `rows` channels x source channels 16w..16w+15 of every tap: the four A (rows) fragments are
+    // read once per K half and shared by the nine taps, a tap costs ONE B fragment (2 transposed reads) per 4 MFMAs —
+    // the loop is LDS-read-bound (2 x 2 waves of 32 x 32 needed 160 KB of reads per stage and workgroup, this 104 KB)
+    const int wk = wave;
     const int tile = blockIdx.z;
     const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
     const int n0 = tn * 64, k0 = tk * 64;
@@ -374,91 +377,117 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
     const __amdgpu_buffer_rsrc_t rs_r = vn_uniform_rsrc(p.rows, p.rows_bytes);
     const uint32_t s_col = (uint32_t)(k0 * 2), r_col = (uint32_t)(n0 * 2);
 
-    // stage = spatial tile tbeg + s
-    auto stage = [&](int sidx, int buf) {
-        int64_t t = tbeg + sidx;
-        const int tx = (int)(t % p.tiles_x); t /= p.tiles_x;
-        const int ty = (int)(t % p.tiles_y); t /= p.tiles_y;
-        const int d = (int)(t % p.Dr);
-        const int b = (int)(t / p.Dr);
+    // ---- loader state.  Per lane and piece, constant over the stages: the site / patch cell it loads (relative to the
+    // tile origin), its byte offset relative to the tile's first site, its 16-B chunk.  Per stage only the tile origin
+    // changes (kept incrementally: no divisions in the loop), so a piece costs a few compares and one add.
+    int r_py[IN], r_px[IN];
+    uint32_t r_dlt[IN], r_chunk[IN];
+#pragma unroll
+    for (int i = 0; i < IN; ++i) {
+        const int r = (i * 4 + wave) * 8 + lane / 8;                         // site 0..63
+        const int c = (lane % 8) ^ chunk_swz<RB, false>(r);
+        r_py[i] = r >> 4; r_px[i] = r & 15;
+        r_dlt[i] = (uint32_t)((((int64_t)(r >> 4)) * p.rH + (int64_t)(r & 15) * p.rW) * 2) + (uint32_t)c * 16u;
+        r_chunk[i] = (n0 + c * 8) < p.N ? 1u : 0u;
+    }
+    constexpr int IPP = (NPP + 3) / 4;
+    int s_qy[IPP], s_qx[IPP];
+    int32_t s_dlt[IPP];
+    uint32_t s_ok[IPP], s_lds[IPP];
+#pragma unroll
+    for (int i = 0; i < IPP; ++i) {
+        const int piece = i * 4 + wave;
+        const int ql = piece / 3, cg = piece - ql * 3;
+        const int qx = cg * 8 + lane / 8;                                    // column inside the line (0..23; 18.. unused)
+        const int prow = ql * LP + qx;
+        const int c = (lane % 8) ^ chunk_swz<RB, false>(prow);
+        s_qy[i] = ql - 1; s_qx[i] = qx - 1;                                  // source cell relative to the tile origin
+        s_dlt[i] = (int32_t)((((int64_t)(ql - 1)) * p.sH + (int64_t)(qx - 1) * p.sW) * 2) + c * 16;
+        s_ok[i] = (piece < NPP && qx < TW + 2 && (k0 + c * 8) < p.C) ? 1u : 0u;
+        s_lds[i] = (uint32_t)((ql * LP + cg * 8) * RB);
+    }
+    // tile coordinates of the NEXT stage to be issued (tile index tbeg + issued)
+    int tx, ty, td, tb;
+    {
+        int64_t t = tbeg;
+        tx = (int)(t % p.tiles_x); t /= p.tiles_x;
+        ty = (int)(t % p.tiles_y); t /= p.tiles_y;
+        td = (int)(t % p.Dr);
+        tb = (int)(t / p.Dr);
+    }
+    auto stage = [&](int buf) {
         const int y0 = ty * TH, x0 = tx * TW;
-        const int sd = d * p.mulD + kd - p.padD;
+        const int sd = td * p.mulD + kd - p.padD;
         const bool plane_ok = (unsigned)sd < (unsigned)p.Ds;  // block-uniform
+        const uint32_t rbase = (uint32_t)(((int64_t)tb * p.rB + (int64_t)td * p.rD + (int64_t)y0 * p.rH + (int64_t)x0 * p.rW) * 2);
+        const uint32_t sbase = (uint32_t)(((int64_t)tb * p.sB + (int64_t)sd * p.sD + (int64_t)y0 * p.sH + (int64_t)x0 * p.sW) * 2);
         char *ln = smem + buf * STAGE + wave * 1024;
 #pragma unroll
         for (int i = 0; i < IN; ++i) {
-            const int r = (i * 4 + wave) * 8 + lane / 8;                     // site 0..63
-            const int c = (lane % 8) ^ chunk_swz<RB, false>(r);
-            const int oy = y0 + (r >> 4), ox = x0 + (r & 15);
-            const bool ok = plane_ok && oy < p.Hr && ox < p.Wr && (n0 + c * 8) < p.N;
-            const uint32_t ro = (uint32_t)(((int64_t)b * p.rB + (int64_t)d * p.rD + (int64_t)oy * p.rH + (int64_t)ox * p.rW) * 2);
-            lds_dma16(rs_r, ln + i * 4096, ok ? ro + (uint32_t)c * 16u : WG_OOB, r_col);
+            const bool ok = plane_ok && r_chunk[i] && y0 + r_py[i] < p.Hr && x0 + r_px[i] < p.Wr;
+            lds_dma16(rs_r, ln + i * 4096, ok ? rbase + r_dlt[i] : WG_OOB, r_col);
         }
         char *lp = smem + buf * STAGE + TILE_N;
 #pragma unroll
-        for (int i = 0; i < (NPP + 3) / 4; ++i) {
-            const int piece = i * 4 + wave;
-            if (piece >= NPP) break;
-            const int ql = piece / 3, cg = piece - ql * 3;
-            const int qx = cg * 8 + lane / 8;                                // column inside the line (0..23; 18.. unused)
-            const int prow = ql * LP + qx;
-            const int c = (lane % 8) ^ chunk_swz<RB, false>(prow);
-            const int sy = y0 - 1 + ql, sx = x0 - 1 + qx;
-            const bool ok = plane_ok && qx < TW + 2 && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws &&
-                            (k0 + c * 8) < p.C;
-            const uint32_t so = (uint32_t)(((int64_t)b * p.sB + (int64_t)sd * p.sD + (int64_t)sy * p.sH + (int64_t)sx * p.sW) * 2);
-            lds_dma16(rs_s, lp + (ql * LP + cg * 8) * RB, ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
+        for (int i = 0; i < IPP; ++i) {
+            if (i * 4 + wave >= NPP) break;
+            const bool ok = plane_ok && s_ok[i] && (unsigned)(y0 + s_qy[i]) < (unsigned)p.Hs &&
+                            (unsigned)(x0 + s_qx[i]) < (unsigned)p.Ws;
+            lds_dma16(rs_s, lp + s_lds[i], ok ? sbase + (uint32_t)s_dlt[i] : WG_OOB, s_col);
+        }
+        // advance to the next tile
+        if (++tx == p.tiles_x) {
+            tx = 0;
+            if (++ty == p.tiles_y) {
+                ty = 0;
+                if (++td == p.Dr) { td = 0; ++tb; }
+            }
         }
     };
 
-    f32x4_t acc[9][2][2];
+    f32x4_t acc[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < 4; ++i) acc[t][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // transposed-read lane geometry: lane = 16g + 4q + pp -> site (ks*32 + 8g + q [+4]), 8-B piece pp of a 16-column tile
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
     // rows tile: sites r0 = ks*32 + 8g + q and r0 + 4 (ks*32 rows = ks*4096 B: an immediate)
-    int aoff[2][2];
+    int aoff[4][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int col = (wn * 2 + i) * 16 + pp * 4, c16 = col >> 3, half = (col >> 2) & 1;
+    for (int i = 0; i < 4; ++i) {
+        const int col = i * 16 + pp * 4, c16 = col >> 3, half = (col >> 2) & 1;
         const int r0 = g * 8 + q;
         aoff[i][0] = r0 * RB + ((c16 ^ chunk_swz<RB, false>(r0)) << 4) + half * 8;
         aoff[i][1] = (r0 + 4) * RB + ((c16 ^ chunk_swz<RB, false>(r0 + 4)) << 4) + half * 8;
     }
     // patch: site (line ks*2 + (g>>1), column (g&1)*8 + q [+4]) shifted by tap (th, tw) -> patch row (line + th)*32 + col + tw
-    int boff[3][2][2];
+    int boff[3][2];
 #pragma unroll
     for (int tw = 0; tw < 3; ++tw)
 #pragma unroll
         for (int wq = 0; wq < 2; ++wq) {
             const int colw = (g & 1) * 8 + q + tw + 4 * wq;
             const int sw = chunk_swz<RB, false>(colw);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = (wk * 2 + j) * 16 + pp * 4, c16 = col >> 3, half = (col >> 2) & 1;
-                boff[tw][wq][j] = ((g >> 1) * LP + colw) * RB + ((c16 ^ sw) << 4) + half * 8;
-            }
+            const int col = wk * 16 + pp * 4, c16 = col >> 3, half = (col >> 2) & 1;
+            boff[tw][wq] = ((g >> 1) * LP + colw) * RB + ((c16 ^ sw) << 4) + half * 8;
         }
 
-    stage(0, 0);
+    stage(0);
     for (int s = 0; s < nst; ++s) {
         const int buf = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < nst) stage(s + 1, buf ^ 1);
+        if (s + 1 < nst) stage(buf ^ 1);
         const char *ln = smem + buf * STAGE;
         const char *lp = ln + TILE_N;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t a[2];
+            bf16x8_t a[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ln + ks * 32 * RB + aoff[i][0]));
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ln + ks * 32 * RB + aoff[i][1]));
                 a[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
@@ -467,18 +496,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
             for (int t = 0; t < 9; ++t) {
                 const int th = t / 3, tw = t % 3;
                 const char *lt = lp + (ks * 2 + th) * LP * RB;               // compile-time offset
-                bf16x8_t bq[2];
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(lt + boff[tw][0]));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(lt + boff[tw][1]));
+                const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(lt + boff[tw][0][j]));
-                    const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(lt + boff[tw][1][j]));
-                    bq[j] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[t][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq[j], acc[t][i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq, acc[t][i], 0, 0, 0);
             }
         }
     }
@@ -487,16 +509,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + wk * 16 + (lane & 15);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int k = k0 + (wk * 2 + j) * 16 + (lane & 15);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int n = n0 + (wn * 2 + i) * 16 + (lane >> 4) * 4 + e;
-                    if (n < p.N && k < p.C) dst[((int64_t)(kd * 9 + t) * p.N + n) * p.C + k] = acc[t][i][j][e];
-                }
+            for (int e = 0; e < 4; ++e) {
+                const int n = n0 + i * 16 + (lane >> 4) * 4 + e;
+                if (n < p.N && k < p.C) dst[((int64_t)(kd * 9 + t) * p.N + n) * p.C + k] = acc[t][i][e];
             }
+        }
 }
 
 template <int TN, int TK, bool F32, int TPB>
