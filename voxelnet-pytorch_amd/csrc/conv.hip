@@ -552,12 +552,15 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    auto stage_b = [&](int id, int ih, int iw, int kc, int buf) {
-        const GGTap tp = p.taps[cl.tap_begin + (id * cl.nH + ih) * cl.nW + iw];
+    // H/W have one class and their taps in kernel order (div 1), so the weight index of tap (id, ih, iw) is that of
+    // (id, 0, 0) plus ih*3 + iw: one scalar load per depth tap, none inside the tap loop
+    const uint32_t tap_bytes = (uint32_t)p.N * (uint32_t)p.Cs * (uint32_t)ESZ;
+    auto wbase_of = [&](int id) { return p.taps[cl.tap_begin + id * 9].widx; };
+    auto stage_b = [&](int wbase, int tap, int kc, int buf) {
         const int k_lane = kc * BKE + k_lane0;
         const bool k_ok = k_lane < p.Cs;
         const uint32_t b_koff = (uint32_t)k_lane * (uint32_t)ESZ;
-        const uint32_t b_soff = __builtin_amdgcn_readfirstlane((uint32_t)((int64_t)tp.widx * p.N * p.Cs * ESZ));
+        const uint32_t b_soff = __builtin_amdgcn_readfirstlane((uint32_t)(wbase + tap) * tap_bytes);
         char *lb = bst + buf * B_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -578,11 +581,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
     for (int id = 0; id < cl.nD; ++id) {
         const int sd = qd * p.mulD + cl.offD[id];
         if ((unsigned)sd >= (unsigned)p.Ds) continue;          // a padding plane: block-uniform skip
+        const int wbase = wbase_of(id);
         for (int kc = 0; kc < nk; ++kc) {
             // everyone is done with the previous patch (and the weight stage the first tap's loads go to)
             __syncthreads();
             stage_patch(sd, kc);
-            if (first) { stage_b(id, 0, 0, kc, bbuf); first = false; }
+            if (first) { stage_b(wbase, 0, kc, bbuf); first = false; }
             for (int tap = 0; tap < 9; ++tap) {
                 const int ih = tap / 3, iw = tap - ih * 3;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -590,7 +594,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
                 asm volatile("" ::: "memory");
                 // next weight tile: next tap, or the first tap of the next (plane, chunk)
                 if (tap < 8) {
-                    stage_b(id, (tap + 1) / 3, (tap + 1) % 3, kc, bbuf ^ 1);
+                    stage_b(wbase, tap + 1, kc, bbuf ^ 1);
                 } else {
                     int nid = id, nkc = kc + 1;
                     if (nkc == nk) {
@@ -598,7 +602,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
                         for (nid = id + 1; nid < cl.nD; ++nid)
                             if ((unsigned)(qd * p.mulD + cl.offD[nid]) < (unsigned)p.Ds) break;
                     }
-                    if (nid < cl.nD) stage_b(nid, 0, 0, nkc, bbuf ^ 1);
+                    if (nid < cl.nD) stage_b(nid == id ? wbase : wbase_of(nid), 0, nkc, bbuf ^ 1);
                 }
                 const int shift = cl.offH[ih] * PW + cl.offW[iw];
                 const char *lb = bst + bbuf * B_BYTES + wn * (64 * 128);
