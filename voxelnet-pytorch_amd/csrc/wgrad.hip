@@ -558,10 +558,12 @@ static WGPlan wgrad_plan(const vnConv *g, int32_t split, int64_t M) {
     w.tiles_k = (int)vn_ceil_div(g->Cs, w.k128 ? 128 : 64);
     w.groups = w.tri ? taps / 3 : taps;
     w.dw_elems = (int64_t)taps * g->Cr * g->Cs;
-    // ~512 workgroups (one round at two resident workgroups per CU) and at least 10 slabs of 64 sites per chunk:
-    // measured on block1 / block2 / the Conv3d layers, more chunks only add partial-tile traffic (each chunk
-    // stores DN x DK x taps fp32 and the reduction reads it back), fewer leave CUs idle
-    int64_t chunks = 512 / ((int64_t)w.groups * w.tiles_n * w.tiles_k);
+    // ~256 workgroups (one per CU; the data-gradient launches of the main stream run beside them) and at least 10
+    // slabs of 64 sites per chunk: more chunks only add partial-tile traffic (each chunk stores DN x DK x taps fp32
+    // and the batched unpack reads it back), fewer leave CUs idle.  Measured in the full step: 128 / 192 / 256 / 384 /
+    // 512 / 768 workgroups -> 357 / 368 / 373 / 370 / 368 / 364 point-clouds/s.
+    static const int target = [] { const char *e = getenv("VN_WG_BLOCKS"); return e && *e ? atoi(e) : 256; }();   // tuning aid
+    int64_t chunks = target / ((int64_t)w.groups * w.tiles_n * w.tiles_k);
     const int64_t slabs = vn_ceil_div(M, 64);
     if (chunks > slabs / 10) chunks = slabs / 10;
     if (chunks > 256) chunks = 256;
