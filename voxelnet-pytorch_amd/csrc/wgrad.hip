@@ -600,7 +600,10 @@ static WPPlan wgrad_patch_plan(const vnConv *g, int32_t split, bool list) {
     w.tiles_n = (int)vn_ceil_div(g->Cr, 64);
     w.tiles_k = (int)vn_ceil_div(g->Cs, 64);
     w.ntiles = (int64_t)g->B * g->Dr * w.tiles_y * w.tiles_x;
-    int64_t chunks = 512 / ((int64_t)g->kD * w.tiles_n * w.tiles_k);
+    // (one workgroup per CU: in the step these launches run on the side stream beside the data gradients;
+    //  128 ... 512 workgroups measure within 1 %, 768 is 3 % slower)
+    static const int ptarget = [] { const char *e = getenv("VN_WGP_BLOCKS"); return e && *e ? atoi(e) : 256; }();   // tuning aid
+    int64_t chunks = ptarget / ((int64_t)g->kD * w.tiles_n * w.tiles_k);
     if (chunks > w.ntiles / 8) chunks = w.ntiles / 8;
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
