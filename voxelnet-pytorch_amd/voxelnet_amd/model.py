@@ -573,7 +573,10 @@ def _detector_backward_native(ctx, d_prob, d_reg):
         table = N.layer_table(mid._block1_stride)
         order = [22] + list(range(21, 15, -1)) + [15] + list(range(14, 8, -1)) + [8] + list(range(7, 2, -1)) + [2, 1, 0]
         side = rpn._side_stream(dev) if rpn.overlap_wgrad else None
-        for sb, se in NATIVE_SEGMENTS:
+        # one segment per DDP bucket when gradients are all-reduced while the backward runs; else a single call
+        # (fewer fork/join points for the side stream, one unpack launch)
+        segments = NATIVE_SEGMENTS if red is not None else [(0, 24)]
+        for sb, se in segments:
             _lib.call("vn_net_backward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
                       prob.data_ptr(), dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K,
                       ws.data_ptr(), ws_bytes, garr,
