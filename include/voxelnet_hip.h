@@ -293,6 +293,9 @@ typedef struct {
     int32_t mode;            /* 0 bf16, 1 fp32 */
     int32_t training;        /* BatchNorm: batch statistics + running-stat update, or running statistics */
     int32_t sparse_first;
+    int32_t defer_join;      /* backward with a side stream: the last segment does NOT wait for the side stream; the
+                              * weight-gradient unpack runs there and the CALLER joins it (stream wait) before anything
+                              * reads the weight gradients — lets e.g. the VFE backward run beside the last weight gradients */
 } vnNetConfig;
 typedef struct {
     const float *weight, *bias, *gamma, *beta;

@@ -609,6 +609,15 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         RT(vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr,
                                stream));
     }
+    if (ws != hs && cfg->defer_join && seg_end == NL + 1) {
+        // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream
+        RT(vn_unpack_wgrads_batch(unpack, nu, wstream));
+        if (zj.n > 0) {
+            k_zero_many<<<zj.n, 256, 0, ws>>>(zj);
+            VN_LAUNCH_STATUS();
+        }
+        return VN_OK;
+    }
     if (ws != hs) {   // join: the segment's weight-gradient partials are complete before they are summed / unpacked
         hipEvent_t e = next_event();
         if (!e) return VN_EINVAL;

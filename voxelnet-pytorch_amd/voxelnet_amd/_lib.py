@@ -44,7 +44,7 @@ class VnVfeGrads(ctypes.Structure):
 
 
 class VnNetConfig(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("B", "D", "H", "W", "block1_stride", "mode", "training", "sparse_first")]
+    _fields_ = [(n, c_i32) for n in ("B", "D", "H", "W", "block1_stride", "mode", "training", "sparse_first", "defer_join")]
 
 
 class VnLayerParams(ctypes.Structure):

@@ -554,6 +554,14 @@ class _DetectorFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(vg) + tuple(_middle_grads_flat(names, G))
 
 
+def _split_heads_grads(views, dhw, dhb):
+    """fused (16,768) heads gradient -> prob_conv / reg_conv parameter gradients (model.py:276-279)"""
+    views["middle_rpn.prob_conv.conv.weight"].copy_(dhw[:2])
+    views["middle_rpn.prob_conv.conv.bias"].copy_(dhb[:2])
+    views["middle_rpn.reg_conv.conv.weight"].copy_(dhw[2:])
+    views["middle_rpn.reg_conv.conv.bias"].copy_(dhb[2:])
+
+
 def _detector_backward_native(ctx, d_prob, d_reg):
     feature, coord, stats, wst, vparams, nat, _, _ = ctx.saved
     cfg, ws, ws_bytes, dense, vw_rows, heads, prob = nat
@@ -576,16 +584,16 @@ def _detector_backward_native(ctx, d_prob, d_reg):
         # one segment per DDP bucket when gradients are all-reduced while the backward runs; else a single call
         # (fewer fork/join points for the side stream, one unpack launch)
         segments = NATIVE_SEGMENTS if red is not None else [(0, 24)]
+        # without a reducer the last weight gradients (side stream) may still run while the VFE backward goes on:
+        # the executor leaves the join to us (cfg.defer_join), we wait for the side stream after featnet_backward
+        cfg.defer_join = int(side is not None and red is None)
         for sb, se in segments:
             _lib.call("vn_net_backward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
                       prob.data_ptr(), dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K,
                       ws.data_ptr(), ws_bytes, garr,
                       dhw.data_ptr(), dhb.data_ptr(), d_in.data_ptr(), sb, se, E.stream(), side)
-            if sb == 0:
-                views["middle_rpn.prob_conv.conv.weight"].copy_(dhw[:2])
-                views["middle_rpn.prob_conv.conv.bias"].copy_(dhb[:2])
-                views["middle_rpn.reg_conv.conv.weight"].copy_(dhw[2:])
-                views["middle_rpn.reg_conv.conv.bias"].copy_(dhb[2:])
+            if sb == 0 and not cfg.defer_join:
+                _split_heads_grads(views, dhw, dhb)
             if red is not None:
                 names = []
                 if sb == 0:
@@ -604,6 +612,9 @@ def _detector_backward_native(ctx, d_prob, d_reg):
         if not cfg.sparse_first:
             d_vw = gather_rows(Rows(d_in, 128), coord, K, 128)
         vg = featnet_backward(feature, wst, stats, d_vw, vparams, out=[views[k] for k in VFE_KEYS])
+        if cfg.defer_join:
+            torch.cuda.current_stream().wait_stream(rpn.__dict__["_side"])
+            _split_heads_grads(views, dhw, dhb)      # (dhw is written by the unpack, which ran on the side stream)
         if red is not None:
             for n in last_names + VFE_KEYS:
                 red.grad_ready(n, views[n])
