@@ -525,9 +525,8 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     order[n++] = L_D2; for (int l = L_D2 - 1; l >= L_B2; --l) order[n++] = l;
     order[n++] = L_D1; for (int l = L_D1 - 1; l >= L_B1; --l) order[n++] = l;
     order[n++] = 2; order[n++] = 1; order[n++] = 0;
-    for (int oi = 0; oi < NL; ++oi) {
-        if (oi + 1 < seg_begin || oi + 1 >= seg_end) continue;
-        const int l = order[oi];
+    // one layer of the backward: BatchNorm backward and data gradient on `ls`, weight gradient on the side stream
+    auto do_layer = [&](int l, vnStream ls, bool on_side, bool accumulate) -> int {
         const Spec &sp = P.spec[l];
         const int taps = sp.k[0] * sp.k[1] * sp.k[2];
         const int C = sp.cout;
@@ -550,26 +549,26 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                 for (int d = 0; d < 2; ++d)
                     RT(vn_bn_bwd_reduce(da.ptr + ((size_t)b * H * W * 128 + d * 64) * des, (vnDtype)da.dtype, 128,
                                         y.ptr + (size_t)(b * 2 + d) * H * W * 64 * yes, (vnDtype)y.dtype, 64,
-                                        (int64_t)H * W, 64, P.stats[l], 1, P.bsums[l], stream));
-            RT(vn_bn_bwd_finalize(P.bsums[l], M, C, 1, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma, G[l].beta, stream));
+                                        (int64_t)H * W, 64, P.stats[l], 1, P.bsums[l], ls));
+            RT(vn_bn_bwd_finalize(P.bsums[l], M, C, 1, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma, G[l].beta, ls));
             for (int b = 0; b < B; ++b)
                 for (int d = 0; d < 2; ++d)
                     RT(vn_bn_bwd_apply(da.ptr + ((size_t)b * H * W * 128 + d * 64) * des, (vnDtype)da.dtype, 128,
                                        y.ptr + (size_t)(b * 2 + d) * H * W * 64 * yes, (vnDtype)y.dtype, 64,
                                        (int64_t)H * W, 64, P.stats[l], P.coef[l], 1,
-                                       dy.ptr + (size_t)(b * 2 + d) * H * W * 64 * P.esz, (vnDtype)dy.dtype, 64, 0, stream));
+                                       dy.ptr + (size_t)(b * 2 + d) * H * W * 64 * P.esz, (vnDtype)dy.dtype, 64, 0, ls));
         } else {
             RT(vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
-                                     P.bslab[l], stream));
+                                     P.bslab[l], ls));
             RT(vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
-                                       G[l].beta, stream));
+                                       G[l].beta, ls));
             if (l == 0 && cfg->sparse_first)   // dy is only gathered at the active sites (flags: the forward's vn_active_sites)
                 RT(vn_bn_bwd_apply_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
                                            P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW,
-                                           static_cast<const uint8_t *>(P.aws), stream));
+                                           static_cast<const uint8_t *>(P.aws), ls));
             else
                 RT(vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
-                                   P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, stream));
+                                   P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, ls));
         }
         zj.ptr[zj.n] = G[l].bias; zj.len[zj.n] = C; ++zj.n;          // bias before a train-mode BN: gradient exactly 0
         int32_t wch = 1;
@@ -579,16 +578,16 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
-            RT(fork());
+            if (!on_side) RT(fork());
             RT(vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
             RT(vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr,
-                                        stream));
-            continue;
+                                        ls));
+            return VN_OK;
         }
         // weight gradient
         const vnConv gw = wgrad_geom(P, l, x);
-        RT(fork());
+        if (!on_side) RT(fork());
         if (sp.transposed) {
             RT(vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, wch, dw_elems};
@@ -599,15 +598,42 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         // data gradient
         Rows dx = P.dx[l];
         if (l == 0) {
-            if (!d_input) continue;
+            if (!d_input) return VN_OK;
             dx = dense_rows(d_input, P.pdt, B, cfg->D, cfg->H, cfg->W, 128);
         }
-        const bool accumulate = (l == L_D1 || l == L_D2);
         const int64_t os[4] = {dx.sB, dx.sD, dx.sH, dx.sW};
         vnConv gd = sp.transposed ? geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, os)
                                   : geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, os);
         RT(vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr,
-                               stream));
+                               ls));
+        return VN_OK;
+    };
+    // Single-call backward with a side stream: deconv2 / deconv1 only depend on the heads' data gradient, so their
+    // whole backward is issued first, on the side stream, and overlaps the block3 / block2 chains (50x44 and 100x88
+    // images: under-filled launches).  Their data gradient then WRITES the shared buffer and the strided block3.0 /
+    // block2.0 data gradient accumulates into it (instead of the other way round).
+    static const int early_on = [] { const char *e = getenv("VN_EARLY_DECONV"); return e && *e ? atoi(e) : 1; }();   // tuning aid
+    const bool early = early_on && ws != hs && seg_begin == 0 && seg_end == NL + 1;
+    hipEvent_t ev_d2 = nullptr, ev_d1 = nullptr;
+    if (early) {
+        RT(fork());
+        RT(do_layer(L_D2, wstream, true, false));
+        ev_d2 = next_event();
+        if (!ev_d2) return VN_EINVAL;
+        VN_HIP(hipEventRecord(ev_d2, ws));
+        RT(do_layer(L_D1, wstream, true, false));
+        ev_d1 = next_event();
+        if (!ev_d1) return VN_EINVAL;
+        VN_HIP(hipEventRecord(ev_d1, ws));
+    }
+    for (int oi = 0; oi < NL; ++oi) {
+        if (oi + 1 < seg_begin || oi + 1 >= seg_end) continue;
+        const int l = order[oi];
+        if (early && (l == L_D2 || l == L_D1)) continue;
+        bool accumulate = (l == L_D1 || l == L_D2);
+        if (early && l == L_B3) { VN_HIP(hipStreamWaitEvent(hs, ev_d2, 0)); accumulate = true; }
+        if (early && l == L_B2) { VN_HIP(hipStreamWaitEvent(hs, ev_d1, 0)); accumulate = true; }
+        RT(do_layer(l, stream, false, accumulate));
     }
     if (ws != hs && cfg->defer_join && seg_end == NL + 1) {
         // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream
