@@ -293,6 +293,8 @@ typedef struct {
     int32_t mode;            /* 0 bf16, 1 fp32 */
     int32_t training;        /* BatchNorm: batch statistics + running-stat update, or running statistics */
     int32_t sparse_first;
+    int32_t prepared;        /* forward: vn_net_prepare has already been issued for this step (weights packed, first layer's
+                              * site list / index grid / bias fill done) and the caller has ordered it before this call */
     int32_t defer_join;      /* backward with a side stream: the last segment does NOT wait for the side stream; the
                               * weight-gradient unpack runs there and the CALLER joins it (stream wait) before anything
                               * reads the weight gradients — lets e.g. the VFE backward run beside the last weight gradients */
@@ -305,6 +307,11 @@ typedef struct {
     float *weight, *bias, *gamma, *beta;   /* overwritten */
 } vnLayerGrads;
 size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K);
+/* The part of the forward that does not depend on the voxel features (weight packing; sparse first layer: active
+ * sites, voxel index grid, bias fill): may be issued on another stream while the VFE forward runs; then set
+ * cfg->prepared for vn_net_forward and make its stream wait for this one. */
+int vn_net_prepare(const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
+                   const int64_t *coord, int64_t K, void *workspace, size_t workspace_bytes, vnStream stream);
 int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,
                    const float *heads_w /*[16,768]*/, const float *heads_b /*[16]*/,
                    const void *dense, const int64_t *coord, const void *vw_rows /* (K,128) voxel rows in the operand dtype, sparse_first only */, int64_t K, void *workspace,

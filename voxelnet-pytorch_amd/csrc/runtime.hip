@@ -338,18 +338,13 @@ extern "C" size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K) {
     return P.bytes;
 }
 
-extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const float *heads_b,
-                              const void *dense, const int64_t *coord, const void *vw_rows, int64_t K, void *workspace,
-                              size_t workspace_bytes, float *prob, float *reg, vnStream stream, vnStream side_stream) {
-    VN_CHECK_ARG(cfg && L && heads_w && heads_b && workspace && prob && reg && K >= 0);
-    VN_CHECK_ARG(cfg->sparse_first ? (coord && vw_rows) : dense != nullptr);
-    Plan P;
-    if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
-    if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
-    hipStream_t hs = vn_stream(stream);
+// Everything of the forward that does not depend on the voxel features: weight packing (all layers, both
+// orientations) and, for the sparse first layer, the active-site list, the voxel index grid and the bias fill of its
+// output.  vn_net_forward does it itself unless cfg->prepared says vn_net_prepare already did (on another stream,
+// beside the VFE forward).
+static int net_prepare(const vnNetConfig *cfg, const Plan &P, const vnLayerParams *L, const float *heads_w,
+                       const int64_t *coord, int64_t K, vnStream stream) {
     const int training = cfg->training;
-    const float mom = 0.1f, eps = 1e-5f;
-    if (P.zf_end > P.zf_begin) VN_HIP(hipMemsetAsync(P.zf_begin, 0, (size_t)(P.zf_end - P.zf_begin), hs));
     {   // every layer's weights -> MFMA operand layout, forward and (training) data-gradient orientation: one launch
         vnPackJob jobs[2 * NL + 2];
         int nj = 0;
@@ -367,6 +362,40 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
         if (training) jobs[nj++] = vnPackJob{heads_w, P.hwp_d, 16, 768, 1, 1, 0, 1, P.adt, 0};
         RT(vn_pack_weights_batch(jobs, nj, stream));
     }
+    if (cfg->sparse_first) {
+        const Spec &sp = P.spec[0];
+        const Rows &y = P.y[0];
+        const Rows xin = dense_rows(nullptr, P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
+        vnConv g = fwd_geom(sp, xin, P.odims[0], y);
+        RT(vn_fill_rows(y.ptr, (vnDtype)y.dtype, y.M(), sp.cout, sp.cout, L[0].bias, stream));
+        RT(vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
+        RT(vn_voxel_index_grid(coord, K, cfg->B, cfg->D, cfg->H, cfg->W, P.igrid, stream));
+    }
+    return VN_OK;
+}
+
+extern "C" int vn_net_prepare(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const int64_t *coord,
+                              int64_t K, void *workspace, size_t workspace_bytes, vnStream stream) {
+    VN_CHECK_ARG(cfg && L && heads_w && workspace && K >= 0 && (!cfg->sparse_first || coord));
+    Plan P;
+    if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
+    if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
+    return net_prepare(cfg, P, L, heads_w, coord, K, stream);
+}
+
+extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const float *heads_b,
+                              const void *dense, const int64_t *coord, const void *vw_rows, int64_t K, void *workspace,
+                              size_t workspace_bytes, float *prob, float *reg, vnStream stream, vnStream side_stream) {
+    VN_CHECK_ARG(cfg && L && heads_w && heads_b && workspace && prob && reg && K >= 0);
+    VN_CHECK_ARG(cfg->sparse_first ? (coord && vw_rows) : dense != nullptr);
+    Plan P;
+    if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
+    if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
+    hipStream_t hs = vn_stream(stream);
+    const int training = cfg->training;
+    const float mom = 0.1f, eps = 1e-5f;
+    if (P.zf_end > P.zf_begin) VN_HIP(hipMemsetAsync(P.zf_begin, 0, (size_t)(P.zf_end - P.zf_begin), hs));
+    if (!cfg->prepared) RT(net_prepare(cfg, P, L, heads_w, coord, K, stream));
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
     Rows x1{}, x2{};
     // deconv1 / deconv2 only feed the concat: with a side stream they run beside block2 / block3 (whose 100x88 and
@@ -391,11 +420,9 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
         vnConv g = fwd_geom(sp, x, P.odims[l], y);
         float *slab = training ? P.slab[l] : nullptr;
         if (l == 0 && cfg->sparse_first) {
-            RT(vn_fill_rows(y.ptr, (vnDtype)y.dtype, M, sp.cout, sp.cout, L[l].bias, stream));
-            RT(vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
+            // (bias fill of y, active-site list, voxel index grid: net_prepare)
             // rulebook: P[v][tap] = W[tap] . x[v] as ONE dense GEMM over the K voxel rows ([27*64][128] packed weights),
             // then every active site adds the P rows of its occupied source cells (no dense grid, no zero work)
-            RT(vn_voxel_index_grid(coord, K, cfg->B, cfg->D, cfg->H, cfg->W, P.igrid, stream));
             if (K > 0) {
                 vnConv q;
                 memset(&q, 0, sizeof(q));

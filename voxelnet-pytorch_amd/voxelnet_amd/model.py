@@ -468,10 +468,30 @@ class _DetectorFn(torch.autograd.Function):
         native = rpn.native_executor and not E.is_split(mode) and fn._grid.D == 10
         if native:
             with torch.cuda.device(feature.device):
+                dev_ = feature.device
+                sparse = bool(rpn.sparse_first_layer)
+                D, H, W = fn._grid.dims
+                K = feature.shape[0]
+                cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, 1 if mode == "fp32" else 0, int(training), int(sparse), 0, 0)
+                heads = _heads_params([f.detach() for f in flat[nv:]])
+                arr, _ = _native_layer_arrays(mid)
+                lib = _lib.load()
+                ws_bytes = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
+                if ws_bytes == 0:
+                    raise _lib.VoxelnetHipError("vn_net_workspace_bytes: unsupported network configuration")
+                ws = rpn._ws_acquire(ws_bytes, dev_)
+                side = rpn._side_stream(dev_) if rpn.overlap_wgrad else None
+                if side is not None:
+                    # what does not depend on the voxel features (weight packing, the first layer's site list / index
+                    # grid / bias fill) runs on the side stream beside the VFE forward
+                    side_t = rpn.__dict__["_side"]
+                    side_t.wait_stream(torch.cuda.current_stream())
+                    _lib.call("vn_net_prepare", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), coord.data_ptr(), K,
+                              ws.data_ptr(), ws_bytes, side)
+                    cfg.prepared = 1
                 vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
                 # With the sparse first Conv3d (rulebook evaluation: voxel rows x packed weights, then a gather-sum per
                 # active site) the dense (B,10,400,352,128) grid of model.py:102-106 is never built.
-                sparse = bool(rpn.sparse_first_layer)
                 dense = None if sparse else scatter_rows(vw, coord, B, fn._grid.dims, mode)
                 if mode == "fp32":
                     vw_rows = vw
@@ -479,24 +499,14 @@ class _DetectorFn(torch.autograd.Function):
                     vw_rows = torch.empty((vw.shape[0], 128), dtype=torch.bfloat16, device=vw.device)
                     _lib.call("vn_cast_rows", vw.data_ptr(), _lib.VN_F32, 128, vw.shape[0], 128, vw_rows.data_ptr(),
                               _lib.VN_BF16, 128, 0, E.stream())
-                D, H, W = fn._grid.dims
-                cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, 1 if mode == "fp32" else 0, int(training),
-                                       int(bool(rpn.sparse_first_layer)))
-                K = vw.shape[0]
-                heads = _heads_params([f.detach() for f in flat[nv:]])
-                arr, _ = _native_layer_arrays(mid)
-                lib = _lib.load()
-                ws_bytes = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
-                if ws_bytes == 0:
-                    raise _lib.VoxelnetHipError("vn_net_workspace_bytes: unsupported network configuration")
-                ws = rpn._ws_acquire(ws_bytes, vw.device)
+                if side is not None:
+                    torch.cuda.current_stream().wait_stream(side_t)
                 hf, wf = H // mid._block1_stride, W // mid._block1_stride
                 prob = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=vw.device)
                 reg = torch.empty((B, 14, hf, wf), dtype=torch.float32, device=vw.device)
                 _lib.call("vn_net_forward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), heads["bias"].data_ptr(),
                           dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K, ws.data_ptr(),
-                          ws_bytes, prob.data_ptr(), reg.data_ptr(), E.stream(),
-                          rpn._side_stream(vw.device) if rpn.overlap_wgrad else None)
+                          ws_bytes, prob.data_ptr(), reg.data_ptr(), E.stream(), side)
             ctx.saved = (feature, coord, stats, wst, vparams, (cfg, ws, ws_bytes, dense, vw_rows, heads, prob.detach()), None, None)
             # (prob.detach(): an alias — keeping the Function's own output on ctx would be a reference cycle)
             ctx.reducer = rpn.grad_reducer
