@@ -378,6 +378,16 @@ int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int64_t da_stride, const v
                     vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
                     const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
                     int64_t lo_off, vnStream stream);
+/* BEV-fold variants for the last Conv3d (model.py:262): y / dy are its plain (B*2*H*W, C=64) rows, a / da the
+ * (B,1,H,W,2C) tensor block1 sees (row stride wide_stride, channel = d*C + c).  hw = H*W.  One launch each. */
+int vn_bn_apply_bev(const void *y, vnDtype y_dtype, int64_t M, int32_t C, int64_t hw, const float *stats,
+                    int32_t relu, void *a, vnDtype a_dtype, int64_t wide_stride, vnStream stream);
+int vn_bn_bwd_reduce_slab_bev(const void *da, vnDtype da_dtype, int64_t wide_stride, const void *y,
+                              vnDtype y_dtype, int64_t M, int32_t C, int64_t hw, const float *stats,
+                              int32_t relu, float *slab, vnStream stream);
+int vn_bn_bwd_apply_bev(const void *da, vnDtype da_dtype, int64_t wide_stride, const void *y,
+                        vnDtype y_dtype, int64_t M, int32_t C, int64_t hw, const float *stats,
+                        const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, vnStream stream);
 /* Row-flag variant for the first middle layer: row_flags = the uint8 site flags vn_active_sites leaves at the head
  * of its workspace ((B,Dr,Hr,Wr) order, 1 = some occupied voxel in the receptive field).  Rows with flag 0 are
  * skipped: that layer's weight- and data-gradient (the row-list kernels) only gather dy at flagged sites. */

@@ -22,6 +22,13 @@ __device__ __forceinline__ void load8(const void *base, int dtype, int64_t off, 
     }
 }
 
+// BEV fold (model.py:262): the (B,2,H,W,64) conv output row m = ((b*2+d)*HW + r) lives at row (b*HW + r), channels
+// d*64.. of the (B,1,H,W,128) tensor the 2-D layers see.  fold = HW (0: no fold), wide = that tensor's row stride.
+__device__ __forceinline__ int64_t fold_off(int64_t m, int64_t fold, int64_t wide, int C) {
+    const int64_t seg = m / fold, r = m - seg * fold;
+    return ((seg >> 1) * fold + r) * wide + (seg & 1) * C;
+}
+
 __device__ __forceinline__ void store8(void *base, int dtype, int64_t lo_off, int64_t off, const float v[8]) {
     if (dtype == VN_F32) {
         float *d = static_cast<float *>(base) + off;
@@ -179,7 +186,7 @@ __global__ void __launch_bounds__(256) k_bn_finalize_slab(const float *__restric
 
 __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, int ydt, int64_t ystride, int64_t M, int C,
                                                   const float *__restrict__ stats, int relu, void *__restrict__ a,
-                                                  int adt, int64_t astride, int64_t lo_off) {
+                                                  int adt, int64_t astride, int64_t lo_off, int64_t fold) {
     const int groups = C >> 3;
     const int64_t total = M * groups;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -192,14 +199,14 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
             float z = fmaf(stats[2 * C + c + j], v[j] - stats[c + j], stats[3 * C + c + j]);
             v[j] = relu ? fmaxf(z, 0.f) : z;
         }
-        store8(a, adt, lo_off, m * astride + c, v);
+        store8(a, adt, lo_off, (fold ? fold_off(m, fold, astride, C) : m * astride) + c, v);
     }
 }
 
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ da, int dadt, int64_t dastride,
                                                        const void *__restrict__ y, int ydt, int64_t ystride, int64_t M,
                                                        int C, const float *__restrict__ stats, int relu,
-                                                       double *__restrict__ sums, float *__restrict__ slab) {
+                                                       double *__restrict__ sums, float *__restrict__ slab, int64_t fold) {
     const int groups = C >> 3, rpb = 256 / groups;
     const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
     float mean[8], invstd[8], S[8], be[8];
@@ -213,7 +220,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
         for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
             float yv[8], dv[8];
             load8(y, ydt, m * ystride + g * 8, yv);
-            load8(da, dadt, m * dastride + g * 8, dv);
+            load8(da, dadt, (fold ? fold_off(m, fold, dastride, C) : m * dastride) + g * 8, dv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d0 = yv[j] - mean[j];
@@ -289,7 +296,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const void *__restrict__ d
                                                       int C, const float *__restrict__ stats,
                                                       const float *__restrict__ coef, int relu, void *__restrict__ dy,
                                                       int dydt, int64_t dystride, int64_t lo_off,
-                                                      const uint8_t *__restrict__ flags) {
+                                                      const uint8_t *__restrict__ flags, int64_t fold) {
     // flags != NULL: rows with flag 0 are skipped (their dy is never read by the caller's consumers)
     const int groups = C >> 3;
     if (256 % groups == 0) {
@@ -305,7 +312,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const void *__restrict__ d
             if (flags && !flags[m]) continue;
             float yv[8], dv[8], o[8];
             load8(y, ydt, m * ystride + c, yv);
-            load8(da, dadt, m * dastride + c, dv);
+            load8(da, dadt, (fold ? fold_off(m, fold, dastride, C) : m * dastride) + c, dv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float d0 = yv[j] - mean[j];
@@ -324,7 +331,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const void *__restrict__ d
         const int c = (int)(i - m * groups) << 3;
         float yv[8], dv[8], o[8];
         load8(y, ydt, m * ystride + c, yv);
-        load8(da, dadt, m * dastride + c, dv);
+        load8(da, dadt, (fold ? fold_off(m, fold, dastride, C) : m * dastride) + c, dv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float d0 = yv[j] - stats[c + j];
@@ -384,7 +391,7 @@ extern "C" int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t y_stride, int
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(y && a && stats);
     k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
-                                                                                   relu, a, (int)a_dtype, a_stride, lo_off);
+                                                                                   relu, a, (int)a_dtype, a_stride, lo_off, 0);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -398,7 +405,7 @@ extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_str
     const int rpb = 256 / (C >> 3);
     k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
-                                                                                 relu, sums, nullptr);
+                                                                                 relu, sums, nullptr, 0);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -415,7 +422,7 @@ extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t d
     const int rpb = 256 / (C >> 3);
     k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
-                                                                                 relu, nullptr, slab);
+                                                                                 relu, nullptr, slab, 0);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -448,7 +455,7 @@ extern "C" int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int64_t da_stri
     VN_CHECK_ARG(da && y && stats && coef && dy);
     k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * 4, 8192), 256, 0, vn_stream(stream)>>>(
         da, (int)da_dtype, da_stride, y, (int)y_dtype, y_stride, M, C, stats, coef, relu, dy, (int)dy_dtype, dy_stride,
-        lo_off, nullptr);
+        lo_off, nullptr, 0);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -464,7 +471,43 @@ extern "C" int vn_bn_bwd_apply_flagged(const void *da, vnDtype da_dtype, int64_t
     VN_CHECK_ARG(da && y && stats && coef && dy && row_flags);
     k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * 4, 8192), 256, 0, vn_stream(stream)>>>(
         da, (int)da_dtype, da_stride, y, (int)y_dtype, y_stride, M, C, stats, coef, relu, dy, (int)dy_dtype, dy_stride, 0,
-        row_flags);
+        row_flags, 0);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+// ---- BEV-fold variants for the last Conv3d (model.py:262: its (B,2,H,W,64) output is the (B,1,H,W,128) input of
+// block1, channel = d*64 + c): ONE launch each instead of one per (batch, depth) slice.  `hw` = H*W; the folded
+// tensor (a / da) has row stride wide_stride (= 128); y / dy are the plain (B*2*H*W, 64) rows.
+extern "C" int vn_bn_apply_bev(const void *y, vnDtype y_dtype, int64_t M, int32_t C, int64_t hw, const float *stats,
+                               int32_t relu, void *a, vnDtype a_dtype, int64_t wide_stride, vnStream stream) {
+    VN_CHECK_ARG(M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
+    VN_CHECK_ARG(y && a && stats);
+    k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, C, M, C, stats, relu, a,
+                                                                                   (int)a_dtype, wide_stride, 0, hw);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_bwd_reduce_slab_bev(const void *da, vnDtype da_dtype, int64_t wide_stride, const void *y,
+                                         vnDtype y_dtype, int64_t M, int32_t C, int64_t hw, const float *stats,
+                                         int32_t relu, float *slab, vnStream stream) {
+    VN_CHECK_ARG(slab && M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
+    VN_CHECK_ARG(da && y && stats);
+    const int rpb = 256 / (C >> 3);
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, wide_stride, y, (int)y_dtype,
+                                                                                 C, M, C, stats, relu, nullptr, slab, hw);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_bn_bwd_apply_bev(const void *da, vnDtype da_dtype, int64_t wide_stride, const void *y, vnDtype y_dtype,
+                                   int64_t M, int32_t C, int64_t hw, const float *stats, const float *coef, int32_t relu,
+                                   void *dy, vnDtype dy_dtype, vnStream stream) {
+    VN_CHECK_ARG(M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
+    VN_CHECK_ARG(da && y && stats && coef && dy);
+    k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * 4, 8192), 256, 0, vn_stream(stream)>>>(
+        da, (int)da_dtype, wide_stride, y, (int)y_dtype, C, M, C, stats, coef, relu, dy, (int)dy_dtype, C, 0, nullptr, hw);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -449,13 +449,9 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
                               L[l].running_mean, L[l].running_var, training, mom, eps, P.stats[l], stream));
         }
         const Rows &a = P.a[l];
-        if (l == L_M2) {
-            const int H = P.odims[l][1], W = P.odims[l][2];
-            for (int b = 0; b < cfg->B; ++b)
-                for (int d = 0; d < 2; ++d)
-                    RT(vn_bn_apply(y.ptr + ((size_t)(b * 2 + d) * H * W * 64) * (y.dtype == VN_F32 ? 4 : 2),
-                                   (vnDtype)y.dtype, 64, (int64_t)H * W, 64, P.stats[l], 1,
-                                   a.ptr + ((size_t)b * H * W * 128 + d * 64) * P.esz, (vnDtype)a.dtype, 128, 0, stream));
+        if (l == L_M2) {   // BEV fold: channel d*64 + c of the (B,1,H,W,128) activation
+            RT(vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], 1, a.ptr,
+                               (vnDtype)a.dtype, 128, stream));
         } else {
             RT(bn_apply_rows(y, P.stats[l], a, sp.cout, stream));
         }
@@ -570,20 +566,13 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         else da = P.dx[l + 1];
         const Rows &dy = P.dy[l];
         if (l == L_M2) {   // da is the BEV gradient (B,1,H,W,128): channel d*64+c
-            const int H = P.odims[l][1], W = P.odims[l][2];
-            const size_t des = da.dtype == VN_F32 ? 4 : 2, yes = y.dtype == VN_F32 ? 4 : 2;
-            for (int b = 0; b < B; ++b)
-                for (int d = 0; d < 2; ++d)
-                    RT(vn_bn_bwd_reduce(da.ptr + ((size_t)b * H * W * 128 + d * 64) * des, (vnDtype)da.dtype, 128,
-                                        y.ptr + (size_t)(b * 2 + d) * H * W * 64 * yes, (vnDtype)y.dtype, 64,
-                                        (int64_t)H * W, 64, P.stats[l], 1, P.bsums[l], ls));
-            RT(vn_bn_bwd_finalize(P.bsums[l], M, C, 1, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma, G[l].beta, ls));
-            for (int b = 0; b < B; ++b)
-                for (int d = 0; d < 2; ++d)
-                    RT(vn_bn_bwd_apply(da.ptr + ((size_t)b * H * W * 128 + d * 64) * des, (vnDtype)da.dtype, 128,
-                                       y.ptr + (size_t)(b * 2 + d) * H * W * 64 * yes, (vnDtype)y.dtype, 64,
-                                       (int64_t)H * W, 64, P.stats[l], P.coef[l], 1,
-                                       dy.ptr + (size_t)(b * 2 + d) * H * W * 64 * P.esz, (vnDtype)dy.dtype, 64, 0, ls));
+            const int64_t hw = (int64_t)P.odims[l][1] * P.odims[l][2];
+            RT(vn_bn_bwd_reduce_slab_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], 1,
+                                         P.bslab[l], ls));
+            RT(vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
+                                       G[l].beta, ls));
+            RT(vn_bn_bwd_apply_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], P.coef[l], 1,
+                                   dy.ptr, (vnDtype)dy.dtype, ls));
         } else {
             RT(vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
                                      P.bslab[l], ls));

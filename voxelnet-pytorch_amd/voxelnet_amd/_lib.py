@@ -114,6 +114,9 @@ SIGNATURES = {
     "vn_bn_bwd_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vn_bn_bwd_apply": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp,
                                 c_i32, c_i64, c_i64, c_vp]),
+    "vn_bn_apply_bev": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
+    "vn_bn_bwd_reduce_slab_bev": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp]),
+    "vn_bn_bwd_apply_bev": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
     "vn_bn_bwd_apply_flagged": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32,
                                         c_i64, c_vp, c_vp]),
     "vn_nchw_to_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_vp]),
