@@ -548,6 +548,43 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     order[n++] = L_D2; for (int l = L_D2 - 1; l >= L_B2; --l) order[n++] = l;
     order[n++] = L_D1; for (int l = L_D1 - 1; l >= L_B1; --l) order[n++] = l;
     order[n++] = 2; order[n++] = 1; order[n++] = 0;
+    // weight gradient of layer l on the side stream (its dy exists in stream order of whoever calls this)
+    auto launch_wgrad = [&](int l) -> int {
+        const Spec &sp = P.spec[l];
+        const int taps = sp.k[0] * sp.k[1] * sp.k[2];
+        const int C = sp.cout;
+        const Rows &dy = P.dy[l];
+        int32_t wch = 1;
+        const int64_t dw_elems = (int64_t)taps * sp.cin * sp.cout;
+        if (l == 0 && cfg->sparse_first) {
+            const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
+            const int64_t rs[4] = {0, 0, 0, 128};
+            vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
+            RT(vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
+            return VN_OK;
+        }
+        const Rows x = input_of(l);
+        const vnConv gw = wgrad_geom(P, l, x);
+        if (sp.transposed) {
+            RT(vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, wch, dw_elems};
+        } else {
+            RT(vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, wch, dw_elems};
+        }
+        return VN_OK;
+    };
+    // Main-stream layers queue their weight gradient; flush() forks ONCE (an event record on the main stream costs a
+    // ~6 us bubble there: measured) and issues the queued ones on the side stream.  Flushed after every block chain.
+    int pending[NL], npend = 0;
+    auto flush = [&]() -> int {
+        if (npend == 0) return VN_OK;
+        RT(fork());
+        for (int i = 0; i < npend; ++i) RT(launch_wgrad(pending[i]));
+        npend = 0;
+        return VN_OK;
+    };
     // one layer of the backward: BatchNorm backward and data gradient on `ls`, weight gradient on the side stream
     auto do_layer = [&](int l, vnStream ls, bool on_side, bool accumulate) -> int {
         const Spec &sp = P.spec[l];
@@ -587,29 +624,16 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
                                    P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, ls));
         }
         zj.ptr[zj.n] = G[l].bias; zj.len[zj.n] = C; ++zj.n;          // bias before a train-mode BN: gradient exactly 0
-        int32_t wch = 1;
-        const int64_t dw_elems = (int64_t)taps * sp.cin * sp.cout;
-        const Rows x = input_of(l);
         const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
+        // weight gradient: at once when this layer runs on the side stream itself, else queued for the next flush
+        if (on_side) RT(launch_wgrad(l));
+        else pending[npend++] = l;
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
-            if (!on_side) RT(fork());
-            RT(vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
-            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
             RT(vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr,
                                         ls));
             return VN_OK;
-        }
-        // weight gradient
-        const vnConv gw = wgrad_geom(P, l, x);
-        if (!on_side) RT(fork());
-        if (sp.transposed) {
-            RT(vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
-            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, wch, dw_elems};
-        } else {
-            RT(vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
-            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, wch, dw_elems};
         }
         // data gradient
         Rows dx = P.dx[l];
@@ -650,7 +674,10 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         if (early && l == L_B3) { VN_HIP(hipStreamWaitEvent(hs, ev_d2, 0)); accumulate = true; }
         if (early && l == L_B2) { VN_HIP(hipStreamWaitEvent(hs, ev_d1, 0)); accumulate = true; }
         RT(do_layer(l, stream, false, accumulate));
+        // flush at the end of every block chain and after each Conv3d (their weight gradients are the long ones)
+        if (l == L_B3 || l == L_B2 || l == L_B1 || l <= L_M2) RT(flush());
     }
+    RT(flush());
     if (ws != hs && cfg->defer_join && seg_end == NL + 1) {
         // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream
         RT(vn_unpack_wgrads_batch(unpack, nu, wstream));
