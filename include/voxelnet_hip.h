@@ -295,6 +295,9 @@ typedef struct {
     int32_t sparse_first;
     int32_t prepared;        /* forward: vn_net_prepare has already been issued for this step (weights packed, first layer's
                               * site list / index grid / bias fill done) and the caller has ordered it before this call */
+    int32_t bucket_events;   /* single-call backward with a side stream: unpack each parameter group's weight gradients on the
+                              * side stream at the group's end and record "group final" events (vn_net_wait_bucket);
+                              * implies that the caller joins the side stream (as defer_join) */
     int32_t defer_join;      /* backward with a side stream: the last segment does NOT wait for the side stream; the
                               * weight-gradient unpack runs there and the CALLER joins it (stream wait) before anything
                               * reads the weight gradients — lets e.g. the VFE backward run beside the last weight gradients */
@@ -307,6 +310,9 @@ typedef struct {
     float *weight, *bias, *gamma, *beta;   /* overwritten */
 } vnLayerGrads;
 size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K);
+/* Make `stream` wait until parameter group `bucket` (0: heads+deconv3+block3, 1: deconv2+block2+deconv1, 2: block1,
+ * 3: middle_layer) of the most recent vn_net_backward issued with cfg->bucket_events has its final gradients. */
+int vn_net_wait_bucket(int32_t bucket, vnStream stream);
 /* The part of the forward that does not depend on the voxel features (weight packing; sparse first layer: active
  * sites, voxel index grid, bias fill): may be issued on another stream while the VFE forward runs; then set
  * cfg->prepared for vn_net_forward and make its stream wait for this one. */

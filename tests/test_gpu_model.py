@@ -260,3 +260,28 @@ def test_sparse_first_layer_has_no_state_between_steps(golden):
         m.detect(feats_b, coords_b)
         p3, r3 = m.detect(feats, coords)
     assert torch.equal(p1, p3) and torch.equal(r1, r3)
+
+
+def test_reducer_path_gives_the_same_gradients(golden):
+    """Bucketed path (parallel.GradAllReducer attached: gradients written into the flat buckets, per-group events,
+    comm stream) == plain path, on one GPU (world size 1: no collective, same plumbing)."""
+    from voxelnet_amd import parallel
+    g = golden("rpn3d_tiny")
+    feats, coords = split(golden("middle_tiny_car"))
+    batch = (["a", "b"], None, feats, None, coords, None, None)
+    grads = []
+    for use_reducer in (False, True):
+        m = make_model("Car", 16, 24, "fp32")
+        m.train()
+        named = list(m.named_parameters())
+        if use_reducer:
+            m.grad_reducer = parallel.GradAllReducer(named)
+        out = m(batch, DEV, targets=(g["pos"], g["neg"], g["targets"]))
+        out[2].backward()
+        if use_reducer:
+            m.grad_reducer.finish(named)
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.detach().clone() for k, p in named})
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (k, float((a - b).abs().max()))

@@ -297,6 +297,20 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
 
 #define RT(call) do { int rc_ = (call); if (rc_ != VN_OK) return rc_; } while (0)
 
+// "gradients of parameter group b are final" events of the most recent single-call backward with cfg->bucket_events:
+// [b][0] recorded on the main stream (BatchNorm gradients, zeroed conv biases), [b][1] on the side stream (weight
+// gradients unpacked).  One executor per process (one process per GPU).
+static hipEvent_t g_bucket_ev[4][2];
+static bool bucket_events_ready() {
+    static const bool ok = [] {
+        for (int b = 0; b < 4; ++b)
+            for (int w = 0; w < 2; ++w)
+                if (hipEventCreateWithFlags(&g_bucket_ev[b][w], hipEventDisableTiming) != hipSuccess) return false;
+        return true;
+    }();
+    return ok;
+}
+
 // zero up to NL small fp32 vectors in one launch (the conv-bias gradients: exactly 0 before a train-mode BatchNorm)
 struct ZeroJobs {
     int32_t n;
@@ -666,18 +680,48 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         if (!ev_d1) return VN_EINVAL;
         VN_HIP(hipEventRecord(ev_d1, ws));
     }
+    // cfg->bucket_events (single call, side stream): at the end of each parameter group (= DDP bucket: heads+deconv3+
+    // block3 | deconv2+block2+deconv1 | block1 | middle_layer) the group's weight gradients are unpacked on the SIDE
+    // stream and two events mark "final" — the main stream never waits for the side stream (vn_net_wait_bucket).
+    const bool bucket_ev = cfg->bucket_events && ws != hs && seg_begin == 0 && seg_end == NL + 1;
+    if (bucket_ev && !bucket_events_ready()) return VN_EINVAL;
+    int u_done = 0, z_done = 0;
+    auto bucket_done = [&](int b) -> int {
+        RT(flush());
+        RT(vn_unpack_wgrads_batch(unpack + u_done, nu - u_done, wstream));
+        u_done = nu;
+        VN_HIP(hipEventRecord(g_bucket_ev[b][1], ws));
+        if (zj.n > z_done) {
+            ZeroJobs part{};
+            part.n = zj.n - z_done;
+            for (int i = 0; i < part.n; ++i) { part.ptr[i] = zj.ptr[z_done + i]; part.len[i] = zj.len[z_done + i]; }
+            k_zero_many<<<part.n, 256, 0, hs>>>(part);
+            VN_LAUNCH_STATUS();
+            z_done = zj.n;
+        }
+        VN_HIP(hipEventRecord(g_bucket_ev[b][0], hs));
+        return VN_OK;
+    };
     for (int oi = 0; oi < NL; ++oi) {
         if (oi + 1 < seg_begin || oi + 1 >= seg_end) continue;
         const int l = order[oi];
-        if (early && (l == L_D2 || l == L_D1)) continue;
-        bool accumulate = (l == L_D1 || l == L_D2);
-        if (early && l == L_B3) { VN_HIP(hipStreamWaitEvent(hs, ev_d2, 0)); accumulate = true; }
-        if (early && l == L_B2) { VN_HIP(hipStreamWaitEvent(hs, ev_d1, 0)); accumulate = true; }
-        RT(do_layer(l, stream, false, accumulate));
-        // flush at the end of every block chain and after each Conv3d (their weight gradients are the long ones)
-        if (l == L_B3 || l == L_B2 || l == L_B1 || l <= L_M2) RT(flush());
+        if (!(early && (l == L_D2 || l == L_D1))) {
+            bool accumulate = (l == L_D1 || l == L_D2);
+            if (early && l == L_B3) { VN_HIP(hipStreamWaitEvent(hs, ev_d2, 0)); accumulate = true; }
+            if (early && l == L_B2) { VN_HIP(hipStreamWaitEvent(hs, ev_d1, 0)); accumulate = true; }
+            RT(do_layer(l, stream, false, accumulate));
+            // flush at the end of every block chain and after each Conv3d (their weight gradients are the long ones)
+            if (l == L_B3 || l == L_B2 || l == L_B1 || l <= L_M2) RT(flush());
+        }
+        if (bucket_ev) {   // group ends (backward order): ... block3.0 | ... deconv1 | ... block1.0 | ... middle_layer.0
+            if (l == L_B3) RT(bucket_done(0));
+            else if (l == L_D1) RT(bucket_done(1));
+            else if (l == L_B1) RT(bucket_done(2));
+            else if (l == 0) RT(bucket_done(3));
+        }
     }
     RT(flush());
+    if (bucket_ev) return VN_OK;   // everything unpacked / zeroed per group; the caller joins the side stream
     if (ws != hs && cfg->defer_join && seg_end == NL + 1) {
         // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream
         RT(vn_unpack_wgrads_batch(unpack, nu, wstream));
@@ -698,5 +742,13 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         k_zero_many<<<zj.n, 256, 0, hs>>>(zj);
         VN_LAUNCH_STATUS();
     }
+    return VN_OK;
+}
+
+extern "C" int vn_net_wait_bucket(int32_t bucket, vnStream stream) {
+    VN_CHECK_ARG(bucket >= 0 && bucket < 4);
+    if (!bucket_events_ready()) return VN_EINVAL;
+    VN_HIP(hipStreamWaitEvent(vn_stream(stream), g_bucket_ev[bucket][0], 0));
+    VN_HIP(hipStreamWaitEvent(vn_stream(stream), g_bucket_ev[bucket][1], 0));
     return VN_OK;
 }

@@ -44,7 +44,7 @@ class VnVfeGrads(ctypes.Structure):
 
 
 class VnNetConfig(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("B", "D", "H", "W", "block1_stride", "mode", "training", "sparse_first", "prepared", "defer_join")]
+    _fields_ = [(n, c_i32) for n in ("B", "D", "H", "W", "block1_stride", "mode", "training", "sparse_first", "prepared", "bucket_events", "defer_join")]
 
 
 class VnLayerParams(ctypes.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
     "vn_net_workspace_bytes": (c_sz, [_P(VnNetConfig), c_i64]),
     "vn_net_forward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
                                c_vp, c_vp, c_vp]),
+    "vn_net_wait_bucket": (c_i32, [c_i32, c_vp]),
     "vn_net_prepare": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "vn_voxel_index_grid": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vn_rulebook_slab_rows": (c_i64, [c_i64]),

@@ -564,33 +564,12 @@ class _DetectorFn(torch.autograd.Function):
         return (None, None, None, None, None) + tuple(vg) + tuple(_middle_grads_flat(names, G))
 
 
-def _split_heads_grads(views, dhw, dhb):
-    """fused (16,768) heads gradient -> prob_conv / reg_conv parameter gradients (model.py:276-279)"""
-    views["middle_rpn.prob_conv.conv.weight"].copy_(dhw[:2])
-    views["middle_rpn.prob_conv.conv.bias"].copy_(dhb[:2])
-    views["middle_rpn.reg_conv.conv.weight"].copy_(dhw[2:])
-    views["middle_rpn.reg_conv.conv.bias"].copy_(dhb[2:])
-
-
-def _detector_backward_native(ctx, d_prob, d_reg):
-    feature, coord, stats, wst, vparams, nat, _, _ = ctx.saved
-    cfg, ws, ws_bytes, dense, vw_rows, heads, prob = nat
-    rpn, red = ctx.rpn, ctx.reducer
+def _detector_backward_segments(cfg, arr, heads, dp, dr, prob, dense, coord, vw_rows, K, ws, ws_bytes, garr, dhw, dhb, d_in,
+                                side, red, views, table, order, rpn, feature, wst, stats, d_vw, vparams):
+    """the executor's backward as one call (no reducer) or one call per DDP bucket (reducer without a comm stream)"""
     mid = rpn.middle_rpn
-    K = feature.shape[0]
-    dev = d_prob.device
-    views = _grad_views(rpn)
-    accumulate = any(p.grad is not None for p in rpn.parameters())   # someone wants sums: hand out copies
-    with torch.cuda.device(dev):
-        arr, garr = _native_layer_arrays(mid, views)
-        dhw = torch.empty((16, 768, 1, 1), dtype=torch.float32, device=dev)
-        dhb = torch.empty(16, dtype=torch.float32, device=dev)
-        d_vw = torch.empty((K, 128), dtype=torch.float32, device=dev)
-        dp, dr = d_prob.contiguous().float(), d_reg.contiguous().float()
-        d_in = d_vw if cfg.sparse_first else torch.empty_like(dense.t)
-        table = N.layer_table(mid._block1_stride)
-        order = [22] + list(range(21, 15, -1)) + [15] + list(range(14, 8, -1)) + [8] + list(range(7, 2, -1)) + [2, 1, 0]
-        side = rpn._side_stream(dev) if rpn.overlap_wgrad else None
+    last_names = []
+    if True:
         # one segment per DDP bucket when gradients are all-reduced while the backward runs; else a single call
         # (fewer fork/join points for the side stream, one unpack launch)
         segments = NATIVE_SEGMENTS if red is not None else [(0, 24)]
@@ -628,6 +607,65 @@ def _detector_backward_native(ctx, d_prob, d_reg):
         if red is not None:
             for n in last_names + VFE_KEYS:
                 red.grad_ready(n, views[n])
+    return vg
+
+
+def _split_heads_grads(views, dhw, dhb):
+    """fused (16,768) heads gradient -> prob_conv / reg_conv parameter gradients (model.py:276-279)"""
+    views["middle_rpn.prob_conv.conv.weight"].copy_(dhw[:2])
+    views["middle_rpn.prob_conv.conv.bias"].copy_(dhb[:2])
+    views["middle_rpn.reg_conv.conv.weight"].copy_(dhw[2:])
+    views["middle_rpn.reg_conv.conv.bias"].copy_(dhb[2:])
+
+
+def _detector_backward_native(ctx, d_prob, d_reg):
+    feature, coord, stats, wst, vparams, nat, _, _ = ctx.saved
+    cfg, ws, ws_bytes, dense, vw_rows, heads, prob = nat
+    rpn, red = ctx.rpn, ctx.reducer
+    mid = rpn.middle_rpn
+    K = feature.shape[0]
+    dev = d_prob.device
+    views = _grad_views(rpn)
+    accumulate = any(p.grad is not None for p in rpn.parameters())   # someone wants sums: hand out copies
+    with torch.cuda.device(dev):
+        arr, garr = _native_layer_arrays(mid, views)
+        dhw = torch.empty((16, 768, 1, 1), dtype=torch.float32, device=dev)
+        dhb = torch.empty(16, dtype=torch.float32, device=dev)
+        d_vw = torch.empty((K, 128), dtype=torch.float32, device=dev)
+        dp, dr = d_prob.contiguous().float(), d_reg.contiguous().float()
+        d_in = d_vw if cfg.sparse_first else torch.empty_like(dense.t)
+        table = N.layer_table(mid._block1_stride)
+        order = [22] + list(range(21, 15, -1)) + [15] + list(range(14, 8, -1)) + [8] + list(range(7, 2, -1)) + [2, 1, 0]
+        side = rpn._side_stream(dev) if rpn.overlap_wgrad else None
+        if red is not None and side is not None and red.comm_stream is not None:
+            # Gradient all-reduce overlapped with a SINGLE backward call: the executor unpacks every parameter group's
+            # weight gradients on the side stream and records "group final" events; the comm stream waits for them
+            # (vn_net_wait_bucket) — the compute streams never stall for the reducer.
+            cfg.bucket_events, cfg.defer_join = 1, 1
+            _lib.call("vn_net_backward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
+                      prob.data_ptr(), dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K,
+                      ws.data_ptr(), ws_bytes, garr, dhw.data_ptr(), dhb.data_ptr(), d_in.data_ptr(), 0, 24, E.stream(), side)
+
+            def waiter(bi):
+                return lambda st: _lib.call("vn_net_wait_bucket", bi, ctypes.c_void_p(st.cuda_stream))
+            dhw.record_stream(red.comm_stream)       # read there (prelude) after this function has returned
+            dhb.record_stream(red.comm_stream)
+            red.launch_bucket(0, wait_fn=waiter(0), prelude=lambda: _split_heads_grads(views, dhw, dhb))
+            red.launch_bucket(1, wait_fn=waiter(1))
+            red.launch_bucket(2, wait_fn=waiter(2))
+            if not cfg.sparse_first:
+                d_vw = gather_rows(Rows(d_in, 128), coord, K, 128)
+            vg = featnet_backward(feature, wst, stats, d_vw, vparams, out=[views[k] for k in VFE_KEYS])
+            vfe_done = torch.cuda.Event()
+            vfe_done.record()
+            red.launch_bucket(3, wait_fn=waiter(3), after_event=vfe_done)
+            torch.cuda.current_stream().wait_stream(rpn.__dict__["_side"])
+        else:
+            # one segment per DDP bucket when gradients are all-reduced while the backward runs (no side stream); else
+            # a single call (fewer fork/join points for the side stream, one unpack launch)
+            vg = _detector_backward_segments(cfg, arr, heads, dp, dr, prob, dense, coord, vw_rows, K, ws, ws_bytes, garr,
+                                             dhw, dhb, d_in, side, red, views, table, order, rpn, feature, wst, stats, d_vw,
+                                             vparams)
     mg = []
     for name, spec in table:
         cv = "deconv" if spec.transposed else "conv"

@@ -94,6 +94,32 @@ class GradAllReducer:
             flat.div_(self.world)
             b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
+    def launch_bucket(self, bi, wait_fn=None, after_event=None, prelude=None):
+        """All-reduce bucket bi on the comm stream once (a) wait_fn(comm_stream) has made the comm stream wait for whatever
+        produces the bucket's gradients (e.g. vn_net_wait_bucket: the native executor's per-group events), (b) the
+        optional torch event has passed and (c) prelude() — small copies into the bucket, issued on the comm stream —
+        has run.  The calling (compute) stream is never blocked."""
+        b = self.buckets[bi]
+        b["pending"] = set()
+        st = self.comm_stream
+        if st is None:                       # CPU tensors / no side stream: plain, in order
+            if prelude is not None:
+                prelude()
+            if self.world > 1 and not self.defer_allreduce:
+                b["flat"].div_(self.world)
+                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            return
+        with torch.cuda.stream(st):
+            if after_event is not None:
+                st.wait_event(after_event)
+            if wait_fn is not None:
+                wait_fn(st)
+            if prelude is not None:
+                prelude()
+            if self.world > 1 and not self.defer_allreduce:
+                b["flat"].div_(self.world)
+                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+
     def allreduce_all(self):
         """deferred mode: all-reduce every (already filled) bucket now, largest first, and wait"""
         if self.world == 1:
