@@ -762,7 +762,13 @@ PatchCfg patch_config(const vnConv *g) {
         if (patch_enabled() == 3 || g->Cr == 64) return none;
         return PatchCfg{2, 64, 128, 16};
     }
-    if (g->Cr == 64) return PatchCfg{1, 256, 64, 32};        // 8 x 32 pixels
+    // 64-channel Conv3d layers: 6 x 32 pixels (patch 35 KB + 2 weight stages = 51 KB: THREE workgroups per CU; measured
+    // 1340 vs 1183 TFLOP/s on middle_layer.2 against 8 x 32 pixels / two workgroups per CU)
+    static const int p1_rows = [] { const char *e = getenv("VN_PATCH_P1"); return e && *e ? atoi(e) : 192; }();   // tuning aid
+    if (g->Cr == 64) return p1_rows == 192 ? PatchCfg{3, 192, 64, 32} : PatchCfg{1, 256, 64, 32};
+    static const int p0_rows = [] { const char *e = getenv("VN_PATCH_P0"); return e && *e ? atoi(e) : 160; }();   // tuning aid
+    if (p0_rows == 96) return PatchCfg{4, 96, 128, 16};      // 6 x 16 pixels, three workgroups per CU
+    if (p0_rows == 128) return PatchCfg{5, 128, 128, 16};    // 8 x 16 pixels
     return PatchCfg{0, 160, 128, 16};                        // 10 x 16 pixels
 }
 int64_t patch_tiles(const PatchCfg &c, int B, int qD, int qH, int qW) {
@@ -781,6 +787,9 @@ int launch_patch(const GGParams &p, dim3 grid, hipStream_t st) {
 }
 int launch_patch_cfg(const PatchCfg &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
     if (c.id == 1) return f32 ? launch_patch<4, 1, 4, 32, true>(p, grid, st) : launch_patch<4, 1, 4, 32, false>(p, grid, st);
+    if (c.id == 4) return f32 ? launch_patch<2, 2, 3, 16, true>(p, grid, st) : launch_patch<2, 2, 3, 16, false>(p, grid, st);
+    if (c.id == 5) return f32 ? launch_patch<2, 2, 4, 16, true>(p, grid, st) : launch_patch<2, 2, 4, 16, false>(p, grid, st);
+    if (c.id == 3) return f32 ? launch_patch<4, 1, 3, 32, true>(p, grid, st) : launch_patch<4, 1, 3, 32, false>(p, grid, st);
     if (c.id == 2) return f32 ? launch_patch<2, 2, 2, 16, true>(p, grid, st) : launch_patch<2, 2, 2, 16, false>(p, grid, st);
     return f32 ? launch_patch<2, 2, 5, 16, true>(p, grid, st) : launch_patch<2, 2, 5, 16, false>(p, grid, st);
 }
