@@ -9,7 +9,7 @@ from voxelnet_amd import engine as E, net as N
 dev = "cuda:0"
 name = sys.argv[2]
 specs = dict(N.layer_table(2))
-IN = {"middle_layer.1": (5, 400, 352), "middle_layer.2": (3, 400, 352)}
+IN = {"middle_layer.1": (5, 400, 352), "middle_layer.2": (3, 400, 352), "block1.1": (1, 200, 176), "block2.1": (1, 100, 88), "block3.1": (1, 50, 44)}
 sp, dims, B = specs[name], IN[name], 2
 x = E.Rows(torch.randn((B,) + dims + (sp.cin,), device=dev).to(torch.bfloat16), sp.cin)
 od = sp.out_dims(dims)
@@ -28,7 +28,7 @@ n = min(int(t[0]), 400)
 r = t[8:8 + n * 8].reshape(n, 8)
 print(f"{name}: stages {n}; wait | barrier | issue next stage | transposed reads + MFMA | total")
 for s in range(2, min(n, 8)):
-    t0, t1, t2, t3, t4 = r[s, :5]
-    print(f"  {t1-t0:6d} | {t2-t1:6d} | {t3-t2:6d} | {t4-t3:6d} | {r[s+1,0]-t0 if s+1<n else t4-t0:6d}")
+    t0, t1, t2, t3, t4, t5 = r[s, :6]
+    print(f"  {t1-t0:6d} | {t2-t1:6d} | {t3-t2:6d} | {t4-t3:6d} (table {t5-t3 if t5 else 0}) | {r[s+1,0]-t0 if s+1<n else t4-t0:6d}")
 tot = r[1:, 0] - r[:-1, 0]
 print(f"  mean stage {tot.mean():.0f} clk")

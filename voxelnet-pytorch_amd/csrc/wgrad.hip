@@ -104,10 +104,13 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
 
     // ---- row table producer state (wave 0: lane <-> row of the current slab) ----
     int cb = 0, cd = 0, ch = 0, cw = 0;
-    int64_t cm = rbeg + lane;   // the site this lane tracks
+    int cm32 = lane;            // the site this lane tracks, relative to the chunk
+    const int rows_in_chunk = (int)(rend - rbeg);
     int tstep = 0;              // slab index its coordinates stand for
+    const uint32_t rBb = (uint32_t)(p.rB * ESZ), rDb = (uint32_t)(p.rD * ESZ), rHb = (uint32_t)(p.rH * ESZ), rWb = (uint32_t)(p.rW * ESZ);
+    const uint32_t sBb = (uint32_t)(p.sB * ESZ), sDb = (uint32_t)(p.sD * ESZ), sHb = (uint32_t)(p.sH * ESZ), sWb = (uint32_t)(p.sW * ESZ);
     if (wave == 0 && !list) {
-        int64_t t = cm;
+        int64_t t = rbeg + lane;
         cw = (int)(t % p.Wr); t /= p.Wr;
         ch = (int)(t % p.Hr); t /= p.Hr;
         cd = (int)(t % p.Dr);
@@ -139,25 +142,32 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
                 }
             }
         } else {
-            while (tstep < step) {   // advance by ROWS sites
-                cm += ROWS;
+            // 32-bit, branch-light arithmetic (wave 0 does this on the critical path of every stage: measured 870 clk
+            // with 64-bit products and loops).  Byte offsets fit 32 bits: the buffer windows are < 4 GB.
+            while (tstep < step) {   // advance by ROWS sites (normally exactly one slab)
+                cm32 += ROWS;
                 cw += ROWS;
-                while (cw >= p.Wr) {
-                    cw -= p.Wr;
-                    if (++ch >= p.Hr) { ch = 0; if (++cd >= p.Dr) { cd = 0; ++cb; } }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {            // ROWS / Wr <= 3 wraps (Wr >= 22)
+                    const bool wrap = cw >= p.Wr;
+                    cw -= wrap ? p.Wr : 0;
+                    ch += wrap ? 1 : 0;
                 }
+                while (cw >= p.Wr) { cw -= p.Wr; ++ch; }   // (narrower rows)
+                while (ch >= p.Hr) { ch -= p.Hr; ++cd; }
+                while (cd >= p.Dr) { cd -= p.Dr; ++cb; }
                 ++tstep;
             }
-            if (cm < rend) {
+            if (cm32 < rows_in_chunk) {
                 const int sd = cd * p.mulD + td * p.tmulD - p.padD;
                 const int sh = ch * p.mulH + th * p.tmulH - p.padH;
-                ro = (uint32_t)(((int64_t)cb * p.rB + (int64_t)cd * p.rD + (int64_t)ch * p.rH + (int64_t)cw * p.rW) * ESZ);
+                ro = (uint32_t)cb * rBb + (uint32_t)cd * rDb + (uint32_t)ch * rHb + (uint32_t)cw * rWb;
                 if ((unsigned)sd < (unsigned)p.Ds && (unsigned)sh < (unsigned)p.Hs) {
-                    const int64_t base = (int64_t)cb * p.sB + (int64_t)sd * p.sD + (int64_t)sh * p.sH;
+                    const uint32_t base = (uint32_t)cb * sBb + (uint32_t)sd * sDb + (uint32_t)sh * sHb;
 #pragma unroll
                     for (int j = 0; j < TPB; ++j) {
                         const int sw = cw * p.mulW + (tw0 + j) * p.tmulW - p.padW;
-                        if ((unsigned)sw < (unsigned)p.Ws) so[j] = (uint32_t)((base + (int64_t)sw * p.sW) * ESZ);
+                        if ((unsigned)sw < (unsigned)p.Ws) so[j] = base + (uint32_t)sw * sWb;
                     }
                 }
             }
