@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="experimental: replay the post-voxelizer part of the step from captured HIP graphs")
+    ap.add_argument("--torch-optim", action="store_true",
+                    help="torch's clip_grad_norm_ + SGD instead of the fused vn_clip_sgd tail (same arithmetic)")
     ap.add_argument("--timer-steps", type=int, default=3)
     ap.add_argument("--force-reducer", action="store_true",
                     help="diagnostic: run the DDP bucket path (flat buckets, segmented backward) on one GPU")
@@ -112,7 +114,10 @@ def main():
     model.train(True)                            # train.py:148
     named = list(model.named_parameters())
     params = [p for _, p in named]
-    opt = torch.optim.SGD(params, lr=LR)         # train.py:130
+    from voxelnet_amd.optim import ClipSGD
+    # train.py:130 + 153-154: clip_grad_norm_(5) + SGD(lr=0.01) as two HIP launches (csrc/optim.hip);
+    # --torch-optim runs torch's own clip_grad_norm_ + SGD instead (same arithmetic, ~12 launches)
+    opt = torch.optim.SGD(params, lr=LR) if args.torch_optim else ClipSGD(params, LR, GRADIENT_CLIP)
     if world > 1:
         for p in params:
             dist.broadcast(p.data, 0)
@@ -174,8 +179,9 @@ def main():
             model.grad_reducer.finish(named)
 
     def optim():
-        torch.nn.utils.clip_grad_norm_(params, GRADIENT_CLIP)              # train.py:153
-        opt.step()                                                         # train.py:154
+        if args.torch_optim:
+            torch.nn.utils.clip_grad_norm_(params, GRADIENT_CLIP)          # train.py:153
+        opt.step()                                                         # train.py:154 (ClipSGD: both lines)
 
     def step_eager():
         feats, coords = voxelize_batch()

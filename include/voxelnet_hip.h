@@ -443,6 +443,24 @@ int vn_rpn_loss_bwd(const float *prob, const float *delta, const float *pos, con
                     const void *workspace, const float *grad_out5, float *d_prob, float *d_delta,
                     vnStream stream);
 
+/* ---- optimizer tail (voxelnet/train.py:153-154 with the optimizer of train.py:130-132) ---------------------
+ * torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by SGD(lr) without momentum / weight decay:
+ *   total = sqrt(sum |g|^2) over every chunk;  coef = min(1, max_norm / (total + 1e-6));  p -= lr * coef * g
+ * in two launches.  `chunks` is a DEVICE array the caller builds once for a fixed set of fp32 tensors: every
+ * (parameter, gradient) pair cut into pieces of at most VN_OPT_CHUNK elements.  scale_grads != 0 also stores
+ * g *= coef (what clip_grad_norm_ leaves behind); total_norm (device, may be NULL) receives the norm before
+ * clipping, clip_grad_norm_'s return value. */
+#define VN_OPT_CHUNK 4096
+typedef struct vnParamChunk {
+    float *param;
+    float *grad;
+    int32_t n;          /* elements in this piece, 1..VN_OPT_CHUNK */
+    int32_t reserved;
+} vnParamChunk;
+size_t vn_clip_sgd_workspace_bytes(int32_t n_chunks);
+int vn_clip_sgd(const vnParamChunk *chunks, int32_t n_chunks, float max_norm, float lr, int32_t scale_grads,
+                void *workspace, size_t workspace_bytes, float *total_norm, vnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,3 +254,13 @@ def forward_backward(features, coordinates, sd, dims, cls_name, d_prob, d_reg):
     prob, reg = middle_rpn(dense, work, cls_name, True)
     torch.autograd.backward([prob, reg], [d_prob, d_reg])
     return prob.detach(), reg.detach(), {k: leaves[k].grad for k in keys}
+
+
+def clip_sgd_step(params, grads, lr=0.01, max_norm=5.0):
+    """train.py:153-154 with the optimizer of train.py:130 restated: clip_grad_norm_(params, max_norm) — 2-norm over
+    all gradients together, coef = max_norm / (total + 1e-6) clamped to 1 — then SGD(lr) without momentum or weight
+    decay.  -> (new params, clipped grads, total norm); computes in the tensors' dtype."""
+    total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads)).to(grads[0].dtype)
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    clipped = [g * coef for g in grads]
+    return [p - lr * g for p, g in zip(params, clipped)], clipped, total

@@ -163,3 +163,25 @@ def test_car_full_forward(golden):
         prob, reg = tr.middle_rpn(dense, sd, "Car", True)
     close(prob[:, :, ::8, ::8], g["prob_lattice"], rtol=1e-3, atol=1e-5)
     close(reg[:, :, ::8, ::8], g["reg_lattice"], rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("scale", [1.0, 1e-3])
+def test_clip_sgd_restatement_equals_the_calls_train_py_makes(scale):
+    """oracle/torch_ref.clip_sgd_step vs the two library calls of train.py:153-154 (clip_grad_norm_(params, 5);
+    SGD(lr=0.01).step(), train.py:130) on the same tensors, both sides of the clamp."""
+    g = torch.Generator().manual_seed(21)
+    shapes = [(16, 7), (16,), (64, 32), (3, 5, 7), (1,)]
+    ps = [torch.randn(s, generator=g) for s in shapes]
+    gs = [torch.randn(s, generator=g) * scale for s in shapes]
+    params = [torch.nn.Parameter(p.clone()) for p in ps]
+    for p, x in zip(params, gs):
+        p.grad = x.clone()
+    total = torch.nn.utils.clip_grad_norm_(params, 5.0)
+    torch.optim.SGD(params, lr=0.01).step()
+    new_p, new_g, t = tr.clip_sgd_step(ps, gs, 0.01, 5.0)
+    assert (total.item() > 5.0) == (scale == 1.0)
+    close(t, total, rtol=1e-6, atol=0)
+    for a, b in zip(new_p, params):
+        close(a, b.detach(), rtol=1e-6, atol=1e-9)
+    for a, b in zip(new_g, params):
+        close(a, b.grad, rtol=1e-6, atol=1e-12)

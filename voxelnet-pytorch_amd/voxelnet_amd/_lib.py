@@ -65,6 +65,10 @@ class VnUnpackJob(ctypes.Structure):
                [("chunk_stride", c_i64)]
 
 
+class VnParamChunk(ctypes.Structure):
+    _fields_ = [("param", c_vp), ("grad", c_vp), ("n", c_i32), ("reserved", c_i32)]
+
+
 # name -> (restype, argtypes); mirrors include/voxelnet_hip.h one to one
 _P = ctypes.POINTER
 SIGNATURES = {
@@ -131,6 +135,8 @@ SIGNATURES = {
     "vn_rpn_loss_fwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp]),
     "vn_rpn_loss_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp,
                                 c_vp]),
+    "vn_clip_sgd_workspace_bytes": (c_sz, [c_i32]),
+    "vn_clip_sgd": (c_i32, [c_vp, c_i32, c_f32, c_f32, c_i32, c_vp, c_sz, c_vp, c_vp]),
 }
 
 _lib = None

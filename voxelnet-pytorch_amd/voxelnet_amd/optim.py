@@ -1,0 +1,74 @@
+"""Optimizer tail of the reference's train step (voxelnet/train.py:153-154):
+
+    clip_grad_norm_(model.parameters(), 5)        # train.py:153
+    optimizer.step()                              # train.py:154, optimizer = SGD(model.parameters(), lr=0.01)
+
+as two HIP launches (csrc/optim.hip, `vn_clip_sgd`) over a device chunk table of the (parameter, gradient) pairs,
+whatever their placement (the module's flat gradient buffer, the DDP buckets' views, or 104 separate tensors).
+No CPU / torch fallback: the HIP library must be present."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CHUNK = 4096    # VN_OPT_CHUNK (include/voxelnet_hip.h)
+
+
+class ClipSGD:
+    """`ClipSGD(params, lr, max_norm).step()` == `clip_grad_norm_(params, max_norm); SGD(params, lr).step()`.
+    step() returns the total gradient norm before clipping (a device scalar, clip_grad_norm_'s return value)."""
+
+    def __init__(self, params, lr, max_norm, scale_grads=False):
+        self.params = [p for p in params]
+        if not self.params:
+            raise ValueError("ClipSGD got an empty parameter list")
+        self.lr, self.max_norm, self.scale_grads = float(lr), float(max_norm), bool(scale_grads)
+        self._key = None
+        self._table = self._ws = self._norm = None
+        self._n_chunks = 0
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            if p.grad is None:
+                continue
+            if set_to_none:
+                p.grad = None
+            else:
+                p.grad.detach_().zero_()
+
+    def _build(self, pairs, dev):
+        rows = []
+        for p, g in pairs:
+            n, pp, gp = p.numel(), p.data_ptr(), g.data_ptr()
+            for off in range(0, n, CHUNK):
+                rows.append((pp + 4 * off, gp + 4 * off, min(CHUNK, n - off), 0))
+        tab = np.array(rows, dtype=np.dtype([("param", "<u8"), ("grad", "<u8"), ("n", "<i4"), ("reserved", "<i4")]))
+        assert tab.dtype.itemsize == ctypes.sizeof(_lib.VnParamChunk)
+        self._table = torch.from_numpy(tab.view(np.uint8).copy()).to(dev)
+        self._n_chunks = len(rows)
+        nbytes = _lib.load().vn_clip_sgd_workspace_bytes(self._n_chunks)
+        self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    @torch.no_grad()
+    def step(self):
+        pairs = [(p, p.grad) for p in self.params if p.grad is not None]
+        if not pairs:
+            return None
+        dev = pairs[0][0].device
+        for p, g in pairs:
+            if not (p.is_cuda and g.is_cuda and p.device == dev and g.device == dev):
+                raise _lib.VoxelnetHipError("ClipSGD: parameters and gradients must live on one HIP device (no CPU path)")
+            if p.dtype != torch.float32 or g.dtype != torch.float32 or not p.is_contiguous() or not g.is_contiguous():
+                raise _lib.VoxelnetHipError("ClipSGD: fp32 contiguous parameters and gradients only")
+        key = tuple((p.data_ptr(), g.data_ptr(), p.numel()) for p, g in pairs)
+        if key != self._key:
+            self._build(pairs, dev)        # pointers are stable from step to step (flat gradient buffer): built once
+            self._key = key
+        with torch.cuda.device(dev):
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            _lib.call("vn_clip_sgd", self._table.data_ptr(), self._n_chunks, self.max_norm, self.lr, int(self.scale_grads),
+                      self._ws.data_ptr(), self._ws.numel(), self._norm.data_ptr(), stream)
+        return self._norm[0]
