@@ -563,7 +563,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     order[n++] = L_D1; for (int l = L_D1 - 1; l >= L_B1; --l) order[n++] = l;
     order[n++] = 2; order[n++] = 1; order[n++] = 0;
     // weight gradient of layer l on the side stream (its dy exists in stream order of whoever calls this)
-    auto launch_wgrad = [&](int l) -> int {
+    auto launch_wgrad = [&](int l, vnStream wstream) -> int {
         const Spec &sp = P.spec[l];
         const int taps = sp.k[0] * sp.k[1] * sp.k[2];
         const int C = sp.cout;
@@ -595,10 +595,20 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     auto flush = [&]() -> int {
         if (npend == 0) return VN_OK;
         RT(fork());
-        for (int i = 0; i < npend; ++i) RT(launch_wgrad(pending[i]));
+        for (int i = 0; i < npend; ++i) RT(launch_wgrad(pending[i], wstream));
         npend = 0;
         return VN_OK;
     };
+    // Tail balance of the deferred-join single call (tuning aids VN_M0_MAIN / VN_EARLY_UNPACK, default on): the side
+    // stream ends with the two long Conv3d weight gradients, the main stream with the short first-layer data gradient.
+    // So the FIRST layer's weight gradient runs on the main stream (behind its data gradient), and everything up to
+    // block1 is unpacked on the side stream before it waits for middle_layer.2's dy (a ~180 us idle gap there): only
+    // the three Conv3d gradients are left for the final unpack.
+    static const int m0_main_on = [] { const char *e = getenv("VN_M0_MAIN"); return e && *e ? atoi(e) : 1; }();
+    static const int early_unpack_on = [] { const char *e = getenv("VN_EARLY_UNPACK"); return e && *e ? atoi(e) : 1; }();
+    const bool tail_balance = ws != hs && cfg->defer_join && !cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
+    const bool m0_on_main = tail_balance && m0_main_on;
+    int u_early = 0;
     // one layer of the backward: BatchNorm backward and data gradient on `ls`, weight gradient on the side stream
     auto do_layer = [&](int l, vnStream ls, bool on_side, bool accumulate) -> int {
         const Spec &sp = P.spec[l];
@@ -640,7 +650,8 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         zj.ptr[zj.n] = G[l].bias; zj.len[zj.n] = C; ++zj.n;          // bias before a train-mode BN: gradient exactly 0
         const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
         // weight gradient: at once when this layer runs on the side stream itself, else queued for the next flush
-        if (on_side) RT(launch_wgrad(l));
+        if (on_side) RT(launch_wgrad(l, wstream));
+        else if (l == 0 && m0_on_main) RT(launch_wgrad(l, stream));
         else pending[npend++] = l;
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
@@ -712,6 +723,10 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
             RT(do_layer(l, stream, false, accumulate));
             // flush at the end of every block chain and after each Conv3d (their weight gradients are the long ones)
             if (l == L_B3 || l == L_B2 || l == L_B1 || l <= L_M2) RT(flush());
+            if (l == L_B1 && tail_balance && early_unpack_on) {
+                RT(vn_unpack_wgrads_batch(unpack, nu, wstream));
+                u_early = nu;
+            }
         }
         if (bucket_ev) {   // group ends (backward order): ... block3.0 | ... deconv1 | ... block1.0 | ... middle_layer.0
             if (l == L_B3) RT(bucket_done(0));
@@ -724,7 +739,8 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     if (bucket_ev) return VN_OK;   // everything unpacked / zeroed per group; the caller joins the side stream
     if (ws != hs && cfg->defer_join && seg_end == NL + 1) {
         // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream
-        RT(vn_unpack_wgrads_batch(unpack, nu, wstream));
+        if (m0_on_main) RT(fork());     // the first layer's partials come from the main stream
+        RT(vn_unpack_wgrads_batch(unpack + u_early, nu - u_early, wstream));
         if (zj.n > 0) {
             k_zero_many<<<zj.n, 256, 0, ws>>>(zj);
             VN_LAUNCH_STATUS();

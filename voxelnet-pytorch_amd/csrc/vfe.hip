@@ -9,20 +9,31 @@
 //   voxelwise = max_T out2                                 model.py:100
 //
 // HBM-bound by design: the only tensors that touch HBM are the (K,T,7) input,
-// the (K,128) output and (backward) one (K,T,16) gradient; the (K,T,32) and
+// the (K,128) output and (backward) one (K,r,16) gradient; the (K,T,32) and
 // (K,T,128) intermediates of the reference are recomputed per pass in registers.
 // Train-mode BatchNorm statistics are global over all K*T rows (padded slots
 // included), so the forward is 3 passes (stats1, stats2, output) and the backward
 // 3 passes (BN2 sums, BN1 sums + layer-2 grads, layer-1 grads) with tiny finalize
 // kernels between them.
-// One wave per voxel, lane = point slot t (T <= 64): the skinny 7->16 and 32->64
-// MLPs are fp32 FMAs with wave-uniform weights (scalar loads), i.e. no MFMA.
-// Reductions over T (max-pool, argmax, BN sums) go through a per-wave LDS tile
-// [T][65] that is then scanned with lane = channel: ~2 LDS ops per element
-// instead of a 6-step cross-lane butterfly per channel.
-// Per-wave partial sums live in registers across the wave's voxels, are combined
-// per workgroup through LDS and written as one slab per workgroup; a reduce kernel
-// sums the slabs in a fixed order (deterministic, double precision).
+//
+// EFFECTIVE ROWS.  A voxel holds n points and T-n padded slots, and every padded slot carries the same 7 values
+// (utils.py:87-88 leaves (0,0,0,0,-cx,-cy,-cz) in all of them), so all of them produce the same h1, p1, h2, p2.
+// A pre-pass finds, per voxel, r = 1 + (index of the last slot that differs bit-wise from slot T-1): slots
+// r-1 .. T-1 are identical, whatever the input was.  Only slots 0 .. r-1 are computed; slot r-1 stands for
+// w = T-r+1 slots:
+//   * BatchNorm sums weigh it by w; max-pools and first-index argmaxes are unchanged (ties resolve to the first
+//     index, and the stand-in IS the first of its copies);
+//   * in the backward, max-pool gradients reach only the first copy, while the dense BatchNorm-backward term
+//     c1*(h-mean)+c2 applies to each of the w copies; all later steps are linear in the row gradient and multiply
+//     it by forward values the copies share, so the stand-in carries c0*impulse + w*(c1*(h-mean)+c2).
+// KITTI voxels average ~4 points of T=35, so this is ~8x less arithmetic and 8x less input traffic.
+// PACKING.  A wave holds 64 rows: G voxels x R=64/G row lanes.  Voxels are binned (stable, deterministic) by r into
+// classes G=8 (r<=8), G=4 (r<=16) and G=1 (r<=64); a wave item is G voxels of one class.  Row-lane phases (the
+// skinny 7->16 and 32->64 MLPs as fp32 FMAs with broadcast LDS weights; no MFMA at these shapes) see 64 busy lanes;
+// channel-lane phases (max-pool / argmax / BN sums over a voxel's rows) run lane = channel per voxel over a per-wave
+// LDS tile [64][65].
+// Partial sums stay in registers across a wave's items, are combined per workgroup through LDS and written as one
+// slab per workgroup; reduce kernels sum the slabs in a fixed order (deterministic, double precision).
 #include "common.h"
 
 namespace {
@@ -31,44 +42,81 @@ constexpr int C1 = 16, C2 = 64, CIN = 7;
 constexpr int ST1 = 0, ST2 = 4 * C1;            // stats: [mean|invstd|S|beta] per layer
 constexpr int STATS_FLOATS = 4 * C1 + 4 * C2;   // 320
 constexpr int TS = 65;                          // tile row stride (floats)
-// per-wave vector scratch (floats)
-constexpr int V_AGG1 = 0, V_U = 16, V_MK = 80, V_R1 = 144, V_G1 = 208, V_R2 = 272, V_G2 = 336, V_AM1 = 400,
-              V_DAG1 = 416, V_S = 432, V_SIZE = 512;
-constexpr int VFE_BLOCKS_MAX = 1024;
+constexpr int NW = 2, NT = NW * 64;             // waves / threads per workgroup (LDS: 2 workgroups per CU)
+constexpr int VFE_BLOCKS_MAX = 512;
 #define VFE_O_UNROLL 4   // the o loops read 16 uniform weights per step from LDS; a full unroll spills
+// per-voxel-slot vectors in LDS (floats); odd stride: the 8 slots of a wave fall into different banks
+constexpr int V_AGG1 = 0, V_AM1 = 16, V_DAG1 = 32, V_U = 48, V_S = 112, SV = 177;
 // slab (per workgroup) float counts
-constexpr int SLAB_P1 = 2 * C1, SLAB_P2 = 2 * C2, SLAB_B1 = 2 * C2;
+constexpr int SLAB_P1 = 64, SLAB_P2 = 2 * C2, SLAB_B1 = 2 * C2;
 constexpr int SLAB_B2 = C2 + C2 * 32 + 64;   // db2 | dW2[64][32] | bn1 sums (32 used, written 64 wide)
-constexpr int SLAB_B3 = C1 * CIN + C1;           // dW1 | db1
+constexpr int SLAB_B3 = 128;                 // dW1 (112) | db1 (16)
 
 struct VfeParams {
     const float *w1, *b1, *w2, *b2;
 };
 
-__device__ __forceinline__ size_t wave_lds_floats(int T) { return (size_t)(T + 1) * TS + (size_t)T * 16 + V_SIZE; }
-
-struct WaveLds {
-    float *tile;   // [T][65]
-    float *p1t;    // [T][16]
-    float *vec;    // V_SIZE
+// work list built by the pre-pass: rows[v] = r, list = voxel ids grouped by class, counts = voxels per class
+struct WorkList {
+    const uint8_t *rows;
+    const int32_t *list;
+    const int32_t *counts;   // [3]
 };
 
-__device__ __forceinline__ WaveLds carve_lds(float *base, int wave, int T) {
-    float *p = base + (size_t)wave * wave_lds_floats(T);
-    return WaveLds{p, p + (size_t)(T + 1) * TS, p + (size_t)(T + 1) * TS + (size_t)T * 16};
+// The skinny-MLP weights (2.2k floats) are wave-uniform.  As kernel-argument loads hipcc hoists ~2000 s_loads out
+// of the per-item loop and spills the SGPRs into VGPR lanes; re-loading them with s_load inside the loop serialises
+// on SMEM latency.  So they live in LDS, one copy per workgroup, read as broadcast ds_read_b128.
+// W2A = W2[o][0..15] as [o][16]; W2B = W2[o][16+i] transposed as [i][65] (lane = o and lane = i reads both clean)
+constexpr int WL_W2A = 0, WL_W2B = 1024, WL_W1 = 2064, WL_B1 = 2176, WL_B2 = 2192, WL_SIZE = 2304;   // floats
+constexpr int WL_ST = WL_SIZE, WL_CF = WL_ST + STATS_FLOATS, WL_END = WL_SIZE + 512;   // BN stats / BN2 backward coefficients
+
+constexpr int WAVE_FLOATS = 64 * TS + 64 * 16 + 64 + 8 * SV + 16;   // tile | p1t | mk | slot vectors | slot ids
+
+struct WaveLds {
+    float *tile;   // [64][65]
+    float *p1t;    // [64][16]   p1 * mask rows
+    float *mk;     // [64]       mask per row lane
+    float *sv;     // [8][SV]    per-slot vectors
+    int *sid;      // [8] voxel id, [8] rows
+};
+
+__device__ __forceinline__ WaveLds carve_lds(float *base, int wave) {
+    float *p = base + (size_t)wave * WAVE_FLOATS;
+    return WaveLds{p, p + 64 * TS, p + 64 * TS + 64 * 16, p + 64 * TS + 64 * 16 + 64,
+                   reinterpret_cast<int *>(p + 64 * TS + 64 * 16 + 64 + 8 * SV)};
 }
 
-// The skinny-MLP weights (2.2k floats) are wave-uniform.  As kernel-argument loads hipcc hoists ~2000 s_loads out
-// of the per-voxel loop and spills the SGPRs into VGPR lanes (v_readlane around every FMA: +20k instructions per
-// voxel); re-loading them with s_load inside the loop serialises on SMEM latency (4x slower still).  So they live
-// in LDS, one copy per workgroup, and are read as broadcast ds_read_b128 (4 weights per LDS instruction).
-constexpr int WL_W2A = 0, WL_W2B = 1024, WL_W1 = 2048, WL_B1 = 2160, WL_B2 = 2176, WL_SIZE = 2304;   // floats
+// ---- items -----------------------------------------------------------------------------
+struct Items {
+    int nA, nB, nC, itemsA, itemsB, total;
+};
 
-// ---- row-lane pieces --------------------------------------------------------------------
-__device__ __forceinline__ void load_row(const float *__restrict__ feature, int64_t v, int T, int lane, float x[CIN],
+__device__ __forceinline__ Items load_items(const WorkList &wk) {
+    Items it;
+    it.nA = wk.counts[0]; it.nB = wk.counts[1]; it.nC = wk.counts[2];
+    it.itemsA = (it.nA + 7) >> 3;
+    it.itemsB = (it.nB + 3) >> 2;
+    it.total = it.itemsA + it.itemsB + it.nC;
+    return it;
+}
+
+// row lane of an item: voxel v (or -1), its row count r, slot s, row j, BN weight of this row (0 = idle lane)
+template <int G>
+__device__ __forceinline__ void item_lane(const WorkList &wk, int first, int n, int item, int T, int lane, int &v, int &r,
+                                          int &s, int &j, float &wgt) {
+    constexpr int R = 64 / G;
+    s = lane / R;
+    j = lane - s * R;
+    const int idx = item * G + s;
+    v = idx < n ? wk.list[first + idx] : -1;
+    r = v >= 0 ? (int)wk.rows[v] : 0;
+    wgt = j < r ? (j == r - 1 ? (float)(T - r + 1) : 1.f) : 0.f;
+}
+
+__device__ __forceinline__ void load_row(const float *__restrict__ feature, int v, int T, int j, bool active, float x[CIN],
                                          float &m) {
-    if (lane < T) {
-        const float *f = feature + ((int64_t)v * T + lane) * CIN;
+    if (active) {
+        const float *f = feature + ((int64_t)v * T + j) * CIN;
         float mx = -INFINITY;
 #pragma unroll
         for (int i = 0; i < CIN; ++i) { x[i] = f[i]; mx = fmaxf(mx, x[i]); }
@@ -100,163 +148,258 @@ __device__ __forceinline__ void layer1_lds(const float *__restrict__ wl, const f
     }
 }
 
-// lane-as-channel scan of tile[t][c] (holding h): max / argmax of p = S*(h-mean)+beta over t < T
-__device__ __forceinline__ void scan_max(const float *tile, int T, int c, float mean, float S, float beta, float &mx,
-                                         int &amx) {
-    mx = -INFINITY;
-    amx = 0;
-    for (int t = 0; t < T; ++t) {
-        const float p = fmaf(S, tile[t * TS + c] - mean, beta);
-        if (p > mx) { mx = p; amx = t; }
-    }
-}
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// forward of one voxel up to h2 (row-lane), leaving: tile = h2[t][0..63], vec[V_AGG1], vec[V_MK], p1t = p1*m
-// returns per-lane x, m, h1, p1 (unmasked) and h2.  am1 (argmax of p1 over t) is written to vec[V_AM1] when WANT_AM1.
-template <bool WANT_AM1>
+// forward of one item up to h2 (row lanes), leaving: tile = h2[row][0..63], sv[slot].AGG1 (and AM1), mk, sid,
+// and (WANT_P1T) p1t = p1*m.  Returns per-lane h1 and p1 (unmasked).
+template <int G, bool WANT_AM1, bool WANT_P1T>
 __device__ __forceinline__ void forward_to_h2(const float *__restrict__ wl, const float *__restrict__ stats,
-                                              const WaveLds &L, int T, int lane,
-                                              const float x[CIN], float m, float h1[C1], float p1[C1]) {
-    const float *w2b_lds = wl + WL_W2B;
+                                              const WaveLds &L, int lane, int v, int r, int s, int j,
+                                              const float x[CIN], float m, const float w2b[C1], float h1[C1],
+                                              float p1[C1]) {
+    constexpr int R = 64 / G;
     layer1_lds(wl, x, h1);
-    // tile <- h1 (16 cols); mask vector
-    if (lane < T) {
 #pragma unroll
-        for (int o = 0; o < C1; ++o) L.tile[lane * TS + o] = h1[o];
-        L.vec[V_MK + lane] = m;
-    }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < C1) {
-        float mx; int amx;
-        scan_max(L.tile, T, lane, stats[ST1 + lane], stats[ST1 + 2 * C1 + lane], stats[ST1 + 3 * C1 + lane], mx, amx);
-        L.vec[V_AGG1 + lane] = mx;
-        if (WANT_AM1) L.vec[V_AM1 + lane] = __int_as_float(amx);
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int o = 0; o < C1; ++o)
+    for (int o = 0; o < C1; ++o) {
         p1[o] = fmaf(stats[ST1 + 2 * C1 + o], h1[o] - stats[ST1 + o], stats[ST1 + 3 * C1 + o]);
-    // u[o] = sum_i W2[o][16+i] * agg1[i]   (lane = o)
-    {
+        L.tile[lane * TS + o] = p1[o];
+    }
+    L.mk[lane] = m;
+    if (j == 0) { L.sid[s] = v; L.sid[8 + s] = r; }
+    __builtin_amdgcn_wave_barrier();
+    // (slot, channel) tasks: agg1 = max over the slot's rows, first index on ties
+    for (int task = lane; task < G * C1; task += 64) {
+        const int ts = task >> 4, c = task & 15;
+        const int tr = L.sid[8 + ts];
+        const int tmax = G == 1 ? uni(tr) : R;
+        float mx = -INFINITY;
+        int amx = 0;
+        for (int t = 0; t < tmax; ++t) {
+            const float p = L.tile[(ts * R + t) * TS + c];
+            if (t < tr && p > mx) { mx = p; amx = t; }
+        }
+        L.sv[ts * SV + V_AGG1 + c] = tr > 0 ? mx : 0.f;      // empty slot: keep idle lanes finite
+        if (WANT_AM1) L.sv[ts * SV + V_AM1 + c] = __int_as_float(amx);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // u[slot][o] = sum_i W2[o][16+i] * agg1[slot][i]   (lane = o)
+#pragma unroll
+    for (int ts = 0; ts < G; ++ts) {
         float u = 0.f;
 #pragma unroll
-        for (int i = 0; i < C1; ++i) u = fmaf(w2b_lds[i * C2 + lane], L.vec[V_AGG1 + i], u);
-        L.vec[V_U + lane] = u;
+        for (int i = 0; i < C1; ++i) u = fmaf(w2b[i], L.sv[ts * SV + V_AGG1 + i], u);
+        L.sv[ts * SV + V_U + lane] = u;
     }
-    if (lane < T) {
+    if (WANT_P1T) {
 #pragma unroll
         for (int i = 0; i < C1; ++i) L.p1t[lane * 16 + i] = p1[i] * m;
     }
     __builtin_amdgcn_wave_barrier();
-    // h2[o] = relu(b2[o] + sum_{i<16} W2[o][i]*p1[i]*m + m*u[o]) -> straight into the tile (h1 was consumed
-    // by the scan above; this lane's own tile row is written, never held in 64 registers)
-    const int trow = (lane < T ? lane : T) * TS;      // lanes >= T dump into the spare row T
+    // h2[o] = relu(b2[o] + m * (sum_{i<16} W2[o][i]*p1[i] + u[o])) -> this lane's tile row (p1 was consumed above)
+    const float *uvec = L.sv + s * SV + V_U;
 #pragma unroll VFE_O_UNROLL
     for (int o = 0; o < C2; ++o) {
         float a = 0.f;
 #pragma unroll
         for (int i = 0; i < C1; ++i) a = fmaf(wl[WL_W2A + o * C1 + i], p1[i], a);
-        a = fmaf(m, a + L.vec[V_U + o], wl[WL_B2 + o]);
-        L.tile[trow + o] = fmaxf(a, 0.f);
+        a = fmaf(m, a + uvec[o], wl[WL_B2 + o]);
+        L.tile[lane * TS + o] = fmaxf(a, 0.f);
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-// combine per-wave lane values across the 4 waves of the workgroup and write the slab
-__device__ __forceinline__ void slab_write(float *red /*[4][n]*/, const float *vals, int nvals_per_lane, int lane,
+// combine per-wave lane values (lane = channel) across the waves of the workgroup and write the slab
+__device__ __forceinline__ void slab_write(float *red /*[NW][n]*/, const float *vals, int nvals_per_lane, int lane,
                                            int wave, float *slab) {
-    // red layout: [wave][j*64 + lane]
     const int n = nvals_per_lane * 64;
     for (int j = 0; j < nvals_per_lane; ++j) red[wave * n + j * 64 + lane] = vals[j];
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) slab[i] = red[i] + red[n + i] + red[2 * n + i] + red[3 * n + i];
+    for (int i = threadIdx.x; i < n; i += NT) {
+        float a = 0.f;
+        for (int w = 0; w < NW; ++w) a += red[w * n + i];
+        slab[i] = a;
+    }
+}
+
+// slab[e] = sum over all row lanes of the workgroup of vals[e] (per-lane accumulators of row-lane phases)
+template <int N>
+__device__ __forceinline__ void lane_sums_to_slab(const float (&vals)[N], float *red, int lane, int wave, float *slab) {
+#pragma unroll
+    for (int c0 = 0; c0 < N; c0 += 32) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 32; ++e)
+            if (c0 + e < N) red[(wave * 32 + e) * TS + lane] = vals[c0 + e];
+        __syncthreads();
+        if (threadIdx.x < 32 && c0 + (int)threadIdx.x < N) {
+            float a = 0.f;
+            for (int w = 0; w < NW; ++w)
+                for (int l = 0; l < 64; ++l) a += red[(w * 32 + threadIdx.x) * TS + l];
+            slab[c0 + threadIdx.x] = a;
+        }
+    }
 }
 
 __device__ __forceinline__ void load_weights_lds(const VfeParams &P, float *wl) {
-    for (int idx = threadIdx.x; idx < C1 * C2; idx += 256) {
+    for (int idx = threadIdx.x; idx < C1 * C2; idx += NT) {
         const int o = idx / C1, i = idx - o * C1;
         wl[WL_W2A + idx] = P.w2[o * 32 + i];                 // first half of W2, [o][i]
         const int i2 = idx / C2, o2 = idx - i2 * C2;
-        wl[WL_W2B + idx] = P.w2[o2 * 32 + 16 + i2];          // second half transposed: [i][o] = W2[o][16+i]
+        wl[WL_W2B + i2 * TS + o2] = P.w2[o2 * 32 + 16 + i2];  // second half transposed: [i][o] = W2[o][16+i]
     }
-    for (int idx = threadIdx.x; idx < C1 * CIN; idx += 256) wl[WL_W1 + idx] = P.w1[idx];
+    for (int idx = threadIdx.x; idx < C1 * CIN; idx += NT) wl[WL_W1 + idx] = P.w1[idx];
     if (threadIdx.x < C1) wl[WL_B1 + threadIdx.x] = P.b1[threadIdx.x];
     if (threadIdx.x < C2) wl[WL_B2 + threadIdx.x] = P.b2[threadIdx.x];
     __syncthreads();
 }
 
-// ---- forward passes ---------------------------------------------------------------------
-// pass 1: sums of h1 ; slab[b] = [sum(16) | sumsq(16)]
-__global__ void __launch_bounds__(256) k_vfe_p1(const float *__restrict__ feature, int64_t K, int T, VfeParams P,
-                                                float *__restrict__ slabs) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *tile = smem + (size_t)wave * T * TS;
-    float s1 = 0.f, s2 = 0.f;
-    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
-        float x[CIN], m, h1[C1];
-        load_row(feature, v, T, lane, x, m);
-        layer1(P, x, h1);
-        if (lane < T) {
-#pragma unroll
-            for (int o = 0; o < C1; ++o) tile[lane * TS + o] = h1[o];
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < C1) {
-            for (int t = 0; t < T; ++t) { const float h = tile[t * TS + lane]; s1 += h; s2 += h * h; }
-        }
-        __builtin_amdgcn_wave_barrier();
+// run BODY<G>(first, n, item) for every item of this wave, class by class (wave-uniform branches)
+#define VFE_FOR_ITEMS(it, BODY)                                                                                       \
+    for (int item_ = blockIdx.x * NW + wave; item_ < (it).total; item_ += gridDim.x * NW) {                            \
+        asm volatile("" ::: "memory"); /* uniform operands are re-read from LDS per item, not hoisted */               \
+        if (item_ < (it).itemsA) { BODY(8, 0, (it).nA, item_) }                                                         \
+        else if (item_ < (it).itemsA + (it).itemsB) { BODY(4, (it).nA, (it).nB, item_ - (it).itemsA) }                  \
+        else { BODY(1, (it).nA + (it).nB, (it).nC, item_ - (it).itemsA - (it).itemsB) }                                 \
     }
-    __syncthreads();
-    // pack: lanes 0..15 sum, lanes 16..31 sumsq
-    const float sq = __shfl(s2, lane & 15, 64);
-    float vals[1] = {lane < C1 ? s1 : (lane < 2 * C1 ? sq : 0.f)};
-    slab_write(smem, vals, 1, lane, wave, slabs + (size_t)blockIdx.x * 64);
+
+// ---- pre-pass ---------------------------------------------------------------------------
+// rows[v] = 1 + index of the last slot whose 7 values differ (bit-wise) from slot T-1; one wave per voxel
+__global__ void __launch_bounds__(256) k_vfe_rows(const float *__restrict__ feature, int64_t K, int T,
+                                                  uint8_t *__restrict__ rows) {
+    const int lane = threadIdx.x & 63;
+    const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (v >= K) return;
+    const uint32_t *f = reinterpret_cast<const uint32_t *>(feature) + v * T * CIN;
+    bool differs = false;
+    if (lane < T - 1) {
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) differs |= f[lane * CIN + i] != f[(T - 1) * CIN + i];
+    }
+    const unsigned long long mask = __ballot(differs);
+    const int last = mask ? 64 - __clzll(mask) : 0;     // slots 0..last-1 are individual
+    if (lane == 0) rows[v] = (uint8_t)(last + 1);       // <= T
 }
 
-// pass 2: sums of h2 ; slab[b] = [sum(64) | sumsq(64)]
-__global__ void __launch_bounds__(256) k_vfe_p2(const float *__restrict__ feature, int64_t K, int T, VfeParams P,
-                                                const float *__restrict__ stats, float *__restrict__ slabs) {
+// stable partition of the voxel ids by class (one workgroup; K <= a few 100k): list = [A.. | B.. | C..]
+__global__ void __launch_bounds__(1024) k_vfe_partition(const uint8_t *__restrict__ rows, int64_t K, int32_t *__restrict__ list,
+                                                        int32_t *__restrict__ counts) {
+    __shared__ int cnt[3][1024];
+    const int tid = threadIdx.x;
+    const int64_t per = (K + 1023) / 1024, lo = tid * per, hi = lo + per < K ? lo + per : K;
+    int c[3] = {0, 0, 0};
+    for (int64_t v = lo; v < hi; ++v) {
+        const int r = rows[v];
+        ++c[r <= 8 ? 0 : (r <= 16 ? 1 : 2)];
+    }
+    for (int k = 0; k < 3; ++k) cnt[k][tid] = c[k];
+    __syncthreads();
+    // inclusive scan per class (Hillis-Steele over 1024 entries)
+    for (int off = 1; off < 1024; off <<= 1) {
+        int t[3];
+        for (int k = 0; k < 3; ++k) t[k] = tid >= off ? cnt[k][tid - off] : 0;
+        __syncthreads();
+        for (int k = 0; k < 3; ++k) cnt[k][tid] += t[k];
+        __syncthreads();
+    }
+    const int nA = cnt[0][1023], nB = cnt[1][1023];
+    int pos[3] = {cnt[0][tid] - c[0], nA + cnt[1][tid] - c[1], nA + nB + cnt[2][tid] - c[2]};
+    for (int64_t v = lo; v < hi; ++v) {
+        const int r = rows[v];
+        list[pos[r <= 8 ? 0 : (r <= 16 ? 1 : 2)]++] = (int32_t)v;
+    }
+    if (tid == 0) { counts[0] = nA; counts[1] = nB; counts[2] = cnt[2][1023]; }
+}
+
+// ---- forward passes ---------------------------------------------------------------------
+// pass 1: weighted sums of h1 ; slab[b] = [sum(16) | sumsq(16) | 0(32)]
+__global__ void __launch_bounds__(NT) k_vfe_p1(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+                                               float *__restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const Items it = load_items(wk);
+    float acc[2 * C1];
+#pragma unroll
+    for (int o = 0; o < 2 * C1; ++o) acc[o] = 0.f;
+#define BODY_P1(G, first, n, item)                                                     \
+    {                                                                                  \
+        int v, r, s, j; float wgt;                                                     \
+        item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);                    \
+        float x[CIN], m, h1[C1];                                                       \
+        load_row(feature, v, T, j, j < r, x, m);                                       \
+        layer1(P, x, h1);                                                              \
+        _Pragma("unroll") for (int o = 0; o < C1; ++o) {                               \
+            const float wh = wgt * h1[o];                                              \
+            acc[o] += wh;                                                              \
+            acc[C1 + o] = fmaf(wh, h1[o], acc[C1 + o]);                                \
+        }                                                                              \
+    }
+    VFE_FOR_ITEMS(it, BODY_P1)
+#undef BODY_P1
+    float *slab = slabs + (size_t)blockIdx.x * SLAB_P1;
+    lane_sums_to_slab(acc, smem, lane, wave, slab);
+    if (threadIdx.x >= 32 && threadIdx.x < 64) slab[threadIdx.x] = 0.f;
+}
+
+// pass 2: weighted sums of h2 ; slab[b] = [sum(64) | sumsq(64)]
+template <int G>
+__device__ __forceinline__ void p2_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
+                                        int item, const float *wl, const float *stats, const WaveLds &L, int lane,
+                                        const float w2b[C1], float &s1, float &s2) {
+    int v, r, s, j; float wgt;
+    item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
+    float x[CIN], m, h1[C1], p1[C1];
+    load_row(feature, v, T, j, j < r, x, m);
+    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, w2b, h1, p1);
+    L.p1t[lane] = wgt;                          // row weights (p1t is free in this pass)
+    __builtin_amdgcn_wave_barrier();
+    for (int t = 0; t < 64; ++t) {              // lane = channel; idle rows weigh 0 and hold finite values
+        const float h = L.tile[t * TS + lane], wh = L.p1t[t] * h;
+        s1 += wh;
+        s2 = fmaf(wh, h, s2);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(NT) k_vfe_p2(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+                                               const float *__restrict__ stats, float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *wl = smem;
     load_weights_lds(P, wl);
-    const WaveLds L = carve_lds(smem + WL_SIZE, wave, T);
+    const WaveLds L = carve_lds(smem + WL_END, wave);
+    const Items it = load_items(wk);
+    float w2b[C1];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) w2b[i] = wl[WL_W2B + i * TS + lane];
     float s1 = 0.f, s2 = 0.f;
-    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
-        float x[CIN], m, h1[C1], p1[C1];
-        load_row(feature, v, T, lane, x, m);
-        forward_to_h2<false>(wl, stats, L, T, lane, x, m, h1, p1);
-        for (int t = 0; t < T; ++t) { const float h = L.tile[t * TS + lane]; s1 += h; s2 += h * h; }
-        __builtin_amdgcn_wave_barrier();
-    }
+#define BODY_P2(G, first, n, item) p2_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, w2b, s1, s2);
+    VFE_FOR_ITEMS(it, BODY_P2)
+#undef BODY_P2
     __syncthreads();
     float vals[2] = {s1, s2};
-    slab_write(smem, vals, 2, lane, wave, slabs + (size_t)blockIdx.x * 128);
+    slab_write(smem, vals, 2, lane, wave, slabs + (size_t)blockIdx.x * SLAB_P2);
 }
 
 // pass 3: voxelwise output (K,128)
-__global__ void __launch_bounds__(256) k_vfe_p3(const float *__restrict__ feature, int64_t K, int T, VfeParams P,
-                                                const float *__restrict__ stats, float *__restrict__ voxelwise) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *wl = smem;
-    load_weights_lds(P, wl);
-    const WaveLds L = carve_lds(smem + WL_SIZE, wave, T);
-    const float mean2 = stats[ST2 + lane], S2 = stats[ST2 + 2 * C2 + lane], be2 = stats[ST2 + 3 * C2 + lane];
-    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
-        float x[CIN], m, h1[C1], p1[C1];
-        load_row(feature, v, T, lane, x, m);
-        forward_to_h2<false>(wl, stats, L, T, lane, x, m, h1, p1);
-        // lane = channel: agg2 = max_t p2 ; vw_lo = max_t p2*m ; vw_hi = max_t agg2*m
-        float agg = -INFINITY, vlo = -INFINITY;
-        float anym = 0.f, allm = 1.f;
-        for (int t = 0; t < T; ++t) {
-            const float p = fmaf(S2, L.tile[t * TS + lane] - mean2, be2);
-            const float mk = L.vec[V_MK + t];
+template <int G>
+__device__ __forceinline__ void p3_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
+                                        int item, const float *wl, const float *stats, const WaveLds &L, int lane,
+                                        const float w2b[C1], float mean2, float S2, float be2,
+                                        float *__restrict__ voxelwise) {
+    constexpr int R = 64 / G;
+    int v, r, s, j; float wgt;
+    item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
+    float x[CIN], m, h1[C1], p1[C1];
+    load_row(feature, v, T, j, j < r, x, m);
+    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, w2b, h1, p1);
+    // lane = channel, per voxel: agg2 = max_t p2 ; vw_lo = max_t p2*m ; vw_hi = max_t agg2*m
+    for (int ts = 0; ts < G; ++ts) {
+        const int tv = uni(L.sid[ts]), tr = uni(L.sid[8 + ts]);
+        if (tv < 0) continue;
+        float agg = -INFINITY, vlo = -INFINITY, anym = 0.f, allm = 1.f;
+        for (int t = 0; t < tr; ++t) {
+            const float p = fmaf(S2, L.tile[(ts * R + t) * TS + lane] - mean2, be2);
+            const float mk = L.mk[ts * R + t];
             agg = fmaxf(agg, p);
             vlo = fmaxf(vlo, p * mk);
             anym = fmaxf(anym, mk);
@@ -264,10 +407,27 @@ __global__ void __launch_bounds__(256) k_vfe_p3(const float *__restrict__ featur
         }
         float vhi = agg * anym;                       // all masks equal -> agg*m
         if (anym != allm) vhi = fmaxf(agg, 0.f);      // both 0 and 1 present
-        voxelwise[v * 128 + lane] = vlo;
-        voxelwise[v * 128 + 64 + lane] = vhi;
-        __builtin_amdgcn_wave_barrier();
+        voxelwise[(int64_t)tv * 128 + lane] = vlo;
+        voxelwise[(int64_t)tv * 128 + 64 + lane] = vhi;
     }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(NT) k_vfe_p3(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+                                               const float *__restrict__ stats, float *__restrict__ voxelwise) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float *wl = smem;
+    load_weights_lds(P, wl);
+    const WaveLds L = carve_lds(smem + WL_END, wave);
+    const Items it = load_items(wk);
+    float w2b[C1];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) w2b[i] = wl[WL_W2B + i * TS + lane];
+    const float mean2 = stats[ST2 + lane], S2 = stats[ST2 + 2 * C2 + lane], be2 = stats[ST2 + 3 * C2 + lane];
+#define BODY_P3(G, first, n, item) p3_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, w2b, mean2, S2, be2, voxelwise);
+    VFE_FOR_ITEMS(it, BODY_P3)
+#undef BODY_P3
 }
 
 // block-wide sum of slab columns: pair (c, C + c) of every slab, in double (fixed order -> deterministic)
@@ -324,61 +484,79 @@ __global__ void __launch_bounds__(256) k_vfe_finalize(const float *__restrict__ 
 }
 
 // ---- backward passes --------------------------------------------------------------------
-// channel-lane analysis of layer-2 outputs for one voxel: impulses of d_p2
+// channel-lane analysis of layer-2 outputs for one voxel slot (rows row0 .. row0+tr-1): impulses of d_p2
 //   r1 = argmax_t p2*m (first), g1 = dvw[c]*m[r1] ; r2 = argmax_t p2, g2 = dvw[64+c]*m[a'], a' = argmax_t agg2*m
-__device__ __forceinline__ void impulses(const WaveLds &L, int T, int lane, float mean2, float S2, float be2,
+__device__ __forceinline__ void impulses(const WaveLds &L, int row0, int tr, int lane, float mean2, float S2, float be2,
                                          float dlo, float dhi, int &r1, float &g1, int &r2, float &g2, float &xh1,
                                          float &xh2, float inv2) {
     float agg = -INFINITY, vlo = -INFINITY;
     r1 = 0; r2 = 0;
     float h_r1 = 0.f, h_r2 = 0.f;
-    for (int t = 0; t < T; ++t) {
-        const float h = L.tile[t * TS + lane];
+    for (int t = 0; t < tr; ++t) {
+        const float h = L.tile[(row0 + t) * TS + lane];
         const float p = fmaf(S2, h - mean2, be2);
-        const float pm = p * L.vec[V_MK + t];
+        const float pm = p * L.mk[row0 + t];
         if (p > agg) { agg = p; r2 = t; h_r2 = h; }
         if (pm > vlo) { vlo = pm; r1 = t; h_r1 = h; }
     }
     // a' = first t maximising agg*m[t]
     int ap = 0;
     float best = -INFINITY;
-    for (int t = 0; t < T; ++t) {
-        const float q = agg * L.vec[V_MK + t];
+    for (int t = 0; t < tr; ++t) {
+        const float q = agg * L.mk[row0 + t];
         if (q > best) { best = q; ap = t; }
     }
-    g1 = dlo * L.vec[V_MK + r1];
-    g2 = dhi * L.vec[V_MK + ap];
+    g1 = dlo * L.mk[row0 + r1];
+    g2 = dhi * L.mk[row0 + ap];
     xh1 = (h_r1 - mean2) * inv2;
     xh2 = (h_r2 - mean2) * inv2;
 }
 
 // backward pass 1: BN2 sums ; slab = [sum d_p2 (64) | sum d_p2*xhat2 (64)]
-__global__ void __launch_bounds__(256) k_vfe_b1(const float *__restrict__ feature, int64_t K, int T, VfeParams P,
-                                                const float *__restrict__ stats, const float *__restrict__ dvw,
-                                                float *__restrict__ slabs) {
+template <int G>
+__device__ __forceinline__ void b1_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
+                                        int item, const float *wl, const float *stats, const WaveLds &L, int lane,
+                                        const float w2b[C1], float mean2, float inv2, float S2, float be2,
+                                        const float *__restrict__ dvw, float &s1, float &s2) {
+    constexpr int R = 64 / G;
+    int v, r, s, j; float wgt;
+    item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
+    float x[CIN], m, h1[C1], p1[C1];
+    load_row(feature, v, T, j, j < r, x, m);
+    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, w2b, h1, p1);
+    for (int ts = 0; ts < G; ++ts) {
+        const int tv = uni(L.sid[ts]), tr = uni(L.sid[8 + ts]);
+        if (tv < 0) continue;
+        int r1, r2; float g1, g2, xh1, xh2;
+        impulses(L, ts * R, tr, lane, mean2, S2, be2, dvw[(int64_t)tv * 128 + lane], dvw[(int64_t)tv * 128 + 64 + lane], r1, g1,
+                 r2, g2, xh1, xh2, inv2);
+        s1 += g1 + g2;
+        s2 += g1 * xh1 + g2 * xh2;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(NT) k_vfe_b1(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+                                               const float *__restrict__ stats, const float *__restrict__ dvw,
+                                               float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *wl = smem;
     load_weights_lds(P, wl);
-    const WaveLds L = carve_lds(smem + WL_SIZE, wave, T);
+    const WaveLds L = carve_lds(smem + WL_END, wave);
+    const Items it = load_items(wk);
+    float w2b[C1];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) w2b[i] = wl[WL_W2B + i * TS + lane];
     const float mean2 = stats[ST2 + lane], inv2 = stats[ST2 + C2 + lane], S2 = stats[ST2 + 2 * C2 + lane],
                 be2 = stats[ST2 + 3 * C2 + lane];
     float s1 = 0.f, s2 = 0.f;
-    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
-        float x[CIN], m, h1[C1], p1[C1];
-        load_row(feature, v, T, lane, x, m);
-        forward_to_h2<false>(wl, stats, L, T, lane, x, m, h1, p1);
-        int r1, r2; float g1, g2, xh1, xh2;
-        impulses(L, T, lane, mean2, S2, be2, dvw[v * 128 + lane], dvw[v * 128 + 64 + lane], r1, g1, r2, g2, xh1, xh2,
-                 inv2);
-        s1 += g1 + g2;
-        s2 += g1 * xh1 + g2 * xh2;
-        __builtin_amdgcn_wave_barrier();
-    }
+#define BODY_B1(G, first, n, item) b1_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, w2b, mean2, inv2, S2, be2, dvw, s1, s2);
+    VFE_FOR_ITEMS(it, BODY_B1)
+#undef BODY_B1
     __syncthreads();
     float vals[2] = {s1, s2};
-    slab_write(smem, vals, 2, lane, wave, slabs + (size_t)blockIdx.x * 128);
+    slab_write(smem, vals, 2, lane, wave, slabs + (size_t)blockIdx.x * SLAB_B1);
 }
 
 // BN backward finalize from slabs: coef = [c0|c1|c2], d_gamma, d_beta ; one workgroup per channel
@@ -404,109 +582,129 @@ __global__ void __launch_bounds__(256) k_vfe_bn_bwd_finalize(const float *__rest
 
 // backward pass 2: layer-2 parameter grads, d_p1 rows -> workspace, BN1 sums
 //   slab = [db2 (64) | dW2 (64*32) | sum d_p1 (16) | sum d_p1*xhat1 (16)]
-__global__ void __launch_bounds__(256) k_vfe_b2(const float *__restrict__ feature, int64_t K, int T, VfeParams P,
-                                                const float *__restrict__ stats_g, const float *__restrict__ dvw,
-                                                const float *__restrict__ coef2_g, float *__restrict__ dp1_ws,
-                                                float *__restrict__ slabs) {
+struct B2Acc {
+    float db2, dw2a[C1], dw2b[C1], bn1[2 * C1];
+};
+
+template <int G>
+__device__ __forceinline__ void b2_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
+                                        int item, const float *wl, const float *stats, const float *coef2, const WaveLds &L,
+                                        int lane, const float w2b[C1], float mean2, float inv2, float S2, float be2,
+                                        float c0, float c1, float c2, const float *__restrict__ dvw,
+                                        float *__restrict__ dp1_ws, B2Acc &A) {
+    constexpr int R = 64 / G;
+    int v, r, s, j; float wgt;
+    item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
+    const bool active = j < r;
+    float x[CIN], m, h1[C1], p1[C1];
+    load_row(feature, v, T, j, active, x, m);
+    forward_to_h2<G, true, true>(wl, stats, L, lane, v, r, s, j, x, m, w2b, h1, p1);
+    // lane = channel o, per voxel: d_pre2[t][o] = (h2>0) * (c0*d_p2 + w_t*(c1*(h2-mean) + c2)) written over h2 in the
+    // tile, with db2, s[o] = sum_t m_t d_pre2 and dW2a[o][i] += sum_t d_pre2[t][o]*p1m[t][i] on the way
+    for (int ts = 0; ts < G; ++ts) {
+        const int tv = uni(L.sid[ts]), tr = uni(L.sid[8 + ts]);
+        if (tv < 0) {
+            L.sv[ts * SV + V_S + lane] = 0.f;
+            continue;
+        }
+        int r1, r2; float g1, g2, xh1, xh2;
+        impulses(L, ts * R, tr, lane, mean2, S2, be2, dvw[(int64_t)tv * 128 + lane], dvw[(int64_t)tv * 128 + 64 + lane], r1, g1,
+                 r2, g2, xh1, xh2, inv2);
+        float sm = 0.f;
+        for (int t = 0; t < tr; ++t) {
+            const int row = ts * R + t;
+            const float h = L.tile[row * TS + lane];
+            float dp = 0.f;
+            if (t == r1) dp += g1;
+            if (t == r2) dp += g2;
+            const float wt = t == tr - 1 ? (float)(T - tr + 1) : 1.f;
+            const float dh = fmaf(c0, dp, wt * fmaf(c1, h - mean2, c2));
+            const float d = h > 0.f ? dh : 0.f;
+            L.tile[row * TS + lane] = d;
+            A.db2 += d;
+            sm = fmaf(L.mk[row], d, sm);
+#pragma unroll
+            for (int i = 0; i < C1; ++i) A.dw2a[i] = fmaf(d, L.p1t[row * 16 + i], A.dw2a[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < C1; ++i) A.dw2b[i] = fmaf(L.sv[ts * SV + V_AGG1 + i], sm, A.dw2b[i]);
+        L.sv[ts * SV + V_S + lane] = sm;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // (slot, i') tasks: d_agg1[i'] = sum_o W2[o][16+i'] * s[o]
+    for (int task = lane; task < G * C1; task += 64) {
+        const int ts = task >> 4, c = task & 15;
+        float da = 0.f;
+        for (int o = 0; o < C2; ++o) da = fmaf(wl[WL_W2B + c * TS + o], L.sv[ts * SV + V_S + o], da);
+        L.sv[ts * SV + V_DAG1 + c] = da;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // row lanes: d_p1m[i] = sum_o d_pre2[o]*W2[o][i] ; d_p1[i] = d_p1m[i]*m + [t == am1[i]] * d_agg1[i]
+    float dp1[C1];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) dp1[i] = 0.f;
+#pragma unroll VFE_O_UNROLL
+    for (int o = 0; o < C2; ++o) {
+        const float d = L.tile[lane * TS + o];
+#pragma unroll
+        for (int i = 0; i < C1; ++i) dp1[i] = fmaf(d, wl[WL_W2A + o * C1 + i], dp1[i]);
+    }
+    const float *svs = L.sv + s * SV;
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        float d = dp1[i] * m;
+        if (__float_as_int(svs[V_AM1 + i]) == j) d += svs[V_DAG1 + i];
+        dp1[i] = active ? d : 0.f;
+    }
+    if (active) {
+        float *dst = dp1_ws + ((int64_t)v * T + j) * C1;
+#pragma unroll
+        for (int i = 0; i < C1; i += 4)
+            *reinterpret_cast<float4 *>(dst + i) = make_float4(dp1[i], dp1[i + 1], dp1[i + 2], dp1[i + 3]);
+    }
+#pragma unroll
+    for (int i = 0; i < C1; ++i) {
+        A.bn1[i] += dp1[i];
+        A.bn1[C1 + i] = fmaf(dp1[i], (h1[i] - stats[ST1 + i]) * stats[ST1 + C1 + i], A.bn1[C1 + i]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+                                               const float *__restrict__ stats_g, const float *__restrict__ dvw,
+                                               const float *__restrict__ coef2_g, float *__restrict__ dp1_ws,
+                                               float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     float *wl = smem;
     load_weights_lds(P, wl);
     // this kernel also keeps the BN statistics and the BN2 backward coefficients in LDS (512 more uniform floats)
-    float *st_l = smem + WL_SIZE, *cf_l = st_l + STATS_FLOATS;
-    for (int i = threadIdx.x; i < STATS_FLOATS; i += 256) st_l[i] = stats_g[i];
-    for (int i = threadIdx.x; i < 3 * C2; i += 256) cf_l[i] = coef2_g[i];
+    float *st_l = smem + WL_ST, *cf_l = smem + WL_CF;
+    for (int i = threadIdx.x; i < STATS_FLOATS; i += NT) st_l[i] = stats_g[i];
+    for (int i = threadIdx.x; i < 3 * C2; i += NT) cf_l[i] = coef2_g[i];
     __syncthreads();
     const float *stats = st_l, *coef2 = cf_l;
-    const WaveLds L = carve_lds(smem + WL_SIZE + 512, wave, T);
+    const WaveLds L = carve_lds(smem + WL_END, wave);
+    const Items it = load_items(wk);
+    float w2b[C1];
+#pragma unroll
+    for (int i = 0; i < C1; ++i) w2b[i] = wl[WL_W2B + i * TS + lane];
     const float mean2 = stats[ST2 + lane], inv2 = stats[ST2 + C2 + lane], S2 = stats[ST2 + 2 * C2 + lane],
                 be2 = stats[ST2 + 3 * C2 + lane];
-    float db2 = 0.f, dw2a[C1], dw2b[C1], bn1 = 0.f;
+    const float c0 = coef2[lane], c1 = coef2[C2 + lane], c2 = coef2[2 * C2 + lane];
+    B2Acc A;
+    A.db2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < C1; ++i) { dw2a[i] = 0.f; dw2b[i] = 0.f; }
-    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
-        float x[CIN], m, h1[C1], p1[C1];
-        load_row(feature, v, T, lane, x, m);
-        forward_to_h2<true>(wl, stats, L, T, lane, x, m, h1, p1);
-        {
-            int r1, r2; float g1, g2, xh1, xh2;
-            impulses(L, T, lane, mean2, S2, be2, dvw[v * 128 + lane], dvw[v * 128 + 64 + lane], r1, g1, r2, g2, xh1,
-                     xh2, inv2);
-            L.vec[V_R1 + lane] = __int_as_float(r1);
-            L.vec[V_G1 + lane] = g1;
-            L.vec[V_R2 + lane] = __int_as_float(r2);
-            L.vec[V_G2 + lane] = g2;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // row-lane: d_pre2[o] = (h2>0) * (c0*d_p2 + c1*(h2-mean) + c2), streamed through the tile IN PLACE
-        // (h2[o] read, d_pre2[o] written back to the same slot) while d_p1m[i] = sum_o d_pre2[o]*W2[o][i] accumulates
-        float dp1[C1];
-#pragma unroll
-        for (int i = 0; i < C1; ++i) dp1[i] = 0.f;
-        const int trow = (lane < T ? lane : T) * TS;
-#pragma unroll VFE_O_UNROLL
-        for (int o = 0; o < C2; ++o) {
-            const float h = L.tile[trow + o];
-            float dp = 0.f;
-            if (__float_as_int(L.vec[V_R1 + o]) == lane) dp += L.vec[V_G1 + o];
-            if (__float_as_int(L.vec[V_R2 + o]) == lane) dp += L.vec[V_G2 + o];
-            const float dh = fmaf(coef2[o], dp, fmaf(coef2[C2 + o], h - stats[ST2 + o], coef2[2 * C2 + o]));
-            const float d = (h > 0.f && lane < T) ? dh : 0.f;
-            L.tile[trow + o] = d;
-#pragma unroll
-            for (int i = 0; i < C1; ++i) dp1[i] = fmaf(d, wl[WL_W2A + o * C1 + i], dp1[i]);
-        }
-        __builtin_amdgcn_wave_barrier();
-        // lane = o: db2, s[o] = sum_t m_t dpre, dW2a[o][i] += sum_t dpre[t][o]*p1m[t][i]
-        float s = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float d = L.tile[t * TS + lane];
-            db2 += d;
-            s = fmaf(L.vec[V_MK + t], d, s);
-#pragma unroll
-            for (int i = 0; i < C1; ++i) dw2a[i] = fmaf(d, L.p1t[t * 16 + i], dw2a[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < C1; ++i) dw2b[i] = fmaf(L.vec[V_AGG1 + i], s, dw2b[i]);
-        L.vec[V_S + lane] = s;
-        __builtin_amdgcn_wave_barrier();
-        // lane = i' < 16: d_agg1[i'] = sum_o W2[o][16+i'] * s[o]
-        if (lane < C1) {
-            float da = 0.f;
-            for (int o = 0; o < C2; ++o) da = fmaf(wl[WL_W2B + lane * C2 + o], L.vec[V_S + o], da);
-            L.vec[V_DAG1 + lane] = da;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // row-lane: d_p1[i] = d_p1m[i]*m + [t == am1[i]] * d_agg1[i] ; store ; BN1 sums through the tile
-#pragma unroll
-        for (int i = 0; i < C1; ++i) {
-            float d = dp1[i] * m;
-            if (__float_as_int(L.vec[V_AM1 + i]) == lane) d += L.vec[V_DAG1 + i];
-            dp1[i] = d;
-        }
-        if (lane < T) {
-            float *dst = dp1_ws + ((int64_t)v * T + lane) * C1;
-#pragma unroll
-            for (int i = 0; i < C1; i += 4)
-                *reinterpret_cast<float4 *>(dst + i) = make_float4(dp1[i], dp1[i + 1], dp1[i + 2], dp1[i + 3]);
-#pragma unroll
-            for (int i = 0; i < C1; ++i) {
-                L.tile[lane * TS + i] = dp1[i];
-                L.tile[lane * TS + C1 + i] = dp1[i] * ((h1[i] - stats[ST1 + i]) * stats[ST1 + C1 + i]);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (lane < 2 * C1) {
-            for (int t = 0; t < T; ++t) bn1 += L.tile[t * TS + lane];
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    for (int i = 0; i < C1; ++i) { A.dw2a[i] = 0.f; A.dw2b[i] = 0.f; A.bn1[i] = 0.f; A.bn1[C1 + i] = 0.f; }
+#define BODY_B2(G, first, n, item) \
+    b2_item<G>(feature, T, wk, first, n, item, wl, stats, coef2, L, lane, w2b, mean2, inv2, S2, be2, c0, c1, c2, dvw, dp1_ws, A);
+    VFE_FOR_ITEMS(it, BODY_B2)
+#undef BODY_B2
     __syncthreads();
     // slab: [db2 | dW2 | bn1]: write through LDS in chunks
     float *slab = slabs + (size_t)blockIdx.x * SLAB_B2;
     {
-        float vals[1] = {db2};
+        float vals[1] = {A.db2};
         slab_write(smem, vals, 1, lane, wave, slab);   // db2[o] at slab[o]
         __syncthreads();
     }
@@ -514,66 +712,57 @@ __global__ void __launch_bounds__(256) k_vfe_b2(const float *__restrict__ featur
         // dW2[o][i] = dw2a[i], dW2[o][16+i] = dw2b[i] ; combined through LDS as [j][lane] then transposed on store
         const int n = 32 * 64;
         for (int j = 0; j < C1; ++j) {
-            smem[wave * n + j * 64 + lane] = dw2a[j];
-            smem[wave * n + (C1 + j) * 64 + lane] = dw2b[j];
+            smem[wave * n + j * 64 + lane] = A.dw2a[j];
+            smem[wave * n + (C1 + j) * 64 + lane] = A.dw2b[j];
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += NT) {
             const int j = i >> 6, o = i & 63;
-            slab[C2 + o * 32 + j] = smem[i] + smem[n + i] + smem[2 * n + i] + smem[3 * n + i];
+            float a = 0.f;
+            for (int w = 0; w < NW; ++w) a += smem[w * n + i];
+            slab[C2 + o * 32 + j] = a;
         }
-        __syncthreads();
     }
-    {
-        float vals[1] = {lane < 2 * C1 ? bn1 : 0.f};
-        slab_write(smem, vals, 1, lane, wave, slab + C2 + C2 * 32);   // 64 wide, first 32 meaningful
-    }
+    lane_sums_to_slab(A.bn1, smem, lane, wave, slab + C2 + C2 * 32);   // first 32 of the 64-wide tail
+    if (threadIdx.x >= 32 && threadIdx.x < 64) slab[C2 + C2 * 32 + threadIdx.x] = 0.f;
 }
 
 // backward pass 3: layer-1 parameter grads ; slab = [dW1 (16*7) | db1 (16)]
-__global__ void __launch_bounds__(256) k_vfe_b3(const float *__restrict__ feature, int64_t K, int T, VfeParams P,
-                                                const float *__restrict__ stats, const float *__restrict__ coef1,
-                                                const float *__restrict__ dp1_ws, float *__restrict__ slabs) {
+__global__ void __launch_bounds__(NT) k_vfe_b3(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+                                               const float *__restrict__ stats, const float *__restrict__ coef1,
+                                               const float *__restrict__ dp1_ws, float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *tile = smem + (size_t)wave * T * TS;
-    // lane handles entries e0 = lane, e1 = lane + 64 of [dW1 (112) | db1 (16)]
-    const int e0 = lane, e1 = lane + 64;
-    const int o0 = e0 / CIN, i0 = e0 - o0 * CIN;                 // e0 < 64 < 112 always a dW1 entry
-    const bool w1e = e1 < C1 * CIN;
-    const int o1 = w1e ? e1 / CIN : e1 - C1 * CIN, i1 = w1e ? e1 - o1 * CIN : 0;
-    float a0 = 0.f, a1 = 0.f;
-    for (int64_t v = (int64_t)blockIdx.x * 4 + wave; v < K; v += (int64_t)gridDim.x * 4) {
-        asm volatile("" ::: "memory");   // uniform operands are re-read from LDS per voxel, not hoisted into 2000 registers
-        float x[CIN], m, h1[C1];
-        load_row(feature, v, T, lane, x, m);
-        layer1(P, x, h1);
-        if (lane < T) {
-            const float *src = dp1_ws + ((int64_t)v * T + lane) * C1;
+    const Items it = load_items(wk);
+    float acc[C1 * CIN + C1];
 #pragma unroll
-            for (int i = 0; i < C1; i += 4) {
-                const float4 d = *reinterpret_cast<const float4 *>(src + i);
-                const float dd[4] = {d.x, d.y, d.z, d.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int o = i + j;
-                    const float dh = fmaf(coef1[o], dd[j], fmaf(coef1[C1 + o], h1[o] - stats[ST1 + o], coef1[2 * C1 + o]));
-                    tile[lane * TS + o] = h1[o] > 0.f ? dh : 0.f;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < CIN; ++i) tile[lane * TS + C1 + i] = x[i];
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int t = 0; t < T; ++t) {
-            a0 = fmaf(tile[t * TS + o0], tile[t * TS + C1 + i0], a0);
-            a1 = w1e ? fmaf(tile[t * TS + o1], tile[t * TS + C1 + i1], a1) : a1 + tile[t * TS + o1];
-        }
-        __builtin_amdgcn_wave_barrier();
+    for (int e = 0; e < C1 * CIN + C1; ++e) acc[e] = 0.f;
+#define BODY_B3(G, first, n, item)                                                                                   \
+    {                                                                                                                \
+        int v, r, s, j; float wgt;                                                                                   \
+        item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);                                                  \
+        const bool active = j < r;                                                                                   \
+        float x[CIN], m, h1[C1];                                                                                     \
+        load_row(feature, v, T, j, active, x, m);                                                                    \
+        layer1(P, x, h1);                                                                                            \
+        if (active) {                                                                                                \
+            const float *src = dp1_ws + ((int64_t)v * T + j) * C1;                                                   \
+            _Pragma("unroll") for (int i = 0; i < C1; i += 4) {                                                      \
+                const float4 d = *reinterpret_cast<const float4 *>(src + i);                                         \
+                const float dd[4] = {d.x, d.y, d.z, d.w};                                                            \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                      \
+                    const int o = i + q;                                                                             \
+                    const float dh = fmaf(coef1[o], dd[q], wgt * fmaf(coef1[C1 + o], h1[o] - stats[ST1 + o], coef1[2 * C1 + o])); \
+                    const float da = h1[o] > 0.f ? dh : 0.f;                                                         \
+                    acc[C1 * CIN + o] += da;                                                                         \
+                    _Pragma("unroll") for (int k = 0; k < CIN; ++k) acc[o * CIN + k] = fmaf(da, x[k], acc[o * CIN + k]); \
+                }                                                                                                    \
+            }                                                                                                        \
+        }                                                                                                            \
     }
-    __syncthreads();
-    float vals[2] = {a0, a1};
-    slab_write(smem, vals, 2, lane, wave, slabs + (size_t)blockIdx.x * 128);
+    VFE_FOR_ITEMS(it, BODY_B3)
+#undef BODY_B3
+    lane_sums_to_slab(acc, smem, lane, wave, slabs + (size_t)blockIdx.x * SLAB_B3);
 }
 
 // out[i] = sum_b slabs[b*stride + off + i]  (double accumulation, fixed order); one wave per output element
@@ -592,67 +781,97 @@ __global__ void __launch_bounds__(256) k_vfe_reduce(const float *__restrict__ sl
 struct Plan {
     int blocks;
     size_t lds_small, lds_full;
-    size_t off_slabs, off_coef, off_dp1, bytes;
+    size_t off_slabs, off_coef, off_rows, off_list, off_counts, off_dp1, bytes;
 };
 
 Plan make_plan(int64_t K, int T) {
     Plan p{};
-    int64_t b = vn_ceil_div(K, 4);
+    int64_t b = vn_ceil_div(K, 2 * NW);   // items are K/8 .. K; every wave loops over its share
     if (b < 1) b = 1;
     if (b > VFE_BLOCKS_MAX) b = VFE_BLOCKS_MAX;
     p.blocks = (int)b;
-    p.lds_small = (size_t)4 * T * TS * sizeof(float);
-    const size_t per_wave = ((size_t)(T + 1) * TS + (size_t)T * 16 + V_SIZE) * sizeof(float);
-    size_t full = (size_t)(WL_SIZE + 512) * sizeof(float) + 4 * per_wave;
-    const size_t red = (size_t)4 * 32 * 64 * sizeof(float);   // slab combine area of pass b2
+    p.lds_small = (size_t)NW * 32 * TS * sizeof(float);                                     // lane_sums_to_slab only
+    size_t full = (size_t)(WL_END + NW * WAVE_FLOATS) * sizeof(float);
+    const size_t red = (size_t)NW * 32 * 64 * sizeof(float);   // slab combine area of pass b2
     if (full < red) full = red;
     p.lds_full = full;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += vn_align(bytes); return r; };
+    const size_t k1 = (size_t)(K > 0 ? K : 1);
     p.off_slabs = take((size_t)VFE_BLOCKS_MAX * SLAB_B2 * sizeof(float));
     p.off_coef = take((size_t)(3 * C1 + 3 * C2) * sizeof(float));
-    p.off_dp1 = take((size_t)(K > 0 ? K : 1) * T * C1 * sizeof(float));
+    p.off_rows = take(k1);
+    p.off_list = take(k1 * sizeof(int32_t));
+    p.off_counts = take(4 * sizeof(int32_t));
+    p.off_dp1 = take(k1 * T * C1 * sizeof(float));
     p.bytes = off;
     return p;
+}
+
+int set_lds_attrs() {
+    static const hipError_t st = [] {
+        const void *fns[] = {reinterpret_cast<const void *>(&k_vfe_p1), reinterpret_cast<const void *>(&k_vfe_p2),
+                             reinterpret_cast<const void *>(&k_vfe_p3), reinterpret_cast<const void *>(&k_vfe_b1),
+                             reinterpret_cast<const void *>(&k_vfe_b2), reinterpret_cast<const void *>(&k_vfe_b3)};
+        for (const void *f : fns) {
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }();
+    return (int)st;
+}
+
+// effective rows per voxel + the class lists (2 small launches)
+int build_worklist(const float *feature, int64_t K, int T, char *ws, const Plan &pl, hipStream_t st, WorkList *wk) {
+    uint8_t *rows = reinterpret_cast<uint8_t *>(ws + pl.off_rows);
+    int32_t *list = reinterpret_cast<int32_t *>(ws + pl.off_list);
+    int32_t *counts = reinterpret_cast<int32_t *>(ws + pl.off_counts);
+    k_vfe_rows<<<(unsigned)vn_ceil_div(K, 4), 256, 0, st>>>(feature, K, T, rows);
+    VN_LAUNCH_STATUS();
+    k_vfe_partition<<<1, 1024, 0, st>>>(rows, K, list, counts);
+    VN_LAUNCH_STATUS();
+    *wk = WorkList{rows, list, counts};
+    return VN_OK;
 }
 
 }  // namespace
 
 extern "C" size_t vn_vfe_workspace_bytes(int64_t K, int32_t T) {
-    if (K < 0 || T <= 0 || T > 64) return 0;
+    if (K < 0 || K >= (1ll << 31) / 64 || T <= 0 || T > 64) return 0;
     return make_plan(K, T).bytes;
 }
 
 extern "C" int vn_vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, int32_t training,
                           float momentum, float eps, float *voxelwise, float *stats, void *workspace,
                           size_t workspace_bytes, vnStream stream) {
-    VN_CHECK_ARG(w && stats && workspace && K >= 0 && T > 0 && T <= 64);
+    VN_CHECK_ARG(w && stats && workspace && K >= 0 && K < (1ll << 31) / 64 && T > 0 && T <= 64);
     VN_CHECK_ARG(w->w1 && w->b1 && w->g1 && w->be1 && w->rm1 && w->rv1 && w->w2 && w->b2 && w->g2 && w->be2 && w->rm2 &&
                  w->rv2);
     const Plan pl = make_plan(K, T);
     if (workspace_bytes < pl.bytes) return VN_EWORKSPACE;
     hipStream_t st = vn_stream(stream);
-    float *slabs = reinterpret_cast<float *>(static_cast<char *>(workspace) + pl.off_slabs);
+    char *ws = static_cast<char *>(workspace);
+    float *slabs = reinterpret_cast<float *>(ws + pl.off_slabs);
     const VfeParams P{w->w1, w->b1, w->w2, w->b2};
-    static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vfe_p2),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vfe_p3),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t a3 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vfe_p1),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess) return (int)(a1 != hipSuccess ? a1 : a2 != hipSuccess ? a2 : a3);
+    if (const int e = set_lds_attrs()) return e;
     const int64_t rows = K * T;
+    WorkList wk{};
+    if (K > 0) {
+        VN_CHECK_ARG(feature && voxelwise);
+        if (const int e = build_worklist(feature, K, T, ws, pl, st, &wk)) return e;
+    }
     if (training) {
         VN_CHECK_ARG(K > 0);
-        k_vfe_p1<<<pl.blocks, 256, pl.lds_small, st>>>(feature, K, T, P, slabs);
+        k_vfe_p1<<<pl.blocks, NT, pl.lds_small, st>>>(feature, T, P, wk, slabs);
         VN_LAUNCH_STATUS();
-        k_vfe_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, 64, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 1, momentum, eps,
-                                         stats + ST1);
+        k_vfe_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, SLAB_P1, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 1, momentum,
+                                         eps, stats + ST1);
         VN_LAUNCH_STATUS();
-        k_vfe_p2<<<pl.blocks, 256, pl.lds_full, st>>>(feature, K, T, P, stats, slabs);
+        k_vfe_p2<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, slabs);
         VN_LAUNCH_STATUS();
-        k_vfe_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, 128, C2, rows, w->g2, w->be2, w->rm2, w->rv2, 1, momentum, eps,
-                                         stats + ST2);
+        k_vfe_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, SLAB_P2, C2, rows, w->g2, w->be2, w->rm2, w->rv2, 1, momentum,
+                                         eps, stats + ST2);
         VN_LAUNCH_STATUS();
     } else {
         k_vfe_finalize<<<C1, 256, 0, st>>>(nullptr, 0, 0, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 0, momentum, eps, stats + ST1);
@@ -661,8 +880,7 @@ extern "C" int vn_vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVf
         VN_LAUNCH_STATUS();
     }
     if (K == 0) return VN_OK;
-    VN_CHECK_ARG(feature && voxelwise);
-    k_vfe_p3<<<pl.blocks, 256, pl.lds_full, st>>>(feature, K, T, P, stats, voxelwise);
+    k_vfe_p3<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, voxelwise);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -670,7 +888,7 @@ extern "C" int vn_vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVf
 extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, const float *stats,
                           const float *d_voxelwise, const vnVfeGrads *g, void *workspace, size_t workspace_bytes,
                           vnStream stream) {
-    VN_CHECK_ARG(feature && w && stats && d_voxelwise && g && workspace && K > 0 && T > 0 && T <= 64);
+    VN_CHECK_ARG(feature && w && stats && d_voxelwise && g && workspace && K > 0 && K < (1ll << 31) / 64 && T > 0 && T <= 64);
     VN_CHECK_ARG(g->dw1 && g->db1 && g->dg1 && g->dbe1 && g->dw2 && g->db2 && g->dg2 && g->dbe2);
     const Plan pl = make_plan(K, T);
     if (workspace_bytes < pl.bytes) return VN_EWORKSPACE;
@@ -681,19 +899,15 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
     float *coef2 = coef1 + 3 * C1;
     float *dp1 = reinterpret_cast<float *>(ws + pl.off_dp1);
     const VfeParams P{w->w1, w->b1, w->w2, w->b2};
-    static const hipError_t a1 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vfe_b1),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t a2 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vfe_b2),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static const hipError_t a3 = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_vfe_b3),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (a1 != hipSuccess || a2 != hipSuccess || a3 != hipSuccess) return (int)(a1 != hipSuccess ? a1 : a2 != hipSuccess ? a2 : a3);
+    if (const int e = set_lds_attrs()) return e;
     const int64_t rows = K * T;
-    k_vfe_b1<<<pl.blocks, 256, pl.lds_full, st>>>(feature, K, T, P, stats, d_voxelwise, slabs);
+    WorkList wk{};
+    if (const int e = build_worklist(feature, K, T, ws, pl, st, &wk)) return e;   // the workspace need not be the forward's
+    k_vfe_b1<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, d_voxelwise, slabs);
     VN_LAUNCH_STATUS();
-    k_vfe_bn_bwd_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, 128, 0, C2, rows, w->g2, stats + ST2, coef2, g->dg2, g->dbe2);
+    k_vfe_bn_bwd_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, SLAB_B1, 0, C2, rows, w->g2, stats + ST2, coef2, g->dg2, g->dbe2);
     VN_LAUNCH_STATUS();
-    k_vfe_b2<<<pl.blocks, 256, pl.lds_full, st>>>(feature, K, T, P, stats, d_voxelwise, coef2, dp1, slabs);
+    k_vfe_b2<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, d_voxelwise, coef2, dp1, slabs);
     VN_LAUNCH_STATUS();
     k_vfe_reduce<<<C2 / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, 0, C2, g->db2);
     VN_LAUNCH_STATUS();
@@ -702,11 +916,11 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
     k_vfe_bn_bwd_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2 + C2 * 32, C1, rows, w->g1, stats + ST1, coef1,
                                             g->dg1, g->dbe1);
     VN_LAUNCH_STATUS();
-    k_vfe_b3<<<pl.blocks, 256, pl.lds_small, st>>>(feature, K, T, P, stats, coef1, dp1, slabs);
+    k_vfe_b3<<<pl.blocks, NT, pl.lds_small, st>>>(feature, T, P, wk, stats, coef1, dp1, slabs);
     VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<C1 * CIN / 4, 256, 0, st>>>(slabs, pl.blocks, 128, 0, C1 * CIN, g->dw1);
+    k_vfe_reduce<<<C1 * CIN / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B3, 0, C1 * CIN, g->dw1);
     VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<C1 / 4, 256, 0, st>>>(slabs, pl.blocks, 128, C1 * CIN, C1, g->db1);
+    k_vfe_reduce<<<C1 / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B3, C1 * CIN, C1, g->db1);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
