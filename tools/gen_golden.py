@@ -16,6 +16,7 @@ Fixture families:
   middle_tiny     MiddleConvNet fwd+bwd, tiny grid, Car and Pedestrian wiring
   rpn3d_tiny      RPN3D.forward (loss included) + backward with seeded targets
   car_full        one full-size car frame: K, checksums, map lattice
+  targets         utils.generate_anchors / generate_targets on seeded KITTI label lines (stored sparsely)
 """
 import hashlib
 import os
@@ -352,9 +353,61 @@ def gen_car_full():
          reg_stats=np.array([reg.abs().max().item(), reg.mean().item(), reg.std().item()]))
 
 
+def target_labels():
+    """Seeded KITTI label lines (camera coordinates, as the dataset hands them to RPN3D.forward): cars and vans over the
+    crop, overlapping pairs, boxes outside the anchor range, ignored classes, one sample without any object."""
+    rng = np.random.default_rng(77)
+
+    def line(cls, lidar_box):
+        x, y, z, h, w, l, rz = lidar_box
+        cx, cy, cz = ref_utils.lidar_to_camera(x, y, z)
+        ry = -rz - np.pi / 2
+        return f"{cls} 0.00 0 0.00 0.00 0.00 0.00 0.00 {h:.2f} {w:.2f} {l:.2f} {cx:.2f} {cy:.2f} {cz:.2f} {ry:.2f}"
+
+    def car(x=None, y=None, rz=None):
+        return [rng.uniform(4, 66) if x is None else x, rng.uniform(-36, 36) if y is None else y, rng.uniform(-1.9, -1.4),
+                rng.uniform(1.4, 1.7), rng.uniform(1.5, 1.8), rng.uniform(3.4, 4.4), rng.uniform(-1.5, 1.5) if rz is None else rz]
+
+    s0 = [line("Car", car()) for _ in range(6)] + [line("Van", car()), line("Pedestrian", car()),
+                                                     "DontCare -1 -1 -10 503.89 169.71 590.61 190.13 -1 -1 -1 -1000 -1000 -1000 -10"]
+    s1 = [line("Car", car(20.0, 3.0, 0.0)), line("Car", car(20.6, 3.2, 0.05)),          # overlapping pair
+          line("Car", car(-6.0, 0.0, 0.3)), line("Car", car(90.0, 10.0, 0.0)),           # outside the anchor range
+          line("Car", car(35.2, -39.9, 1.5)), line("Car", car(0.1, 39.9, -1.5)), line("Car", car(70.3, 0.0, 0.7))]
+    s2 = [line("Pedestrian", car()), line("Cyclist", car())]                            # nothing accepted for Car
+    s3 = [line("Car", car()) for _ in range(14)]
+    return [s0, s1, s2, s3]
+
+
+def gen_targets():
+    labels = target_labels()
+    arr = np.empty(len(labels), dtype=object)
+    for i, l in enumerate(labels):
+        arr[i] = l
+    anchors = ref_utils.generate_anchors()
+    shape = (ref_utils.cfg.OBJECT.FEATURE_HEIGHT, ref_utils.cfg.OBJECT.FEATURE_WIDTH)
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")               # bbox_iou divides by a zero union now and then
+        pos, neg, tgt = ref_utils.generate_targets(arr, shape, anchors)
+    gt = ref_utils.label_to_gt_box_3d(arr, "Car", "lidar")
+    out = dict(n_samples=np.array(len(labels)), anchors_sha=np.array(sha(anchors)), anchors_corner=anchors[::50, ::44].copy(),
+               shape=np.array(shape))
+    for b in range(len(labels)):
+        out[f"labels{b}"] = np.array(labels[b])
+        out[f"gt{b}"] = gt[b]
+        out[f"pos_idx{b}"] = np.flatnonzero(pos[b]).astype(np.int32)
+        out[f"neg_bits{b}"] = np.packbits(neg[b].reshape(-1).astype(np.uint8))
+        nz = np.flatnonzero(tgt[b])
+        out[f"tgt_idx{b}"] = nz.astype(np.int32)
+        out[f"tgt_val{b}"] = tgt[b].reshape(-1)[nz]
+        out[f"sums{b}"] = np.array([pos[b].sum(), neg[b].sum(), np.abs(tgt[b]).sum()])
+    assert set(np.unique(pos)) <= {0.0, 1.0} and set(np.unique(neg)) <= {0.0, 1.0}
+    save("targets_car", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["voxelize", "featnet", "layers", "middle", "rpn3d", "car_full"]
+    which = sys.argv[1:] or ["voxelize", "featnet", "layers", "middle", "rpn3d", "car_full", "targets"]
     for name in which:
         globals()["gen_" + name]()
