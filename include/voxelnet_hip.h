@@ -461,6 +461,22 @@ size_t vn_clip_sgd_workspace_bytes(int32_t n_chunks);
 int vn_clip_sgd(const vnParamChunk *chunks, int32_t n_chunks, float max_norm, float lr, int32_t scale_grads,
                 void *workspace, size_t workspace_bytes, float *total_norm, vnStream stream);
 
+/* ---- RPN training targets (voxelnet/utils.py:376-473 generate_targets, :344-373 bbox_iou, :213-227
+ * anchor_to_standup_box2d; called by RPN3D.forward, voxelnet/model.py:309) -------------------------------
+ * Per sample b: gt_count[b] ground-truth boxes in lidar coordinates, gt [B,max_gt,7] = (x,y,z,h,w,l,r) float64 and
+ * their stand-up rectangles gt_standup [B,max_gt,4] = (x1,y1,x2,y2) float32 (utils.label_to_gt_box_3d and
+ * corner_to_standup_box2d(center_to_corner_box_2d(.)) on the host: O(boxes) work).  anchors [n_anchors,7] float64 is
+ * utils.generate_anchors().reshape(-1,7): anchor n = (iy*W + ix)*2 + rotation.
+ * Outputs in the reference's channels-last layouts: pos, neg [B,n_anchors] == (B,h,w,2); targets [B,n_anchors,7] ==
+ * (B,h,w,14); float32 (model.py:327-329 converts the float64 arrays).  Which anchors are positive / negative is
+ * bit-exact with the reference, its IoU quirks included; regression targets are float64 arithmetic rounded to fp32. */
+#define VN_TARGETS_MAX_GT 128
+size_t vn_rpn_targets_workspace_bytes(int32_t B, int32_t n_anchors, int32_t max_gt);
+int vn_rpn_targets(const double *anchors, int32_t n_anchors, const double *gt, const float *gt_standup,
+                   const int32_t *gt_count /*device [B]*/, int32_t B, int32_t max_gt, float pos_iou, float neg_iou,
+                   double anchor_h, float *pos, float *neg, float *targets, void *workspace, size_t workspace_bytes,
+                   vnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

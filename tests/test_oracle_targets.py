@@ -60,3 +60,15 @@ def test_iou_quirks():
     iou = ot.bbox_iou(box1, box2)
     ua = (2.0 - 10.0 + 1.0) * (2.0 - 2.0 + 1.0) + 5.0 * 3.0 - 1.0
     assert iou.dtype == np.float32 and iou[0, 0] == np.float32(1.0 / ua) and iou[0, 1] == 0
+
+
+def test_product_host_helpers_match_oracle():
+    """voxelnet_amd.targets' host half (label parsing, camera->lidar, stand-up rectangles, anchors) is NumPy and runs
+    without a GPU: bit-identical to the oracle's restatement on the fixture's labels."""
+    from voxelnet_amd import targets as T
+    g, n, labels = load()
+    for a, b in zip(T.label_to_gt_box_3d(labels, "Car"), ot.label_to_gt_box_3d(labels, "Car")):
+        assert np.array_equal(a, b)
+        assert np.array_equal(T.gt_standup_boxes(a), ot.gt_standup_2d(b))
+    for cls in ("Car", "Pedestrian", "Cyclist"):
+        assert np.array_equal(T.generate_anchors(cls), ot.generate_anchors(cls))

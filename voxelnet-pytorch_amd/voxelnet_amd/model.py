@@ -738,9 +738,9 @@ class _LossFn(torch.autograd.Function):
 
 class RPN3D(nn.Module):
     """model.py:284-362.  forward(x: 7-tuple batch, device) -> 7-tuple like the reference.
-    Targets: pass `targets=(pos_equal_one, neg_equal_one, targets)` (channels-last arrays as
-    utils.generate_targets returns them, model.py:309) or set `target_fn`; CPU target
-    generation itself is outside this path."""
+    Targets (model.py:309): generated on the device from the batch's label lines x[1] (voxelnet_amd/targets.py,
+    csrc/targets.hip), unless `targets=(pos_equal_one, neg_equal_one, targets)` (channels-last arrays as
+    utils.generate_targets returns them) is passed or `target_fn` is set."""
 
     def __init__(self, cls_name="Car", alpha=ALPHA, beta=BETA, sigma=SIGMA):
         super().__init__()
@@ -748,6 +748,7 @@ class RPN3D(nn.Module):
         self.feature_net = FeatureLearningNet(cls_name)
         self.middle_rpn = MiddleConvNet(cls_name)
         self.rpn_output_shape = self.middle_rpn.output_shape
+        self.anchors = None      # model.py:295 utils.generate_anchors(): built with the first target generation
         self.target_fn = None    # callable(label, rpn_output_shape) -> (pos, neg, targets)
         self.sparse_first_layer = True   # first Conv3d only at active sites / occupied voxels (same results)
         self.direct_grads = True         # native path: .grad = views of one persistent flat buffer (no clones);
@@ -779,6 +780,18 @@ class RPN3D(nn.Module):
         if len(pool) < 2 and all(t is not ws for t in pool):
             pool.append(ws)
 
+    def _target_generator(self, device):
+        from .targets import TargetGenerator
+        gen = self.__dict__.get("_targets")
+        if gen is None or gen.device != torch.device(device):
+            gen = TargetGenerator(self.cls_name, device)
+            if tuple(gen.shape) != tuple(self.rpn_output_shape):
+                # (the reference has the same mismatch for Pedestrian / Cyclist: its loss cannot run)
+                raise _lib.VoxelnetHipError(f"anchor grid {tuple(gen.shape)} != RPN output {tuple(self.rpn_output_shape)}")
+            self.__dict__["_targets"] = gen
+            self.anchors = gen.anchors
+        return gen
+
     def detect(self, voxel_features, voxel_coordinates):
         """feature_net + middle_rpn (model.py:305-306), fused."""
         bs = len(voxel_features)
@@ -806,8 +819,12 @@ class RPN3D(nn.Module):
         voxel_coordinates = [c.to(device) for c in voxel_coordinates]
         prob_out, delta_out = self.detect(voxel_features, voxel_coordinates)
         if targets is None:
-            if self.target_fn is None:
-                raise _lib.VoxelnetHipError("RPN3D.forward needs targets=(pos,neg,targets) or a target_fn")
-            targets = self.target_fn(label, self.rpn_output_shape)
+            if self.target_fn is not None:
+                targets = self.target_fn(label, self.rpn_output_shape)
+            elif label is None:
+                raise _lib.VoxelnetHipError("RPN3D.forward needs the batch's labels (x[1]), targets=(pos,neg,targets) or a "
+                                            "target_fn")
+            else:
+                targets = self._target_generator(prob_out.device)(label)
         loss, cls_loss, reg_loss, cpos, cneg = self.loss(prob_out, delta_out, *targets)
         return prob_out, delta_out, loss, cls_loss, reg_loss, cpos, cneg
