@@ -3,7 +3,7 @@ KernelTimer labels "k_gather_gemm") from two rocprofv3 --pmc passes -> profiles/
 roofline object's `traffic`.  FETCH_SIZE is doubled (gfx950: 128-B requests tallied at 64 B; MI355X_MICROARCH.md)."""
 import csv, glob, json, sys, collections
 def load(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     return rows
