@@ -12,7 +12,8 @@ M.set_precision("bf16")
 torch.manual_seed(0)
 model = M.RPN3D("Car").to(dev).train()
 params = list(model.parameters())
-opt = torch.optim.SGD(params, lr=0.01)
+from voxelnet_amd.optim import ClipSGD
+opt = ClipSGD(params, 0.01, 5.0)
 grid = grid_config("Car")
 frames = [torch.from_numpy(f).to(dev) for f in synth.workload_frames(2, batch=2)]
 targets = bench.synthetic_targets(2, 200, 176, 99, dev)
@@ -25,7 +26,6 @@ def step(vox):
         feats, coords = [x[0] for x in fc], [x[1] for x in fc]
     out = model((None, None, feats, None, coords, None, None), dev, targets=targets)
     out[2].backward()
-    torch.nn.utils.clip_grad_norm_(params, 5.0)
     opt.step(); opt.zero_grad(set_to_none=True)
 for vox in (False, True):
     for _ in range(3): step(vox)
