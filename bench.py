@@ -273,10 +273,21 @@ def main():
         print("[bench] per-step ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(step_events, step_events[1:])),
               file=sys.stderr)
     assert torch.isfinite(loss).item(), "non-finite loss"
+    ranks_in_sync = None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # self-check of the data-parallel path (outside the timed region): every rank started from rank 0's weights
+        # and applied the same averaged gradients, so the parameters must still be bit-identical on all ranks
+        with torch.no_grad():
+            cs = torch.stack([torch.stack([p.double().sum(), p.double().abs().sum()]) for p in params]).sum(0)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        ranks_in_sync = bool(torch.equal(lo, hi))
+        if not ranks_in_sync and rank == 0:
+            print("[bench] WARNING: parameter checksums differ between ranks", file=sys.stderr)
 
     # ---- per-kernel durations: HIP events around every MFMA-kernel launch, eager steps on the same inputs
     timer = None
@@ -312,6 +323,8 @@ def main():
             "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
             "model_flops_fraction_of_bf16_peak": value / world * FLOP_PER_PC_FWD_BWD / (PEAK_BF16_DENSE_TFLOPS * 1e12),
         }
+        if ranks_in_sync is not None:
+            res["ranks_in_sync"] = ranks_in_sync       # parameters bit-identical on all ranks after the timed steps
         if timer is not None:
             summ = timer.summary()
             kern = {}

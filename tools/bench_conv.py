@@ -8,10 +8,11 @@ from voxelnet_amd import engine as E, net as N
 
 dev = "cuda:0"
 specs = dict(N.layer_table(2))
+specs["heads"] = N.HEADS
 B = 2
 IN = {"middle_layer.1": (5, 400, 352), "middle_layer.2": (3, 400, 352), "block1.0": (1, 400, 352), "block1.1": (1, 200, 176),
       "deconv1": (1, 200, 176), "block2.0": (1, 200, 176), "block2.1": (1, 100, 88), "deconv2": (1, 100, 88),
-      "block3.0": (1, 100, 88), "block3.1": (1, 50, 44), "deconv3": (1, 50, 44), "middle_layer.0": (10, 400, 352)}
+      "block3.0": (1, 100, 88), "heads": (1, 200, 176), "block3.1": (1, 50, 44), "deconv3": (1, 50, 44), "middle_layer.0": (10, 400, 352)}
 names = sys.argv[1:] or ["middle_layer.1", "middle_layer.2", "block1.0", "block1.1", "block2.1", "block3.1", "deconv1", "deconv3"]
 mode = "bf16"
 
@@ -42,7 +43,7 @@ for name in names:
     else:
         a = (sp.stride, (1, 1, 1), sp.pad, (1, 1, 1))
         b = ((1, 1, 1), (-1, -1, -1), tuple(-p for p in sp.pad), sp.stride)
-    slab = torch.empty((-(-y.M // 32), 2, sp.cout), device=dev) if not sp.transposed else None
+    slab = torch.empty((-(-y.M // 32), 2, sp.cout), device=dev) if not sp.transposed and name != "heads" else None
     t_f = timeit(lambda: E.gather_gemm(x, wp, bias, y, sp.k, sp.cin, sp.cout, *a, od, stats=slab))
     dx = E.Rows(torch.empty((B,) + dims + (sp.cin,), dtype=torch.bfloat16, device=dev), sp.cin)
     dy = E.Rows(torch.randn((B,) + od + (sp.cout,), device=dev).to(torch.bfloat16), sp.cout)
