@@ -477,6 +477,19 @@ int vn_rpn_targets(const double *anchors, int32_t n_anchors, const double *gt, c
                    double anchor_h, float *pos, float *neg, float *targets, void *workspace, size_t workspace_bytes,
                    vnStream stream);
 
+/* ---- inference tail (voxelnet/model.py:364-395 RPN3D.predict: utils.deltas_to_boxes_3d utils.py:476-489,
+ * filter_boxes model.py:28-57, utils.nms utils.py:492-553) ----------------------------------------------
+ * probs (B,2,h,w) and deltas (B,14,h,w): the module's fp32 NCHW outputs, read as the flat (B, n_anchors) and
+ * (B, n_anchors, 7) views the reference's reshapes take (no permute: utils.py:478, model.py:384); anchors
+ * [n_anchors,7] float64.  Per sample: boxes [top_k,7] (x,y,z,h,w,l,r) and scores [top_k] of the kept detections in
+ * descending score, counts[b] of them valid.  score_thres = cfg.RPN.SCORE_THRES (>= keeps), nms_thres =
+ * cfg.RPN.NMS_THRES, top_k = cfg.RPN.NMS_POST_TOPK <= VN_PREDICT_MAX_TOPK. */
+#define VN_PREDICT_MAX_TOPK 64
+size_t vn_rpn_predict_workspace_bytes(int32_t B, int32_t n_anchors);
+int vn_rpn_predict(const float *probs, const float *deltas, const double *anchors, int32_t B, int32_t n_anchors,
+                   float score_thres, double nms_thres, int32_t top_k, double anchor_h, float *boxes, float *scores,
+                   int32_t *counts, void *workspace, size_t workspace_bytes, vnStream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -17,6 +17,7 @@ Fixture families:
   rpn3d_tiny      RPN3D.forward (loss included) + backward with seeded targets
   car_full        one full-size car frame: K, checksums, map lattice
   targets         utils.generate_anchors / generate_targets on seeded KITTI label lines (stored sparsely)
+  predict         utils.deltas_to_boxes_3d + model.filter_boxes (score filter, stand-up boxes, nms) on seeded maps
 """
 import hashlib
 import os
@@ -405,9 +406,41 @@ def gen_targets():
     save("targets_car", **out)
 
 
+
+def predict_maps():
+    """Seeded (B,2,h,w) probabilities and (B,14,h,w) deltas: sparse high scores in clusters (so that the NMS has
+    something to suppress), one sample without any score above the threshold.  No exact score ties: the reference
+    sorts with torch.sort(stable=False) (utils.py:509), so their order is implementation-defined there."""
+    rng = np.random.default_rng(91)
+    B, h, w = 3, 200, 176
+    probs = (rng.random((B, 2, h, w)) * 0.9).astype(np.float32)
+    deltas = (rng.standard_normal((B, 14, h, w)) * 0.15).astype(np.float32)
+    for b in range(2):
+        for _ in range(12):
+            c, y, x = rng.integers(0, 2), rng.integers(2, h - 2), rng.integers(2, w - 8)
+            probs[b, c, y, x:x + 6] = (0.96 + 0.04 * rng.random(6)).astype(np.float32)
+    probs[0, 1, 10, 10] = np.float32(0.96)                 # exactly the threshold (>= keeps it)
+    return probs, deltas
+
+
+def gen_predict():
+    probs, deltas = predict_maps()
+    anchors = ref_utils.generate_anchors()
+    boxes = ref_utils.deltas_to_boxes_3d(deltas, anchors)
+    B = probs.shape[0]
+    batch_probs = probs.reshape((B, -1))
+    ret_b, ret_s = ref_model.filter_boxes(B, batch_probs, boxes, boxes[:, :, [0, 1, 4, 5, 6]], torch.device("cpu"))
+    out = dict(n_samples=np.array(B), boxes_sha=np.array(sha(boxes)), boxes_sample=boxes[:, ::997].copy())
+    for b in range(B):
+        out[f"ret_boxes{b}"] = np.asarray(ret_b[b], dtype=np.float32).reshape(-1, 7)
+        out[f"ret_scores{b}"] = np.asarray(ret_s[b], dtype=np.float32).reshape(-1)
+        out[f"n_above{b}"] = np.array(int((batch_probs[b] >= ref_model.cfg.RPN.SCORE_THRES).sum()))
+    save("predict_car", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["voxelize", "featnet", "layers", "middle", "rpn3d", "car_full", "targets"]
+    which = sys.argv[1:] or ["voxelize", "featnet", "layers", "middle", "rpn3d", "car_full", "targets", "predict"]
     for name in which:
         globals()["gen_" + name]()

@@ -138,6 +138,9 @@ SIGNATURES = {
     "vn_rpn_targets_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "vn_rpn_targets": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, ctypes.c_double, c_vp, c_vp, c_vp,
                                c_vp, c_sz, c_vp]),
+    "vn_rpn_predict_workspace_bytes": (c_sz, [c_i32, c_i32]),
+    "vn_rpn_predict": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, ctypes.c_double, c_i32, ctypes.c_double, c_vp, c_vp, c_vp,
+                               c_vp, c_sz, c_vp]),
     "vn_clip_sgd_workspace_bytes": (c_sz, [c_i32]),
     "vn_clip_sgd": (c_i32, [c_vp, c_i32, c_f32, c_f32, c_i32, c_vp, c_sz, c_vp, c_vp]),
 }

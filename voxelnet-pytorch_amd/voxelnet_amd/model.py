@@ -792,6 +792,26 @@ class RPN3D(nn.Module):
             self.anchors = gen.anchors
         return gen
 
+    def predict(self, data, probs, deltas, summary=False, visual=False):
+        """model.py:364-441 without the drawing branches: -> (tag, ret_box_3d_score), one array per sample of
+        [cls_name, x, y, z, h, w, l, r, score] rows (strings, as np.concatenate makes them at model.py:389-394).
+        Decoding, score filter and NMS run on the device (voxelnet_amd/predict.py, csrc/predict.hip)."""
+        if summary or visual:
+            raise NotImplementedError("the summary / visual branches of RPN3D.predict draw with OpenCV (model.py:396-439): "
+                                      "outside the accelerated path")
+        from .predict import BoxDecoder
+        dec = self.__dict__.get("_decoder")
+        if dec is None or dec.device != probs.device:
+            dec = BoxDecoder(self.cls_name, probs.device)
+            self.__dict__["_decoder"] = dec
+            self.anchors = dec.anchors
+        ret_box_3d, ret_score = dec(probs, deltas)
+        out = []
+        for boxes_3d, scores in zip(ret_box_3d, ret_score):
+            out.append(np.concatenate([np.tile(self.cls_name, len(boxes_3d))[:, np.newaxis], boxes_3d,
+                                       scores[:, np.newaxis]], axis=-1))
+        return data[0], out
+
     def detect(self, voxel_features, voxel_coordinates):
         """feature_net + middle_rpn (model.py:305-306), fused."""
         bs = len(voxel_features)
