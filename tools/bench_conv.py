@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "voxelnet-pytorch_amd")]
 import torch
 from voxelnet_amd import engine as E, net as N
+if os.environ.get("VN_LIB"):        # an experimental build of the library (tools/ubench/bin/*.so)
+    from voxelnet_amd import _lib as _l
+    _l.LIB_PATH = os.path.abspath(os.environ["VN_LIB"])
 
 dev = "cuda:0"
 specs = dict(N.layer_table(2))
