@@ -217,7 +217,29 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
     }
     float s1[8] = {0}, s2[8] = {0};
     if (rr < rpb) {
-        for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
+        // two rows in flight per lane (the loads of both are issued before either is used)
+        const int64_t step = (int64_t)gridDim.x * rpb;
+        int64_t m = (int64_t)blockIdx.x * rpb + rr;
+        for (; m + step < M; m += 2 * step) {
+            float yv[2][8], dv[2][8];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int64_t mu = m + u * step;
+                load8(y, ydt, mu * ystride + g * 8, yv[u]);
+                load8(da, dadt, (fold ? fold_off(mu, fold, dastride, C) : mu * dastride) + g * 8, dv[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d0 = yv[u][j] - mean[j];
+                    const float z = fmaf(S[j], d0, be[j]);
+                    const float dz = (!relu || z > 0.f) ? dv[u][j] : 0.f;
+                    s1[j] += dz;
+                    s2[j] += dz * (d0 * invstd[j]);
+                }
+        }
+        for (; m < M; m += step) {
             float yv[8], dv[8];
             load8(y, ydt, m * ystride + g * 8, yv);
             load8(da, dadt, (fold ? fold_off(m, fold, dastride, C) : m * dastride) + g * 8, dv);
@@ -349,6 +371,12 @@ inline unsigned gs_blocks(int64_t total, int per_block, int cap) {
     if (b > cap) b = cap;
     return (unsigned)b;
 }
+// rows per workgroup of the backward reduction = rpb * BWD_ROWS_PER_LANE (tuning aid VN_BN_RPL; fewer rows per lane =
+// more workgroups in flight on the mid-size layers, more slab rows for the finalize)
+inline int bwd_rpl() {
+    static const int v = [] { const char *e = getenv("VN_BN_RPL"); const int x = e && *e ? atoi(e) : 4; return x < 1 ? 1 : x; }();
+    return v;
+}
 inline bool rows_ok(int C, int64_t stride) { return C >= 8 && (C & 7) == 0 && C <= 2048 && (stride & 7) == 0; }
 
 }  // namespace
@@ -403,7 +431,7 @@ extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_str
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, sums, nullptr, 0);
     VN_LAUNCH_STATUS();
@@ -412,7 +440,7 @@ extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_str
 
 extern "C" int64_t vn_bn_bwd_slab_rows(int64_t M, int32_t C) {
     if (M <= 0 || !rows_ok(C, 8)) return 0;
-    return gs_blocks(M, (256 / (C >> 3)) * 8, 2048);
+    return gs_blocks(M, (256 / (C >> 3)) * bwd_rpl(), 2048);
 }
 
 extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y, vnDtype y_dtype,
@@ -420,7 +448,7 @@ extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t d
                                      float *slab, vnStream stream) {
     VN_CHECK_ARG(slab && M > 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0 && da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, nullptr, slab, 0);
     VN_LAUNCH_STATUS();
@@ -495,7 +523,7 @@ extern "C" int vn_bn_bwd_reduce_slab_bev(const void *da, vnDtype da_dtype, int64
     VN_CHECK_ARG(slab && M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
     VN_CHECK_ARG(da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * 8, 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, wide_stride, y, (int)y_dtype,
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, wide_stride, y, (int)y_dtype,
                                                                                  C, M, C, stats, relu, nullptr, slab, hw);
     VN_LAUNCH_STATUS();
     return VN_OK;
