@@ -371,11 +371,17 @@ inline unsigned gs_blocks(int64_t total, int per_block, int cap) {
     if (b > cap) b = cap;
     return (unsigned)b;
 }
-// rows per workgroup of the backward reduction = rpb * BWD_ROWS_PER_LANE (tuning aid VN_BN_RPL; fewer rows per lane =
-// more workgroups in flight on the mid-size layers, more slab rows for the finalize)
-inline int bwd_rpl() {
-    static const int v = [] { const char *e = getenv("VN_BN_RPL"); const int x = e && *e ? atoi(e) : 4; return x < 1 ? 1 : x; }();
-    return v;
+// Rows per lane of the backward reduction's workgroups: at most 4 (two in flight), and fewer on the small layers so
+// that a launch has ~1000 workgroups — those launches are latency-bound (one HBM round trip per row and lane), not
+// bandwidth-bound.  The slab has one row per workgroup (vn_bn_bwd_slab_rows uses the same rule).
+inline int bwd_rpl(int64_t M, int rpb) {
+    const int64_t r = M / ((int64_t)rpb * 1024);
+    return r < 1 ? 1 : (r > 4 ? 4 : (int)r);
+}
+// 8-channel groups per lane of the backward apply's grid (same reasoning)
+inline int apply_epl(int64_t total) {
+    const int64_t r = total / (256 * 2048);
+    return r < 1 ? 1 : (r > 4 ? 4 : (int)r);
 }
 inline bool rows_ok(int C, int64_t stride) { return C >= 8 && (C & 7) == 0 && C <= 2048 && (stride & 7) == 0; }
 
@@ -431,7 +437,7 @@ extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_str
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, sums, nullptr, 0);
     VN_LAUNCH_STATUS();
@@ -440,7 +446,7 @@ extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_str
 
 extern "C" int64_t vn_bn_bwd_slab_rows(int64_t M, int32_t C) {
     if (M <= 0 || !rows_ok(C, 8)) return 0;
-    return gs_blocks(M, (256 / (C >> 3)) * bwd_rpl(), 2048);
+    return gs_blocks(M, (256 / (C >> 3)) * bwd_rpl(M, 256 / (C >> 3)), 2048);
 }
 
 extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y, vnDtype y_dtype,
@@ -448,7 +454,7 @@ extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t d
                                      float *slab, vnStream stream) {
     VN_CHECK_ARG(slab && M > 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0 && da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, nullptr, slab, 0);
     VN_LAUNCH_STATUS();
@@ -481,7 +487,7 @@ extern "C" int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int64_t da_stri
     VN_CHECK_ARG(lo_off >= 0 && (lo_off & 7) == 0 && (!lo_off || dy_dtype == VN_BF16));
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(da && y && stats && coef && dy);
-    k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * 4, 8192), 256, 0, vn_stream(stream)>>>(
+    k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * apply_epl(M * (C >> 3)), 8192), 256, 0, vn_stream(stream)>>>(
         da, (int)da_dtype, da_stride, y, (int)y_dtype, y_stride, M, C, stats, coef, relu, dy, (int)dy_dtype, dy_stride,
         lo_off, nullptr, 0);
     VN_LAUNCH_STATUS();
@@ -497,7 +503,7 @@ extern "C" int vn_bn_bwd_apply_flagged(const void *da, vnDtype da_dtype, int64_t
     VN_CHECK_ARG(M >= 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0 && (dy_stride & 7) == 0);
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(da && y && stats && coef && dy && row_flags);
-    k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * 4, 8192), 256, 0, vn_stream(stream)>>>(
+    k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * apply_epl(M * (C >> 3)), 8192), 256, 0, vn_stream(stream)>>>(
         da, (int)da_dtype, da_stride, y, (int)y_dtype, y_stride, M, C, stats, coef, relu, dy, (int)dy_dtype, dy_stride, 0,
         row_flags, 0);
     VN_LAUNCH_STATUS();
@@ -523,7 +529,7 @@ extern "C" int vn_bn_bwd_reduce_slab_bev(const void *da, vnDtype da_dtype, int64
     VN_CHECK_ARG(slab && M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
     VN_CHECK_ARG(da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, wide_stride, y, (int)y_dtype,
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, wide_stride, y, (int)y_dtype,
                                                                                  C, M, C, stats, relu, nullptr, slab, hw);
     VN_LAUNCH_STATUS();
     return VN_OK;
@@ -534,7 +540,7 @@ extern "C" int vn_bn_bwd_apply_bev(const void *da, vnDtype da_dtype, int64_t wid
                                    void *dy, vnDtype dy_dtype, vnStream stream) {
     VN_CHECK_ARG(M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
     VN_CHECK_ARG(da && y && stats && coef && dy);
-    k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * 4, 8192), 256, 0, vn_stream(stream)>>>(
+    k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * apply_epl(M * (C >> 3)), 8192), 256, 0, vn_stream(stream)>>>(
         da, (int)da_dtype, wide_stride, y, (int)y_dtype, C, M, C, stats, coef, relu, dy, (int)dy_dtype, C, 0, nullptr, hw);
     VN_LAUNCH_STATUS();
     return VN_OK;
