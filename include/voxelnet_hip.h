@@ -416,9 +416,11 @@ int vn_rows_to_nchw(const void *src, vnDtype src_dtype, int64_t src_stride, int3
 /* row-wise cast/copy of M rows of C channels between strided buffers (+ residual at lo_off) */
 int vn_cast_rows(const void *src, vnDtype src_dtype, int64_t src_stride, int64_t M, int32_t C,
                  void *dst, vnDtype dst_dtype, int64_t dst_stride, int64_t lo_off, vnStream stream);
-/* per-channel column sums of M rows (bias gradients): out[C] += sum_m rows[m,:] (float; caller zeroes) */
+/* per-channel column sums of M rows (bias gradients): out[C] = sum_m rows[m,:] (float), two passes through per-
+ * workgroup partial rows in the workspace — no atomics: bit-reproducible */
+size_t vn_col_sums_workspace_bytes(int64_t M, int32_t C);
 int vn_col_sums(const void *rows, vnDtype dtype, int64_t stride, int64_t M, int32_t C,
-                float *out, vnStream stream);
+                float *out, void *workspace, size_t workspace_bytes, vnStream stream);
 /* heads epilogue (model.py:281): rows (M,16) = [2 prob logits | 14 reg] ->
  * NCHW prob = sigmoid (B,2,S), reg (B,14,S); and its backward:
  * d_rows = [d_prob * p * (1-p) | d_reg] as f32, bf16 or split bf16 rows */

@@ -372,10 +372,15 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     }
     int buf = 0, nbuf = NS - 1;                 // stage consumed by this step / stage the next loads go to
     for (int s = 0; s < nsteps; ++s) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AHEAD) : "memory");
+        // RAW: stage s is read after ITS loads have landed in every wave (counted vmcnt, then the barrier).
+        // WAR: right after the barrier the fastest wave re-stages the buffer step s-1 read — so every wave's LDS reads
+        // of step s-1 must have RETURNED before it arrives: lgkmcnt(0).  (hipcc may sink the last MFMAs of a step, and
+        // with them the wait for their operands, below an asm statement; without this wait the fragment reads of a slow
+        // wave could still be in flight when the DMA overwrote them — one wrong tile in ~10 % of the steps once another
+        // kernel shared the CUs, found by tools/debug_determinism.py.)
         // bare s_barrier: __syncthreads() carries a workgroup fence, which makes hipcc drain vmcnt to 0 (the LDS-DMA
-        // loads of the stages still in flight) and so serialises the pipeline.  The explicit vmcnt above is the
-        // only ordering the LDS hand-off needs: a stage is read after ITS loads have landed in every wave.
+        // loads of the stages still in flight) and so serialises the pipeline.
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AHEAD) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         const bool live = s + NS - 1 < nsteps;
@@ -589,7 +594,9 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
             if (first) { stage_b(wbase, 0, kc, bbuf); first = false; }
             for (int tap = 0; tap < 9; ++tap) {
                 const int ih = tap / 3, iw = tap - ih * 3;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                // (lgkmcnt(0): the previous tap's fragment reads of every wave have returned before the barrier lets the
+                //  fastest wave re-stage that weight buffer — see k_gather_gemm)
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
                 // next weight tile: next tap, or the first tap of the next (plane, chunk)

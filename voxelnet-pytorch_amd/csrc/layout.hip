@@ -210,9 +210,10 @@ __global__ void __launch_bounds__(256) k_cast_rows(const void *__restrict__ src,
     }
 }
 
-// column sums: thread (cg = tid % groups) walks rows; LDS reduce; float atomics
+// column sums, pass 1: thread (cg = tid % groups) walks rows; LDS reduce; one partial row per workgroup (plain stores:
+// no atomics, so the result does not depend on the order in which workgroups finish)
 __global__ void __launch_bounds__(256) k_col_sums(const void *__restrict__ rows, int dtype, int64_t stride, int64_t M,
-                                                  int C, float *__restrict__ out) {
+                                                  int C, float *__restrict__ part /* [gridDim.x][C] */) {
     __shared__ float red[256 * 4];
     const int groups = C >> 2;            // <= 256
     const int rpb = 256 / groups;         // rows per block iteration
@@ -238,7 +239,16 @@ __global__ void __launch_bounds__(256) k_col_sums(const void *__restrict__ rows,
 #pragma unroll
             for (int j = 0; j < 4; ++j) t[j] += red[(r * groups + threadIdx.x) * 4 + j];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(out + threadIdx.x * 4 + j, t[j]);
+        for (int j = 0; j < 4; ++j) part[(size_t)blockIdx.x * C + threadIdx.x * 4 + j] = t[j];
+    }
+}
+
+// pass 2: out[c] = sum of the partial rows in a fixed order (double)
+__global__ void __launch_bounds__(256) k_col_sums_final(const float *__restrict__ part, int nblk, int C, float *__restrict__ out) {
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double s = 0.0;
+        for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * C + c];
+        out[c] = (float)s;
     }
 }
 
@@ -385,13 +395,23 @@ extern "C" int vn_cast_rows(const void *src, vnDtype src_dtype, int64_t src_stri
     return VN_OK;
 }
 
+extern "C" size_t vn_col_sums_workspace_bytes(int64_t M, int32_t C) {
+    if (M <= 0 || C <= 0 || (C & 3) || C > 1024) return 0;
+    return vn_align(sizeof(float) * (size_t)gs_blocks(M, (256 / (C >> 2)) * 16, 256) * C);
+}
+
 extern "C" int vn_col_sums(const void *rows, vnDtype dtype, int64_t stride, int64_t M, int32_t C, float *out,
-                           vnStream stream) {
+                           void *workspace, size_t workspace_bytes, vnStream stream) {
     VN_CHECK_ARG(out && M >= 0 && C > 0 && (C & 3) == 0 && C <= 1024 && (stride & 3) == 0);
-    if (M == 0) return VN_OK;
-    VN_CHECK_ARG(rows);
+    if (M == 0) return (int)hipMemsetAsync(out, 0, sizeof(float) * C, vn_stream(stream));
+    VN_CHECK_ARG(rows && workspace);
+    if (workspace_bytes < vn_col_sums_workspace_bytes(M, C)) return VN_EWORKSPACE;
     const int rpb = 256 / (C >> 2);
-    k_col_sums<<<gs_blocks(M, rpb * 16, 1024), 256, 0, vn_stream(stream)>>>(rows, (int)dtype, stride, M, C, out);
+    const unsigned blocks = gs_blocks(M, rpb * 16, 256);
+    float *part = static_cast<float *>(workspace);
+    k_col_sums<<<blocks, 256, 0, vn_stream(stream)>>>(rows, (int)dtype, stride, M, C, part);
+    VN_LAUNCH_STATUS();
+    k_col_sums_final<<<1, 256, 0, vn_stream(stream)>>>(part, (int)blocks, C, out);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -89,7 +89,7 @@ struct Plan {
     Rows dy[NL], dx[NL];
     float *dwp[NL]; size_t dwp_bytes[NL];   // row-chunk partials of the weight gradient (vn_conv_wgrad_partials)
     // heads
-    void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes;
+    void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes; void *hcs_ws; size_t hcs_ws_bytes;
     // sparse first layer
     int64_t *alist; int32_t *acount; int64_t acap; void *aws; size_t aws_bytes;
     int32_t *igrid; float *rbP;   // rulebook: voxel index grid over the input cells, P[v][tap][64]
@@ -246,6 +246,8 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     P->zb_begin = base ? base + A.off : nullptr;
     for (int l = 0; l < NL; ++l) P->bsums[l] = (double *)A.take(2 * 256 * sizeof(double));
     P->hcs = (float *)A.take(64 * sizeof(float));
+    P->hcs_ws_bytes = vn_col_sums_workspace_bytes((int64_t)B * P->hf * P->wf, 16);
+    P->hcs_ws = A.take(P->hcs_ws_bytes);
     P->zb_end = base ? base + A.off : nullptr;
     for (int l = 0; l < NL; ++l) {
         const Spec &sp = P->spec[l];
@@ -530,8 +532,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
         RT(vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows.ptr, (vnDtype)P.adt, 16, 0, stream));
-        RT(vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, P.hcs, stream));
-        VN_HIP(hipMemcpyAsync(d_heads_b, P.hcs, 16 * sizeof(float), hipMemcpyDeviceToDevice, hs));
+        RT(vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, stream));
         const int od[3] = {1, P.hf, P.wf};
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);

@@ -348,8 +348,10 @@ def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=Fa
         grads["bias"] = torch.zeros(C, dtype=torch.float32, device=dev)
     else:
         width = dy.t.shape[-1]   # column sums of dy (hi + lo parts)
-        cs = torch.zeros(width, dtype=torch.float32, device=dev)
-        _lib.call("vn_col_sums", dy.ptr(), _dt(dy.t), dy.row_stride(), M, width, cs.data_ptr(), stream())
+        cs = torch.empty(width, dtype=torch.float32, device=dev)
+        nb = _lib.load().vn_col_sums_workspace_bytes(M, width)
+        cws = torch.empty(max(nb, 1), dtype=torch.uint8, device=dev)
+        _lib.call("vn_col_sums", dy.ptr(), _dt(dy.t), dy.row_stride(), M, width, cs.data_ptr(), cws.data_ptr(), nb, stream())
         grads["bias"] = cs[:C] + cs[C:2 * C] if width == 2 * C else cs
     # weight gradient
     taps = spec.taps
