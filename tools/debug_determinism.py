@@ -29,6 +29,9 @@ for rep in range(REPS):
             setattr(model, k_, bool(int(v_)))
     params = list(model.parameters())
     names = [n for n, _ in model.named_parameters()]
+    if os.environ.get("VN_DBG_REDUCER") == "1":          # the DDP path (bucket events, comm stream), world size 1
+        from voxelnet_amd import parallel
+        model.grad_reducer = parallel.GradAllReducer(list(model.named_parameters()))
     h, w = model.rpn_output_shape
     g = torch.Generator().manual_seed(3)
     pos = (torch.rand((B, h, w, 2), generator=g) < 0.02).float().to(DEV)
@@ -40,6 +43,8 @@ for rep in range(REPS):
     vw_probe, st_probe = vw_probe.clone(), st_probe.clone()
     out = model((None, None, feats, None, coords, None, None), DEV, targets=(pos, neg, tgt))
     out[2].backward()
+    if model.grad_reducer is not None:
+        model.grad_reducer.finish(list(model.named_parameters()))
     early = torch.nn.utils.clip_grad_norm_(params, 1e9)          # stream order, no sync (as the test does)
     grads = [p.grad.detach().clone() for p in params]
     prob = out[0].detach().clone()
