@@ -434,15 +434,17 @@ int vn_heads_bwd(const float *d_prob /*(B,2,S)*/, const float *d_reg /*(B,14,S)*
  *   pos, neg (B,h,w,2), targets (B,h,w,14): utils.generate_targets' arrays as fp32 channels-last (model.py:309)
  *   out5 = [loss, cls_loss, reg_loss, cls_pos_loss_rec, cls_neg_loss_rec]  (model.py:342-351)
  * vn_rpn_loss_fwd leaves the per-sample normalisers max(1, sum pos), max(1, sum neg) (model.py:313-322) at the
- * head of the workspace; vn_rpn_loss_bwd reads them and the five upstream gradients grad_out5 (device) and
- * writes d loss / d prob and d loss / d delta. */
+ * head of the workspace; vn_rpn_loss_bwd reads them and the upstream gradients of the five outputs — five device
+ * scalars, NULL = 0 (what autograd hands a five-output function; typically only g_loss is set) — and writes
+ * d loss / d prob and d loss / d delta. */
 size_t vn_rpn_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
 int vn_rpn_loss_fwd(const float *prob, const float *delta, const float *pos, const float *neg,
                     const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
                     void *workspace, size_t workspace_bytes, float *out5, vnStream stream);
 int vn_rpn_loss_bwd(const float *prob, const float *delta, const float *pos, const float *neg,
                     const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
-                    const void *workspace, const float *grad_out5, float *d_prob, float *d_delta,
+                    const void *workspace, const float *g_loss, const float *g_cls, const float *g_reg,
+                    const float *g_cls_pos, const float *g_cls_neg, float *d_prob, float *d_delta,
                     vnStream stream);
 
 /* ---- optimizer tail (voxelnet/train.py:153-154 with the optimizer of train.py:130-132) ---------------------

@@ -36,12 +36,20 @@ def test_loss_values_and_gradients(B, H, W, empty):
     (ref * gw.double()).sum().backward()
     # HIP path
     pg, dg = prob.to(DEV).requires_grad_(True), delta.to(DEV).requires_grad_(True)
-    out = M._LossFn.apply(pg, dg, pos.to(DEV), neg.to(DEV), tgt.to(DEV), 1.5, 1.0, 3.0)
-    (out * gw.to(DEV)).sum().backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().numpy(), rtol=1e-5, atol=1e-6)
+    out = M._LossFn.apply(pg, dg, pos.to(DEV), neg.to(DEV), tgt.to(DEV), 1.5, 1.0, 3.0)     # five scalars
+    assert len(out) == 5 and all(o.dim() == 0 for o in out)
+    sum(o * w for o, w in zip(out, gw.to(DEV))).backward()
+    np.testing.assert_allclose([o.item() for o in out], ref.detach().numpy(), rtol=1e-5, atol=1e-6)
     for got, want in ((pg.grad, p64.grad), (dg.grad, d64.grad)):
         got, want = got.cpu().double(), want
         assert (got - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-12
+    # the usual case: only the total loss is differentiated (the other four upstream gradients arrive as None)
+    p64b, d64b = prob.double().requires_grad_(True), delta.double().requires_grad_(True)
+    tr.rpn_loss(p64b, d64b, pos.double(), neg.double(), tgt.double(), 1.5, 1.0, 3.0)[0].backward()
+    pg2, dg2 = prob.to(DEV).requires_grad_(True), delta.to(DEV).requires_grad_(True)
+    M._LossFn.apply(pg2, dg2, pos.to(DEV), neg.to(DEV), tgt.to(DEV), 1.5, 1.0, 3.0)[0].backward()
+    for got, want in ((pg2.grad, p64b.grad), (dg2.grad, d64b.grad)):
+        assert (got.cpu().double() - want).abs().max().item() <= 1e-5 * want.abs().max().item() + 1e-12
 
 
 def test_loss_module_api(golden):

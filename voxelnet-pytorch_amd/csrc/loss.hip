@@ -63,12 +63,18 @@ __device__ __forceinline__ float smooth_l1(float diff, float sigma2, float *ddif
     return o1 * o2 + o2 * (1.f - sign);
 }
 
+// upstream gradients of the five outputs as separate device scalars (what autograd hands a five-output Function: no
+// stack / zeros kernels to assemble a vector); a NULL pointer stands for 0
+struct LossGrads {
+    const float *g[5];
+};
+
 template <bool BWD>
 __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__ prob, const float *__restrict__ reg,
                                                        const float *__restrict__ pos, const float *__restrict__ neg,
                                                        const float *__restrict__ tgt, const float *__restrict__ norm,
                                                        LossGeom g, float *__restrict__ slab /* fwd: [blocks][3] */,
-                                                       const float *__restrict__ gout /* bwd: [5] */,
+                                                       LossGrads gout /* bwd: five device scalars, NULL = 0 */,
                                                        float *__restrict__ d_prob, float *__restrict__ d_reg) {
     const int64_t hw = (int64_t)g.H * g.W, sites = hw * g.B;
     const int64_t site = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x;
@@ -82,7 +88,8 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
         const float pa[2] = {ps.x, ps.y}, na[2] = {ng.x, ng.y};
         float kp = 0.f, kn = 0.f, kr = 0.f;
         if (BWD) {
-            const float gl = gout[0], gc = gout[1], gr = gout[2], gp = gout[3], gn = gout[4];
+            const float gl = gout.g[0] ? *gout.g[0] : 0.f, gc = gout.g[1] ? *gout.g[1] : 0.f, gr = gout.g[2] ? *gout.g[2] : 0.f,
+                        gp = gout.g[3] ? *gout.g[3] : 0.f, gn = gout.g[4] ? *gout.g[4] : 0.f;
             kp = g.alpha * (gl + gc) + gp;
             kn = g.beta * (gl + gc) + gn;
             kr = gl + gr;
@@ -173,7 +180,7 @@ extern "C" int vn_rpn_loss_fwd(const float *prob, const float *delta, const floa
     k_loss_norm_final<<<B, 64, 0, st>>>(slab, norm, B);
     VN_LAUNCH_STATUS();
     const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
-    k_loss<false><<<blocks, LOSS_THREADS, 0, st>>>(prob, delta, pos, neg, targets, norm, g, slab, nullptr, nullptr, nullptr);
+    k_loss<false><<<blocks, LOSS_THREADS, 0, st>>>(prob, delta, pos, neg, targets, norm, g, slab, LossGrads{}, nullptr, nullptr);
     VN_LAUNCH_STATUS();
     k_loss_finalize<<<1, LOSS_THREADS, 0, st>>>(slab, blocks, alpha, beta, out5);
     VN_LAUNCH_STATUS();
@@ -182,14 +189,16 @@ extern "C" int vn_rpn_loss_fwd(const float *prob, const float *delta, const floa
 
 extern "C" int vn_rpn_loss_bwd(const float *prob, const float *delta, const float *pos, const float *neg,
                                const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
-                               const void *workspace, const float *grad_out5, float *d_prob, float *d_delta,
+                               const void *workspace, const float *g_loss, const float *g_cls, const float *g_reg,
+                               const float *g_cls_pos, const float *g_cls_neg, float *d_prob, float *d_delta,
                                vnStream stream) {
-    VN_CHECK_ARG(prob && delta && pos && neg && targets && workspace && grad_out5 && d_prob && d_delta &&
-                 loss_args_ok(B, H, W) && sigma > 0.f);
+    VN_CHECK_ARG(prob && delta && pos && neg && targets && workspace && d_prob && d_delta && loss_args_ok(B, H, W) &&
+                 sigma > 0.f);
     const float *norm = static_cast<const float *>(workspace);   // written by vn_rpn_loss_fwd
     const int blocks = (int)vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
     const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
-    k_loss<true><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, nullptr, grad_out5,
+    k_loss<true><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, nullptr,
+                                                                  LossGrads{{g_loss, g_cls, g_reg, g_cls_pos, g_cls_neg}},
                                                                   d_prob, d_delta);
     VN_LAUNCH_STATUS();
     return VN_OK;

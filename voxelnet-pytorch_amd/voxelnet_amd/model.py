@@ -722,17 +722,18 @@ class _LossFn(torch.autograd.Function):
             _lib.call("vn_rpn_loss_fwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
                       B, H, W, alpha, beta, sigma, ws.data_ptr(), ws_bytes, out.data_ptr(), E.stream())
         ctx.saved = (prob, delta, pos, neg, tgt, ws, (B, H, W, alpha, beta, sigma))
-        return out
+        ctx.set_materialize_grads(False)          # unused outputs arrive as None in backward, not as zero tensors
+        return tuple(out[i] for i in range(5))    # five scalars (views of one buffer): loss, cls, reg, cls_pos, cls_neg
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *gs):
         prob, delta, pos, neg, tgt, ws, (B, H, W, alpha, beta, sigma) = ctx.saved
-        g = g.contiguous().float()
+        gs = [None if g is None else g.contiguous().float() for g in gs]
         with torch.cuda.device(prob.device):
             d_prob, d_delta = torch.empty_like(prob), torch.empty_like(delta)
             _lib.call("vn_rpn_loss_bwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
-                      B, H, W, alpha, beta, sigma, ws.data_ptr(), g.data_ptr(), d_prob.data_ptr(), d_delta.data_ptr(),
-                      E.stream())
+                      B, H, W, alpha, beta, sigma, ws.data_ptr(), *[None if g is None else g.data_ptr() for g in gs],
+                      d_prob.data_ptr(), d_delta.data_ptr(), E.stream())
         return d_prob, d_delta, None, None, None, None, None, None
 
 
@@ -812,6 +813,27 @@ class RPN3D(nn.Module):
                                        scores[:, np.newaxis]], axis=-1))
         return data[0], out
 
+    def _tick(self):
+        """num_batches_tracked += 1 of all 25 BatchNorms (nn.BatchNorm*.forward in train mode) as ONE launch, on the side
+        stream: nothing in the step depends on the counters, so they do not sit on the main chain."""
+        if not self.training:
+            return
+        dev = self.middle_rpn.prob_conv.conv.weight.device
+        ctrs = self.__dict__.get("_nbt")
+        if ctrs is None or ctrs[0].device != dev:
+            ctrs = [m.num_batches_tracked for m in self.modules()
+                    if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d))]
+            self.__dict__["_nbt"] = ctrs
+        side = self.__dict__.get("_side") if self.overlap_wgrad and dev.type == "cuda" else None
+        if side is None:
+            torch._foreach_add_(ctrs, 1)
+            return
+        side.wait_stream(torch.cuda.current_stream())          # (after whatever wrote the counters before, e.g. load_state_dict)
+        with torch.cuda.stream(side):
+            torch._foreach_add_(ctrs, 1)
+        if not torch.is_grad_enabled():                        # no backward will join the side stream: do it here
+            torch.cuda.current_stream().wait_stream(side)
+
     def detect(self, voxel_features, voxel_coordinates):
         """feature_net + middle_rpn (model.py:305-306), fused."""
         bs = len(voxel_features)
@@ -819,8 +841,7 @@ class RPN3D(nn.Module):
         coord = torch.cat(list(voxel_coordinates), dim=0).contiguous().long()
         flat = _vfe_weights(self.feature_net) + _collect_middle(self.middle_rpn)[3]
         prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, *flat)
-        self.feature_net._tick()
-        self.middle_rpn._tick()
+        self._tick()
         return prob, reg
 
     def loss(self, prob_out, delta_out, pos_equal_one, neg_equal_one, targets):
@@ -829,9 +850,8 @@ class RPN3D(nn.Module):
 
         def f32(a):
             return (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev).float().contiguous()
-        out = _LossFn.apply(prob_out, delta_out, f32(pos_equal_one), f32(neg_equal_one), f32(targets),
-                            float(self.alpha), float(self.beta), float(self.sigma))
-        return tuple(out.unbind(0))
+        return _LossFn.apply(prob_out, delta_out, f32(pos_equal_one), f32(neg_equal_one), f32(targets),
+                             float(self.alpha), float(self.beta), float(self.sigma))
 
     def forward(self, x, device, targets=None):
         label, voxel_features, voxel_coordinates = x[1], x[2], x[4]
