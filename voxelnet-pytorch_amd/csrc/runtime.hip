@@ -83,7 +83,6 @@ struct Plan {
     double *fsums[NL];           // forward bn_stats sums (deconvs)
     float *stats[NL];
     // backward
-    double *bsums[NL];
     float *bslab[NL]; int64_t bslab_rows[NL];
     float *coef[NL];
     Rows dy[NL], dx[NL];
@@ -244,7 +243,6 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     }
     // ---- backward buffers
     P->zb_begin = base ? base + A.off : nullptr;
-    for (int l = 0; l < NL; ++l) P->bsums[l] = (double *)A.take(2 * 256 * sizeof(double));
     P->hcs = (float *)A.take(64 * sizeof(float));
     P->hcs_ws_bytes = vn_col_sums_workspace_bytes((int64_t)B * P->hf * P->wf, 16);
     P->hcs_ws = A.take(P->hcs_ws_bytes);
@@ -410,7 +408,7 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
     hipStream_t hs = vn_stream(stream);
     const int training = cfg->training;
     const float mom = 0.1f, eps = 1e-5f;
-    if (P.zf_end > P.zf_begin) VN_HIP(hipMemsetAsync(P.zf_begin, 0, (size_t)(P.zf_end - P.zf_begin), hs));
+    // (no memset: every statistics buffer of the forward is a per-workgroup slab written with plain stores)
     if (!cfg->prepared) RT(net_prepare(cfg, P, L, heads_w, coord, K, stream));
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
     Rows x1{}, x2{};
@@ -507,7 +505,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     hipStream_t hs = vn_stream(stream);
     // backward steps: 0 = heads, 1..23 = the BatchNorm layers in backward order; [seg_begin, seg_end) runs now
     VN_CHECK_ARG(seg_begin >= 0 && seg_end <= NL + 1 && seg_begin < seg_end);
-    if (seg_begin == 0) VN_HIP(hipMemsetAsync(P.zb_begin, 0, (size_t)(P.zb_end - P.zb_begin), hs));
+    // (no memset: the backward sums are per-workgroup slabs / partial rows written with plain stores)
     const int B = cfg->B;
     const int64_t S = (int64_t)P.hf * P.wf;
     // packed fp32 weight gradients -> torch layouts: collected here, one launch at the end of the segment.
