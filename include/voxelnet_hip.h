@@ -424,6 +424,8 @@ int vn_col_sums(const void *rows, vnDtype dtype, int64_t stride, int64_t M, int3
 /* heads epilogue (model.py:281): rows (M,16) = [2 prob logits | 14 reg] ->
  * NCHW prob = sigmoid (B,2,S), reg (B,14,S); and its backward:
  * d_rows = [d_prob * p * (1-p) | d_reg] as f32, bf16 or split bf16 rows */
+/* forward side in one launch: rows16 (B*S,16) fp32 (stride 16) -> prob = sigmoid(rows[:, :2]) (B,2,S), reg (B,14,S) */
+int vn_heads_to_nchw(const float *rows16, int32_t B, int64_t S, float *prob, float *reg, vnStream stream);
 int vn_heads_bwd(const float *d_prob /*(B,2,S)*/, const float *d_reg /*(B,14,S)*/,
                  const float *prob /*(B,2,S)*/, int32_t B, int64_t S, void *d_rows, vnDtype d_dtype,
                  int64_t d_stride, int32_t split, vnStream stream);

@@ -181,6 +181,23 @@ __global__ void __launch_bounds__(256) k_rows_to_nchw(const void *__restrict__ s
     }
 }
 
+// heads epilogue in one launch (model.py:276-281): rows (B*S,16) fp32 = [2 prob logits | 14 reg] -> prob = sigmoid
+// (B,2,S) and reg (B,14,S), NCHW.  One thread per site: a 64-B row read, 16 stores that are coalesced across the wave
+// (consecutive sites of one channel).
+__global__ void __launch_bounds__(256) k_heads_to_nchw(const float *__restrict__ rows, int B, int64_t S, float *__restrict__ prob,
+                                                       float *__restrict__ reg) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)B * S) return;
+    const int64_t b = i / S, s = i - b * S;
+    const float4 *r = reinterpret_cast<const float4 *>(rows + i * 16);
+    const float4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3];
+    const float v[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+    prob[(b * 2 + 0) * S + s] = 1.0f / (1.0f + expf(-v[0]));
+    prob[(b * 2 + 1) * S + s] = 1.0f / (1.0f + expf(-v[1]));
+#pragma unroll
+    for (int c = 0; c < 14; ++c) reg[(b * 14 + c) * S + s] = v[2 + c];
+}
+
 // 4 channels per thread
 __global__ void __launch_bounds__(256) k_cast_rows(const void *__restrict__ src, int sdt, int64_t sstride, int64_t M,
                                                    int C, void *__restrict__ dst, int ddt, int64_t dstride, int64_t lo_off) {
@@ -379,6 +396,13 @@ extern "C" int vn_rows_to_nchw(const void *src, vnDtype src_dtype, int64_t src_s
     VN_CHECK_ARG(src && dst && B > 0 && C > 0 && S > 0 && B <= 65535 && src_stride >= C);
     const dim3 grid((unsigned)vn_ceil_div(S, 32), (unsigned)vn_ceil_div(C, 32), (unsigned)B);
     k_rows_to_nchw<<<grid, 256, 0, vn_stream(stream)>>>(src, (int)src_dtype, src_stride, C, S, dst, sigmoid_first_n);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_heads_to_nchw(const float *rows16, int32_t B, int64_t S, float *prob, float *reg, vnStream stream) {
+    VN_CHECK_ARG(rows16 && prob && reg && B > 0 && S > 0 && (int64_t)B * S < (1ll << 31));
+    k_heads_to_nchw<<<(unsigned)vn_ceil_div((int64_t)B * S, 256), 256, 0, vn_stream(stream)>>>(rows16, B, S, prob, reg);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -486,8 +486,7 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
         vnConv g = fwd_geom(hs16, P.cat, od, P.hy);
         RT(vn_conv_gather_gemm(P.cat.ptr, P.hwp_f, heads_b, P.hy.ptr, VN_F32, &g, 0, nullptr, stream));
         const int64_t S = (int64_t)P.hf * P.wf;
-        RT(vn_rows_to_nchw(P.hy.ptr, VN_F32, 16, cfg->B, 2, S, prob, 2, stream));
-        RT(vn_rows_to_nchw(P.hy.ptr + 2 * sizeof(float), VN_F32, 16, cfg->B, 14, S, reg, 0, stream));
+        RT(vn_heads_to_nchw(reinterpret_cast<const float *>(P.hy.ptr), cfg->B, S, prob, reg, stream));
     }
     return VN_OK;
 }
