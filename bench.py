@@ -7,11 +7,11 @@ point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2 per GPU).
 
 One step = the reference's train step (train.py:148-155) on one batch of synthetic KITTI-shaped
 frames whose raw (N,4) point clouds are already resident in HBM:
-    voxelize (HIP) -> VFE x2 + max (HIP) -> sparse->dense scatter (HIP) -> 3 Conv3d + RPN (MFMA gather-GEMM)
-    -> loss (model.py:310-352) -> backward of all of it -> [N>1: bucketed RCCL all-reduce overlapped with
-    backward] -> clip_grad_norm_(5) -> SGD(lr=0.01) step -> zero_grad.
+    voxelize (HIP) -> VFE x2 + max (HIP) -> [sparse->dense scatter folded into the rulebook first Conv3d] -> 3 Conv3d +
+    RPN (MFMA implicit GEMM) -> loss (model.py:310-352) -> backward of all of it -> [N>1: bucketed RCCL all-reduce
+    overlapped with backward] -> clip_grad_norm_(5) + SGD(lr=0.01) step (fused: vn_clip_sgd) -> zero_grad.
 Rank 0 prints ONE JSON line.  `roofline` is measured live (HIP events around every launch of the
-MFMA kernels during the timed steps); `cpu_baseline` times the oracle (PyTorch-CPU restatement of the
+MFMA kernels in eager steps right after the timed region); `cpu_baseline` times the oracle (PyTorch-CPU restatement of the
 reference's op sequence + the C voxelizer) on this box's host cores, on a bounded sample.
 """
 import argparse
