@@ -462,10 +462,11 @@ class _DetectorFn(torch.autograd.Function):
         fn, mid = rpn.feature_net, rpn.middle_rpn
         nv = 8
         vparams = [p.detach() for p in flat[:nv]]
-        names, P, Bf, _ = _collect_middle(mid)
-        P = _detached(P)
-        P["heads"] = _heads_params([f.detach() for f in flat[nv:]])
         native = rpn.native_executor and not E.is_split(mode) and fn._grid.D == 10
+        if not native:          # (the per-launch Python orchestration works on name -> tensor dicts)
+            names, P, Bf, _ = _collect_middle(mid)
+            P = _detached(P)
+            P["heads"] = _heads_params([f.detach() for f in flat[nv:]])
         if native:
             with torch.cuda.device(feature.device):
                 dev_ = feature.device
