@@ -406,8 +406,21 @@ NATIVE_SEGMENTS = [(0, 8), (8, 16), (16, 21), (21, 24)]
 
 
 def _native_layer_arrays(mid, grad_views=None):
-    """ctypes arrays of vnLayerParams (and vnLayerGrads) in execution order"""
+    """ctypes arrays of vnLayerParams (and vnLayerGrads) in execution order.  Cached on the module: building them walks
+    23 layers x 10 attributes (~0.2 ms of host time per call, twice per step); the key is the data pointer of the first
+    and last parameter / running buffer / gradient view, which change whenever the storage behind them does
+    (`.to()`, a new flat gradient buffer, a reducer's buckets)."""
     table = N.layer_table(mid._block1_stride)
+    first, last = getattr(mid, table[0][0].partition(".")[0])[0], mid.deconv3
+    key = (first.conv.weight.data_ptr(), first.batch_norm.running_mean.data_ptr(), last.deconv.weight.data_ptr(),
+           last.batch_norm.running_var.data_ptr(), mid._block1_stride)
+    if grad_views is not None:
+        key += (grad_views["middle_rpn.middle_layer.0.conv.weight"].data_ptr(),
+                grad_views["middle_rpn.deconv3.batch_norm.bias"].data_ptr())
+    cache = mid.__dict__.setdefault("_native_arrays", {})
+    hit = cache.get(grad_views is not None)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
     arr = (_lib.VnLayerParams * len(table))()
     garr = (_lib.VnLayerGrads * len(table))() if grad_views is not None else None
     for i, (name, spec) in enumerate(table):
@@ -425,6 +438,7 @@ def _native_layer_arrays(mid, grad_views=None):
             garr[i] = _lib.VnLayerGrads(grad_views[pre + cv + ".weight"].data_ptr(), grad_views[pre + cv + ".bias"].data_ptr(),
                                         grad_views[pre + "batch_norm.weight"].data_ptr(),
                                         grad_views[pre + "batch_norm.bias"].data_ptr())
+    cache[grad_views is not None] = (key, arr, garr)
     return arr, garr
 
 
@@ -683,7 +697,7 @@ def _detector_backward_native(ctx, d_prob, d_reg):
     if rpn.direct_grads:
         # hand the gradients to the parameters directly: returning the (shared) views through autograd would make
         # AccumulateGrad clone all 104 of them every step
-        plist = _vfe_weights(rpn.feature_net) + _collect_middle(mid)[3]
+        plist = rpn._flat_params()
         for p_, g_ in zip(plist, out):
             p_.grad = g_
         return (None,) * (5 + len(out))
@@ -814,6 +828,15 @@ class RPN3D(nn.Module):
                                        scores[:, np.newaxis]], axis=-1))
         return data[0], out
 
+    def _flat_params(self):
+        """the 8 VFE + 96 middle/RPN parameters in the executor's order (the Parameter objects are stable: `.to()` and
+        `load_state_dict` change their data in place), cached: the module walk costs ~0.15 ms of host time per call"""
+        fp = self.__dict__.get("_flat_param_list")
+        if fp is None:
+            fp = _vfe_weights(self.feature_net) + _collect_middle(self.middle_rpn)[3]
+            self.__dict__["_flat_param_list"] = fp
+        return fp
+
     def _tick(self):
         """num_batches_tracked += 1 of all 25 BatchNorms (nn.BatchNorm*.forward in train mode) as ONE launch, on the side
         stream: nothing in the step depends on the counters, so they do not sit on the main chain."""
@@ -840,7 +863,7 @@ class RPN3D(nn.Module):
         bs = len(voxel_features)
         feature = torch.cat(list(voxel_features), dim=0).contiguous().float()
         coord = torch.cat(list(voxel_coordinates), dim=0).contiguous().long()
-        flat = _vfe_weights(self.feature_net) + _collect_middle(self.middle_rpn)[3]
+        flat = self._flat_params()
         prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, *flat)
         self._tick()
         return prob, reg
