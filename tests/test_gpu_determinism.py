@@ -11,7 +11,10 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_train_step_is_bit_reproducible():
+@pytest.mark.parametrize("reducer", [False, True])
+def test_train_step_is_bit_reproducible(reducer):
+    """reducer: the data-parallel path (gradients written into the all-reduce buckets, per-bucket events, comm stream)
+    with world size 1"""
     from voxelnet_amd import model as M
     from voxelnet_amd import synth
     from voxelnet_amd.config import grid_config
@@ -25,6 +28,9 @@ def test_train_step_is_bit_reproducible():
         coords.append(cb)
     torch.manual_seed(5)
     model = M.RPN3D("Car").to(DEV).train(True)
+    if reducer:
+        from voxelnet_amd import parallel
+        model.grad_reducer = parallel.GradAllReducer(list(model.named_parameters()))
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     h, w = model.rpn_output_shape
     g = torch.Generator().manual_seed(3)
@@ -33,11 +39,13 @@ def test_train_step_is_bit_reproducible():
     tgt = (torch.randn((2, h, w, 14), generator=g) * 0.3).to(DEV)
     names = [n for n, _ in model.named_parameters()]
     ref = None
-    for rep in range(40):
+    for rep in range(30):
         model.load_state_dict(sd0)                         # same weights and running statistics every time
         model.zero_grad(set_to_none=True)
         out = model((None, None, feats, None, coords, None, None), DEV, targets=(pos, neg, tgt))
         out[2].backward()
+        if reducer:
+            model.grad_reducer.finish(list(model.named_parameters()))
         cur = [out[0].detach().clone(), out[1].detach().clone(), out[2].detach().clone()] + \
               [p.grad.detach().clone() for p in model.parameters()]
         torch.cuda.synchronize()
