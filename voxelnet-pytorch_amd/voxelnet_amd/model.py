@@ -442,6 +442,9 @@ def _native_layer_arrays(mid, grad_views=None):
     return arr, garr
 
 
+HEADS_W, HEADS_B = "__heads_weight_fused__", "__heads_bias_fused__"
+
+
 def _grad_views(rpn):
     """name -> gradient tensor the kernels write into: the DDP buckets' views when a reducer is attached, else
     views of one persistent flat buffer owned by the module (no per-step allocation of 104 tensors)."""
@@ -456,10 +459,20 @@ def _grad_views(rpn):
     if cache is None or cache[0] != key:
         total = sum(p.numel() for _, p in named)
         flat = torch.zeros(total, dtype=torch.float32, device=named[0][1].device)
-        views, off = {}, 0
-        for n, p in named:
-            views[n] = flat[off:off + p.numel()].view_as(p)
-            off += p.numel()
+        # the two heads' weights (and biases) are laid out back to back, so that the executor's fused (16,768) heads
+        # gradient IS the two parameters' gradients: no split copies (HEADS_W / HEADS_B name the fused views)
+        hw = ["middle_rpn.prob_conv.conv.weight", "middle_rpn.reg_conv.conv.weight"]
+        hb = ["middle_rpn.prob_conv.conv.bias", "middle_rpn.reg_conv.conv.bias"]
+        byname = dict(named)
+        order = [n for n, _ in named if n not in hw + hb] + hw + hb
+        views, off, start = {}, 0, {}
+        for n in order:
+            p_ = byname[n]
+            start[n] = off
+            views[n] = flat[off:off + p_.numel()].view_as(p_)
+            off += p_.numel()
+        views[HEADS_W] = flat[start[hw[0]]:start[hw[0]] + 16 * 768].view(16, 768, 1, 1)
+        views[HEADS_B] = flat[start[hb[0]]:start[hb[0]] + 16]
         cache = (key, flat, views)
         rpn.__dict__["_flat_grads"] = cache
     return cache[2]
@@ -626,7 +639,10 @@ def _detector_backward_segments(cfg, arr, heads, dp, dr, prob, dense, coord, vw_
 
 
 def _split_heads_grads(views, dhw, dhb):
-    """fused (16,768) heads gradient -> prob_conv / reg_conv parameter gradients (model.py:276-279)"""
+    """fused (16,768) heads gradient -> prob_conv / reg_conv parameter gradients (model.py:276-279); nothing to do when
+    the gradient views are laid out as that fused block (_grad_views)"""
+    if HEADS_W in views:
+        return
     views["middle_rpn.prob_conv.conv.weight"].copy_(dhw[:2])
     views["middle_rpn.prob_conv.conv.bias"].copy_(dhb[:2])
     views["middle_rpn.reg_conv.conv.weight"].copy_(dhw[2:])
@@ -644,8 +660,9 @@ def _detector_backward_native(ctx, d_prob, d_reg):
     accumulate = any(p.grad is not None for p in rpn.parameters())   # someone wants sums: hand out copies
     with torch.cuda.device(dev):
         arr, garr = _native_layer_arrays(mid, views)
-        dhw = torch.empty((16, 768, 1, 1), dtype=torch.float32, device=dev)
-        dhb = torch.empty(16, dtype=torch.float32, device=dev)
+        fused_heads = HEADS_W in views          # flat buffer: the fused heads gradient is written in place
+        dhw = views[HEADS_W] if fused_heads else torch.empty((16, 768, 1, 1), dtype=torch.float32, device=dev)
+        dhb = views[HEADS_B] if fused_heads else torch.empty(16, dtype=torch.float32, device=dev)
         d_vw = torch.empty((K, 128), dtype=torch.float32, device=dev)
         dp, dr = d_prob.contiguous().float(), d_reg.contiguous().float()
         d_in = d_vw if cfg.sparse_first else torch.empty_like(dense.t)
