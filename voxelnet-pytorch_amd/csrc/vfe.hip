@@ -887,7 +887,7 @@ extern "C" int vn_vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVf
 
 extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, const float *stats,
                           const float *d_voxelwise, const vnVfeGrads *g, void *workspace, size_t workspace_bytes,
-                          vnStream stream) {
+                          int32_t workspace_is_forwards, vnStream stream) {
     VN_CHECK_ARG(feature && w && stats && d_voxelwise && g && workspace && K > 0 && K < (1ll << 31) / 64 && T > 0 && T <= 64);
     VN_CHECK_ARG(g->dw1 && g->db1 && g->dg1 && g->dbe1 && g->dw2 && g->db2 && g->dg2 && g->dbe2);
     const Plan pl = make_plan(K, T);
@@ -902,7 +902,12 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
     if (const int e = set_lds_attrs()) return e;
     const int64_t rows = K * T;
     WorkList wk{};
-    if (const int e = build_worklist(feature, K, T, ws, pl, st, &wk)) return e;   // the workspace need not be the forward's
+    if (workspace_is_forwards) {   // vn_vfe_fwd's work list for the same feature / K / T is still in this workspace
+        wk = WorkList{reinterpret_cast<const uint8_t *>(ws + pl.off_rows), reinterpret_cast<const int32_t *>(ws + pl.off_list),
+                      reinterpret_cast<const int32_t *>(ws + pl.off_counts)};
+    } else if (const int e = build_worklist(feature, K, T, ws, pl, st, &wk)) {
+        return e;
+    }
     k_vfe_b1<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, d_voxelwise, slabs);
     VN_LAUNCH_STATUS();
     k_vfe_bn_bwd_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, SLAB_B1, 0, C2, rows, w->g2, stats + ST2, coef2, g->dg2, g->dbe2);

@@ -79,7 +79,7 @@ SIGNATURES = {
     "vn_voxelize_gather": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vn_vfe_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "vn_vfe_fwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
-    "vn_vfe_bwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_vp, c_vp, _P(VnVfeGrads), c_vp, c_sz, c_vp]),
+    "vn_vfe_bwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_vp, c_vp, _P(VnVfeGrads), c_vp, c_sz, c_i32, c_vp]),
     "vn_scatter_dense_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,
                                      c_i32, c_vp]),
     "vn_scatter_dense_update": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,

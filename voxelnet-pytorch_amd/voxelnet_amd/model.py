@@ -206,8 +206,9 @@ def featnet_backward(feature, wstruct, stats, d_vw, params, out=None):
     grads = out if out is not None else [torch.empty_like(p) for p in params]
     g = _lib.VnVfeGrads(*[t.data_ptr() for t in grads])
     d_vw = d_vw.contiguous()
+    # (ws is the forward's workspace, kept alive and untouched by the saved handle: its work list is reused)
     _lib.call("vn_vfe_bwd", feature.data_ptr(), K, T, ctypes.byref(w), stats.data_ptr(), d_vw.data_ptr(),
-              ctypes.byref(g), ws.data_ptr(), ws_bytes, E.stream())
+              ctypes.byref(g), ws.data_ptr(), ws_bytes, 1, E.stream())
     return grads
 
 
