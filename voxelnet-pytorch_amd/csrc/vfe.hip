@@ -778,10 +778,37 @@ __global__ void __launch_bounds__(256) k_vfe_reduce(const float *__restrict__ sl
     if (lane == 0) out[i] = (float)s;
 }
 
+// the same for up to 4 (slab, stride, offset, n, out) jobs in ONE launch: blocks [first[j], first[j+1]) serve job j
+struct ReduceJobs {
+    const float *slabs[4];
+    float *out[4];
+    int stride[4], off[4], n[4], first[5];
+};
+__global__ void __launch_bounds__(256) k_vfe_reduce_multi(const ReduceJobs J, int nslabs) {
+    int j = 0;
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if ((int)blockIdx.x >= J.first[q]) j = q;
+    const float *slabs = J.slabs[0];
+    float *out = J.out[0];
+    int stride = J.stride[0], off = J.off[0], n = J.n[0], first = J.first[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)          // (static indices: no dynamic index into the by-value parameter struct)
+        if (j == q) { slabs = J.slabs[q]; out = J.out[q]; stride = J.stride[q]; off = J.off[q]; n = J.n[q]; first = J.first[q]; }
+    const int i = ((int)blockIdx.x - first) * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int b = lane; b < nslabs; b += 64) s += slabs[(size_t)b * stride + off + i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) out[i] = (float)s;
+}
+
 struct Plan {
     int blocks;
     size_t lds_small, lds_full;
-    size_t off_slabs, off_coef, off_rows, off_list, off_counts, off_dp1, bytes;
+    size_t off_slabs, off_slabs3, off_coef, off_rows, off_list, off_counts, off_dp1, bytes;
 };
 
 Plan make_plan(int64_t K, int T) {
@@ -799,6 +826,7 @@ Plan make_plan(int64_t K, int T) {
     auto take = [&](size_t bytes) { size_t r = off; off += vn_align(bytes); return r; };
     const size_t k1 = (size_t)(K > 0 ? K : 1);
     p.off_slabs = take((size_t)VFE_BLOCKS_MAX * SLAB_B2 * sizeof(float));
+    p.off_slabs3 = take((size_t)VFE_BLOCKS_MAX * SLAB_B3 * sizeof(float));   // pass b3's own slab: b2's is reduced after it
     p.off_coef = take((size_t)(3 * C1 + 3 * C2) * sizeof(float));
     p.off_rows = take(k1);
     p.off_list = take(k1 * sizeof(int32_t));
@@ -914,18 +942,27 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
     VN_LAUNCH_STATUS();
     k_vfe_b2<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, d_voxelwise, coef2, dp1, slabs);
     VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<C2 / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, 0, C2, g->db2);
-    VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<C2 * 32 / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2, C2 * 32, g->dw2);
-    VN_LAUNCH_STATUS();
     k_vfe_bn_bwd_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2 + C2 * 32, C1, rows, w->g1, stats + ST1, coef1,
                                             g->dg1, g->dbe1);
     VN_LAUNCH_STATUS();
-    k_vfe_b3<<<pl.blocks, NT, pl.lds_small, st>>>(feature, T, P, wk, stats, coef1, dp1, slabs);
+    float *slabs3 = reinterpret_cast<float *>(ws + pl.off_slabs3);
+    k_vfe_b3<<<pl.blocks, NT, pl.lds_small, st>>>(feature, T, P, wk, stats, coef1, dp1, slabs3);
     VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<C1 * CIN / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B3, 0, C1 * CIN, g->dw1);
-    VN_LAUNCH_STATUS();
-    k_vfe_reduce<<<C1 / 4, 256, 0, st>>>(slabs, pl.blocks, SLAB_B3, C1 * CIN, C1, g->db1);
-    VN_LAUNCH_STATUS();
+    {   // the four parameter-gradient reductions (db2, dW2 from pass b2's slab; dW1, db1 from pass b3's) in one launch
+        ReduceJobs J{};
+        const float *sl[4] = {slabs, slabs, slabs3, slabs3};
+        float *out[4] = {g->db2, g->dw2, g->dw1, g->db1};
+        const int stride[4] = {SLAB_B2, SLAB_B2, SLAB_B3, SLAB_B3}, off[4] = {0, C2, 0, C1 * CIN};
+        const int n[4] = {C2, C2 * 32, C1 * CIN, C1};
+        int first = 0;
+        for (int j = 0; j < 4; ++j) {
+            J.slabs[j] = sl[j]; J.out[j] = out[j]; J.stride[j] = stride[j]; J.off[j] = off[j]; J.n[j] = n[j];
+            J.first[j] = first;
+            first += (n[j] + 3) / 4;
+        }
+        J.first[4] = first;
+        k_vfe_reduce_multi<<<first, 256, 0, st>>>(J, pl.blocks);
+        VN_LAUNCH_STATUS();
+    }
     return VN_OK;
 }
