@@ -525,6 +525,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         VN_HIP(hipStreamWaitEvent(ws, e, 0));
         return VN_OK;
     };
+    bool heads_forked = false;     // the side stream already waits for the main stream's state after the heads
     // ---- heads
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
@@ -534,12 +535,15 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
         int32_t hch = 1;
-        RT(fork());
-        RT(vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, &gw, 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
-        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
         const int64_t os[4] = {P.d_cat.sB, P.d_cat.sD, P.d_cat.sH, P.d_cat.sW};
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
+        // the heads' weight gradient goes to the side stream behind ONE fork that also serves the early deconv
+        // branches (which need the data gradient): one event record less on the main stream (483 vs 480 pc/s)
         RT(vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.pdt, &gd, 0, nullptr, stream));
+        RT(fork());
+        heads_forked = true;
+        RT(vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, &gw, 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
+        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
     }
     auto cat_slice = [&](int off) {
         Rows r = P.d_cat;
@@ -679,7 +683,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     const bool early = early_on && ws != hs && seg_begin == 0 && seg_end == NL + 1;
     hipEvent_t ev_d2 = nullptr, ev_d1 = nullptr;
     if (early) {
-        RT(fork());
+        if (!heads_forked) RT(fork());
         RT(do_layer(L_D2, wstream, true, false));
         ev_d2 = next_event();
         if (!ev_d2) return VN_EINVAL;
