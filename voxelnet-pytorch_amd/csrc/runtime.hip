@@ -609,7 +609,8 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     static const int m0_main_on = [] { const char *e = getenv("VN_M0_MAIN"); return e && *e ? atoi(e) : 1; }();
     static const int early_unpack_on = [] { const char *e = getenv("VN_EARLY_UNPACK"); return e && *e ? atoi(e) : 1; }();
     const bool tail_balance = ws != hs && cfg->defer_join && !cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
-    const bool m0_on_main = tail_balance && m0_main_on;
+    const bool bucket_mode = ws != hs && cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
+    const bool m0_on_main = (tail_balance || bucket_mode) && m0_main_on;
     int u_early = 0;
     // one layer of the backward: BatchNorm backward and data gradient on `ls`, weight gradient on the side stream
     auto do_layer = [&](int l, vnStream ls, bool on_side, bool accumulate) -> int {
@@ -701,18 +702,19 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     int u_done = 0, z_done = 0;
     auto bucket_done = [&](int b) -> int {
         RT(flush());
+        if (b == 3 && m0_on_main) RT(fork());     // the first layer's partials come from the main stream
         RT(vn_unpack_wgrads_batch(unpack + u_done, nu - u_done, wstream));
         u_done = nu;
-        VN_HIP(hipEventRecord(g_bucket_ev[b][1], ws));
-        if (zj.n > z_done) {
+        if (zj.n > z_done) {   // (bias gradients in front of a train-mode BatchNorm: zero; off the main chain)
             ZeroJobs part{};
             part.n = zj.n - z_done;
             for (int i = 0; i < part.n; ++i) { part.ptr[i] = zj.ptr[z_done + i]; part.len[i] = zj.len[z_done + i]; }
-            k_zero_many<<<part.n, 256, 0, hs>>>(part);
+            k_zero_many<<<part.n, 256, 0, ws>>>(part);
             VN_LAUNCH_STATUS();
             z_done = zj.n;
         }
-        VN_HIP(hipEventRecord(g_bucket_ev[b][0], hs));
+        VN_HIP(hipEventRecord(g_bucket_ev[b][1], ws));
+        VN_HIP(hipEventRecord(g_bucket_ev[b][0], hs));   // (the BatchNorm gradients of the group: written on the main stream)
         return VN_OK;
     };
     for (int oi = 0; oi < NL; ++oi) {
