@@ -141,11 +141,17 @@ def main():
     pending = {}
 
     slots = [[VoxelBuffers(pts.shape[0], grid, 4, dev) for pts in frames] for _ in range(3)]   # 3-deep ring
-    ring = {"i": 0}
+    ring = {"i": 0, "use": 0}
+    slot_free = [None, None, None]     # event recorded on the training stream after the last consumer of the slot
 
     def launch_voxelize():
-        bufs = slots[ring["i"] % 3]
+        si = ring["i"] % 3
+        bufs = slots[si]
         ring["i"] += 1
+        if slot_free[si] is not None:
+            # write-after-read: the train step that consumed this slot (VFE forward AND backward read its feature
+            # buffer) must have finished before the voxelizer overwrites it — the host runs several steps ahead
+            vox_stream.wait_event(slot_free[si])
         with torch.cuda.stream(vox_stream):
             pending["next"] = [voxelize_device_async(pts, grid, b, coord_cols=4, buffers=bufs[b])
                                for b, pts in enumerate(frames)]
@@ -186,6 +192,12 @@ def main():
     def step_eager():
         feats, coords = voxelize_batch()
         loss = fwd_bwd(feats, coords)
+        if not args.static_voxels:         # this step's slot may be re-used once the backward (queued above) is done
+            si = ring["use"] % 3
+            ring["use"] += 1
+            ev = slot_free[si] if slot_free[si] is not None else torch.cuda.Event()
+            ev.record()
+            slot_free[si] = ev
         reduce_grads()
         optim()
         opt.zero_grad(set_to_none=True)                                    # train.py:155

@@ -77,6 +77,18 @@ int vn_voxelize_gather(const float *points, int64_t n_points, const vnGrid *grid
                        float *feature /*[K,T,7]*/, int64_t *coord /*[K,coord_cols]*/,
                        int64_t *number /*[K]*/, const int32_t *k_dev, vnStream stream);
 
+/* Host (CPU) variant of the two phases for the reference's own call site — pcl_to_voxels inside forked DataLoader
+ * worker processes (dataset.py:58, train.py:77-84), which cannot touch the GPU.  HOST pointers, no stream, synchronous;
+ * same arithmetic, row order and output formats as the device pair above, bit for bit.  The index phase leaves its
+ * row table in `workspace`; the gather phase must be given the K it returned. */
+size_t vn_voxelize_host_workspace_bytes(int64_t n_points, const vnGrid *grid);
+int vn_voxelize_host_index(const float *points /*host [N,4]*/, int64_t n_points, const vnGrid *grid,
+                           void *workspace /*host*/, size_t workspace_bytes, int64_t *k_out);
+int vn_voxelize_host_gather(const float *points, int64_t n_points, const vnGrid *grid, const void *workspace,
+                            size_t workspace_bytes, int64_t K, int64_t batch_index, int32_t coord_cols,
+                            float *feature /*host [K,T,7]*/, int64_t *coord /*host [K,coord_cols]*/,
+                            int64_t *number /*host [K]*/);
+
 /* ------------------------------------------------------------------------
  * Voxel feature encoder — FeatureLearningNet.forward up to the scatter
  * (model.py:93-100) incl. both VFELayer.forward calls (model.py:74-82):
@@ -108,6 +120,21 @@ int vn_vfe_fwd(const float *feature /*[K,T,7]*/, int64_t K, int32_t T, const vnV
 int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, const float *stats,
                const float *d_voxelwise, const vnVfeGrads *g, void *workspace,
                size_t workspace_bytes, int32_t workspace_is_forwards, vnStream stream);
+
+/* Stand-alone VFELayer.forward(inputs, mask) (model.py:60-82) for callers that compose the layers themselves:
+ * out (K,T,2*units) = concat(p, max_t p) * mask with p = BatchNorm1d(relu(inputs W^T + b)) over the K*T rows
+ * (training: batch statistics + running-stat update with `momentum`; else the running statistics).  mask: one
+ * byte per (voxel, slot) row.  cin, units <= 64.  The backward reads the forward's workspace (same pointer, untouched
+ * in between) and returns the gradients of inputs (may be NULL), weight (units,cin), bias, gamma, beta. */
+size_t vn_vfe_layer_workspace_bytes(int64_t K, int32_t T, int32_t cin, int32_t units);
+int vn_vfe_layer_fwd(const float *inputs /*[K,T,cin]*/, const uint8_t *mask /*[K,T]*/, int64_t K, int32_t T,
+                     int32_t cin, int32_t units, const float *weight, const float *bias, const float *gamma,
+                     const float *beta, float *running_mean, float *running_var, int32_t training, float momentum,
+                     float eps, float *out /*[K,T,2*units]*/, void *workspace, size_t workspace_bytes, vnStream stream);
+int vn_vfe_layer_bwd(const float *inputs, const uint8_t *mask, const float *d_out /*[K,T,2*units]*/, int64_t K,
+                     int32_t T, int32_t cin, int32_t units, const float *weight, int32_t training, float *d_inputs,
+                     float *d_weight, float *d_bias, float *d_gamma, float *d_beta, void *workspace,
+                     size_t workspace_bytes, vnStream stream);
 
 /* ------------------------------------------------------------------------
  * Sparse -> dense scatter — model.py:102-106 (sparse COO .to_dense()).
@@ -181,6 +208,10 @@ int vn_conv_gather_gemm(const void *src, const void *w_packed /*[taps][Cr][Cs]*/
                         const float *bias /*[Cr] or NULL*/, void *out, vnDtype out_dtype,
                         const vnConv *geom, int32_t accumulate, float *stats_slab,
                         vnStream stream);
+/* Introspection for the parity tests (no launch): which kernel / tile vn_conv_gather_gemm picks for `geom`:
+ * 100 + k_conv_patch tile id (0 = 10x16, 1 = 8x32, 2 = 4x16, 3 = 6x32, 4 = 6x16, 5 = 8x16 pixels), else the
+ * k_gather_gemm tile id (0 = 256x64, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 160x128 rows x channels); < 0: bad geom. */
+int32_t vn_conv_plan_id(const vnConv *geom);
 
 /* Weight-gradient: dw[tap][n][k] += sum_m src[site(m,tap), k] * rows[m, n]
  * fp32, packed [taps][Cr][C] orientation, C = real source channels — the caller zeroes dw first.
@@ -194,6 +225,9 @@ size_t vn_conv_wgrad_workspace_bytes(const vnConv *geom, int32_t split, int64_t 
 int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16*/, float *dw_packed,
                   const vnConv *geom, int32_t split, void *workspace, size_t workspace_bytes,
                   vnStream stream);
+/* Introspection (no launch): 200 = k_wgrad_patch, else 1000 * three-tap + 10 * TN + TK of k_wgrad<TN,TK> (tile =
+ * 32 TN x 32 TK channels) for this geometry. */
+int32_t vn_conv_wgrad_plan_id(const vnConv *geom, int32_t split, int64_t n_rows);
 /* Same products, but the row-chunk partials are left in the workspace: chunk c at workspace + c * (taps*Cr*C) floats,
  * *chunks (host) = their number.  vn_unpack_wgrads_batch sums them (vnUnpackJob.chunks) while it converts the layout,
  * so a backward pass needs no per-layer reduction launch and no zeroed accumulator.  row_list != NULL: the
@@ -312,27 +346,48 @@ typedef struct {
     float *weight, *bias, *gamma, *beta;   /* overwritten */
 } vnLayerGrads;
 size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K);
+/* Executor context: the HIP events of the two-stream schedule (fork / join ring, "parameter group final" events), created
+ * on the current device.  Caller-owned (one per executor instance, e.g. one RPN3D module on one device) — the library
+ * keeps no mutable state of its own.  Calls sharing a context must not overlap on the host. */
+typedef struct vnNet vnNet;
+int vn_net_create(vnNet **out);
+int vn_net_destroy(vnNet *net);
 /* Make `stream` wait until parameter group `bucket` (0: heads+deconv3+block3, 1: deconv2+block2+deconv1, 2: block1,
  * 3: middle_layer) of the most recent vn_net_backward issued with cfg->bucket_events has its final gradients. */
-int vn_net_wait_bucket(int32_t bucket, vnStream stream);
+int vn_net_wait_bucket(vnNet *net, int32_t bucket, vnStream stream);
 /* The part of the forward that does not depend on the voxel features (weight packing; sparse first layer: active
  * sites, voxel index grid, bias fill): may be issued on another stream while the VFE forward runs; then set
  * cfg->prepared for vn_net_forward and make its stream wait for this one. */
-int vn_net_prepare(const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
+int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
                    const int64_t *coord, int64_t K, void *workspace, size_t workspace_bytes, vnStream stream);
-int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,
+int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,
                    const float *heads_w /*[16,768]*/, const float *heads_b /*[16]*/,
                    const void *dense, const int64_t *coord, const void *vw_rows /* (K,128) voxel rows in the operand dtype, sparse_first only */, int64_t K, void *workspace,
                    size_t workspace_bytes, float *prob /*(B,2,h,w)*/, float *reg /*(B,14,h,w)*/,
                    vnStream stream,
                    vnStream side_stream /* NULL, or a second stream deconv1 / deconv2 run on beside block2 / block3 */);
-int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
+/* VN_EUNSUPPORTED when cfg->training == 0: only the train-mode BatchNorm backward exists. */
+int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
                     const float *d_prob, const float *d_reg, const float *prob, const void *dense,
                     const int64_t *coord, const void *vw_rows, int64_t K, void *workspace,
                     size_t workspace_bytes, const vnLayerGrads *grads /*[23]*/, float *d_heads_w,
                     float *d_heads_b, void *d_input, int32_t seg_begin, int32_t seg_end,
                     vnStream stream, vnStream side_stream /* NULL, or a second stream the weight-gradient
                     launches run on beside the data-gradient ones; joined back before the call returns */);
+
+/* ------------------------------------------------------------------------
+ * Data-parallel gradient exchange over RCCL / xGMI (the reference has no distributed code):
+ * thin wrappers, RCCL bound at run time (dlopen; inside a PyTorch process torch's own librccl is reused).
+ * Status: VN_EUNSUPPORTED when no librccl can be found, 1000 + ncclResult_t for RCCL errors.
+ * vn_comm_create is collective (every rank, on its own current device, with rank 0's 128-byte id);
+ * `nccl_comm` is a plain ncclComm_t — a communicator made elsewhere (e.g. by an MPI launcher) works as well.
+ * vn_allreduce_bucket: bucket[i] = sum over ranks of scale * bucket[i], in place, asynchronous on `stream`
+ * (scale = 1/world: the mean stock DDP takes; scaled before the sum, so all ranks end bit-identical).
+ * ---------------------------------------------------------------------- */
+int vn_comm_unique_id(void *id128 /* out: 128 bytes (ncclUniqueId) */);
+int vn_comm_create(void **nccl_comm, const void *id128, int32_t world, int32_t rank);
+int vn_comm_destroy(void *nccl_comm);
+int vn_allreduce_bucket(void *nccl_comm, float *bucket, int64_t count, float scale, vnStream stream);
 
 /* ------------------------------------------------------------------------
  * BatchNorm(+ReLU) over channels-last rows — nn.BatchNorm{1,2,3}d defaults

@@ -12,8 +12,52 @@ for p in (ROOT, os.path.join(ROOT, "voxelnet-pytorch_amd")):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+DDP_REHEARSAL = {}     # filled by pytest_sessionstart on a GPU run: {"procs": [...], "dir": ..., "error": ...}
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _gpu_run(config):
+    expr = (config.getoption("-m") or "").replace(" ", "")
+    return "gpu" in expr and "notgpu" not in expr
+
+
+def pytest_sessionstart(session):
+    """tests/test_gpu_multiproc.py needs two FRESH processes on cuda:0.  They are started here, before this process has
+    made any GPU call (a process that has initialised HIP must not fork + exec on the GPU boxes), run beside the other
+    GPU tests and are collected by the test at the end."""
+    import subprocess
+    import tempfile
+    if not _gpu_run(session.config) or os.environ.get("VN_NO_DDP_REHEARSAL") == "1":
+        return
+    try:
+        import socket
+
+        import torch
+        if torch.cuda.device_count() < 1:          # (device_count() does not initialise the GPU)
+            return
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = str(s.getsockname()[1])
+        s.close()
+        d = tempfile.mkdtemp(prefix="vn_ddp_")
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs = []
+        for r in range(2):
+            log = open(os.path.join(d, f"rank{r}.log"), "w")
+            procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), "2", port, d],
+                                          stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT))
+        DDP_REHEARSAL.update(procs=procs, dir=d)
+    except Exception as e:  # noqa: BLE001 - reported by the test
+        DDP_REHEARSAL["error"] = repr(e)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    for p in DDP_REHEARSAL.get("procs", []):
+        if p.poll() is None:
+            p.kill()
 
 
 @pytest.fixture(scope="session")

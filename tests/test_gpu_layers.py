@@ -3,8 +3,9 @@ C ABI (gather-GEMM, wgrad, BatchNorm kernels) against the golden vectors produce
 imported reference modules and against the oracle (oracle/torch_ref.py, CPU fp32).
 
 Tolerances (relative to the tensor's maximum): "fp32" (exact fp32 MFMA products; the parity
-mode for BASELINE.json's <=1e-3 bar) 2e-4 per layer, "bf16x3" 1e-3, "bf16" 1e-1 (reduced-
-precision training mode, not a parity mode)."""
+mode for BASELINE.json's <=1e-3 bar) 2e-4 per layer, "bf16x3" 1e-3.  The "bf16" mode (the benchmarked
+one) is checked stage by stage against a bf16-operand oracle with half-ulp bars in
+tests/test_gpu_bf16_parity.py (these same fixtures + the production tile sizes)."""
 import numpy as np
 import pytest
 import torch
@@ -13,7 +14,7 @@ from layer_cases import LAYER_CASES, build_layer_state, layer_input, layer_upstr
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 2e-4, "bf16x3": 1e-3, "bf16": 1e-1}
+TOL = {"fp32": 2e-4, "bf16x3": 1e-3, "bf16": 8e-3}   # bf16: heads only (fp32 output, bf16 operands vs the fp32 reference)
 
 
 def rel_err(a, b):
@@ -54,14 +55,13 @@ def _spec(case):
                      bn=(kind != "head"), relu=(kind != "head"))
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", LAYER_CASES, ids=lambda c: c[0])
 def test_layer_fwd_bwd(golden, case, mode):
     from voxelnet_amd import engine as E
     g = golden("layers_tiny")
     name, kind, dim, cin, cout, k, s, p, sp = case
     idx = [c[0] for c in LAYER_CASES].index(name)
-    split = mode != "bf16"        # full-precision gradient checks
     tol = TOL[mode]
     spec = _spec(case)
     if kind == "head" and cout % 4:
@@ -105,31 +105,18 @@ def test_layer_fwd_bwd(golden, case, mode):
     if mode == "fp32":   # and the golden dx of the imported reference (robust to an isolated mask flip)
         assert robust_err(E.rows_to_nchw(dx, dim), g[name + ".dx"]) < tol
     ref_w = leaves[f"L.{wkey}.weight"].grad.numpy()
-    if split:
-        assert rel_err(grads["weight"], ref_w) < tol
-    else:
-        # bf16 operands: a weight gradient behind a train-mode BatchNorm is a sum with heavy cancellation
-        # (sum_m dy = 0, dW is orthogonal to W), so bf16 rounding of a and dy shows up as noise relative
-        # to the small true value at these tiny M.  Same kernels pass at 1e-3 in bf16x3 mode above.
-        gw = grads["weight"].float().cpu().numpy().ravel()
-        cos = float(np.dot(gw, ref_w.ravel()) / (np.linalg.norm(gw) * np.linalg.norm(ref_w) + 1e-30))
-        assert cos > 0.97, cos
+    assert rel_err(grads["weight"], ref_w) < tol
     ref_b = leaves[f"L.{wkey}.bias"].grad.numpy()
     if kind == "head":
         assert rel_err(grads["bias"], ref_b) < tol
     else:
         # conv bias feeding a train-mode BatchNorm: the true gradient is 0 (rounding noise in the reference)
-        if split:   # (bf16 mode: the column sums of bf16-rounded dy are rounding noise, not a signal)
-            assert float(grads["bias"].abs().max()) < 1e-2 * max(1.0, float(np.abs(up.cpu().numpy()).sum()) * 1e-3)
+        assert float(grads["bias"].abs().max()) < 1e-2 * max(1.0, float(np.abs(up.cpu().numpy()).sum()) * 1e-3)
         for key, ref_k in (("gamma", "L.batch_norm.weight"), ("beta", "L.batch_norm.bias")):
             ref_g = leaves[ref_k].grad.numpy()
-            if split:
-                assert rel_err(grads[key], ref_g) < max(tol, 1e-3)
-            else:   # bf16 y: ReLU-mask flips at z ~ 0 move whole elements of these tiny (M <= 960) sums
-                gg = grads[key].float().cpu().numpy()
-                assert float(np.dot(gg, ref_g) / (np.linalg.norm(gg) * np.linalg.norm(ref_g) + 1e-30)) > 0.97
+            assert rel_err(grads[key], ref_g) < max(tol, 1e-3)
         for k_ in ("running_mean", "running_var"):
-            assert rel_err(Bf[k_], g[f"{name}.buf.batch_norm.{k_}"]) < 1e-3 or mode == "bf16"
+            assert rel_err(Bf[k_], g[f"{name}.buf.batch_norm.{k_}"]) < 1e-3
 
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])

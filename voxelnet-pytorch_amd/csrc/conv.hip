@@ -935,6 +935,18 @@ extern "C" int64_t vn_conv_stats_slab_rows(const vnConv *g) {
     return vn_ceil_div(rows, gg_config(rows, g->Cr, 1).BM);
 }
 
+// Which kernel / tile vn_conv_gather_gemm picks for a geometry (tests assert that the production instantiations are
+// the ones compared with the oracle): 100 + patch tile id (k_conv_patch: 0 = 10x16, 1 = 8x32, 2 = 4x16, 3 = 6x32,
+// 4 = 6x16, 5 = 8x16 pixels) or the k_gather_gemm tile id (0 = 256x64, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 160x128).
+extern "C" int32_t vn_conv_plan_id(const vnConv *g) {
+    if (!g || g->divD < 1 || g->divH < 1 || g->divW < 1 || g->B <= 0) return -1;
+    const PatchCfg pc = patch_config(g);          // (depth residue classes are fine for the patch kernel)
+    if (pc.id >= 0) return 100 + pc.id;
+    const int64_t qd = vn_ceil_div(g->Dr, g->divD), qh = vn_ceil_div(g->Hr, g->divH), qw = vn_ceil_div(g->Wr, g->divW);
+    const int nd = g->divD < g->Dr ? g->divD : g->Dr, nh = g->divH < g->Hr ? g->divH : g->Hr, nw = g->divW < g->Wr ? g->divW : g->Wr;
+    return gg_config((int64_t)g->B * qd * qh * qw, g->Cr, nd * nh * nw).id;   // largest class x number of classes
+}
+
 extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const float *bias, void *out,
                                    vnDtype out_dtype, const vnConv *g, int32_t accumulate, float *stats_slab,
                                    vnStream stream) {

@@ -12,8 +12,7 @@
 // The per-layer call sequences are exactly those of voxelnet_amd/engine.py (the Python reference
 // orchestration, still used by the per-layer tests and the bf16x3 mode).
 #include "common.h"
-#include <atomic>
-#include <mutex>
+#include <new>
 #include <string.h>
 
 namespace {
@@ -297,19 +296,53 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
 
 #define RT(call) do { int rc_ = (call); if (rc_ != VN_OK) return rc_; } while (0)
 
-// "gradients of parameter group b are final" events of the most recent single-call backward with cfg->bucket_events:
-// [b][0] recorded on the main stream (BatchNorm gradients, zeroed conv biases), [b][1] on the side stream (weight
-// gradients unpacked).  One executor per process (one process per GPU).
-static hipEvent_t g_bucket_ev[4][2];
-static bool bucket_events_ready() {
-    static const bool ok = [] {
-        for (int b = 0; b < 4; ++b)
-            for (int w = 0; w < 2; ++w)
-                if (hipEventCreateWithFlags(&g_bucket_ev[b][w], hipEventDisableTiming) != hipSuccess) return false;
-        return true;
-    }();
-    return ok;
+}  // namespace
+
+// Executor context (vn_net_create / vn_net_destroy): the HIP events the two-stream schedule needs.  Caller-owned, one
+// per executor instance (an RPN3D module on one device); the library itself keeps no mutable state.
+//   bucket_ev[b][0/1]: "gradients of parameter group b are final" of the most recent single-call backward with
+//     cfg->bucket_events — [0] recorded on the main stream (BatchNorm gradients, zeroed conv biases), [1] on the side
+//     stream (weight gradients unpacked); vn_net_wait_bucket makes a communication stream wait for both.
+//   ring: timing-less events for the fork / join of the side stream (re-recording an event that an earlier
+//     hipStreamWaitEvent has consumed is well defined: the wait captured the record that preceded it).
+// Calls that share a context must not run concurrently on the host (they never do: one step = one thread).
+struct vnNet {
+    hipEvent_t bucket_ev[4][2];
+    hipEvent_t ring[64];
+    unsigned next;
+    hipEvent_t next_event() { return ring[next++ & 63]; }
+};
+
+extern "C" int vn_net_create(vnNet **out) {
+    VN_CHECK_ARG(out);
+    *out = nullptr;
+    vnNet *n = new (std::nothrow) vnNet();
+    if (!n) return VN_EINVAL;
+    memset(n, 0, sizeof(*n));
+    hipError_t err = hipSuccess;
+    for (int b = 0; b < 4 && err == hipSuccess; ++b)
+        for (int w = 0; w < 2 && err == hipSuccess; ++w) err = hipEventCreateWithFlags(&n->bucket_ev[b][w], hipEventDisableTiming);
+    for (int i = 0; i < 64 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&n->ring[i], hipEventDisableTiming);
+    if (err != hipSuccess) {
+        vn_net_destroy(n);
+        return (int)err;
+    }
+    *out = n;
+    return VN_OK;
 }
+
+extern "C" int vn_net_destroy(vnNet *n) {
+    if (!n) return VN_OK;
+    for (int b = 0; b < 4; ++b)
+        for (int w = 0; w < 2; ++w)
+            if (n->bucket_ev[b][w]) (void)hipEventDestroy(n->bucket_ev[b][w]);
+    for (int i = 0; i < 64; ++i)
+        if (n->ring[i]) (void)hipEventDestroy(n->ring[i]);
+    delete n;
+    return VN_OK;
+}
+
+namespace {
 
 // zero up to NL small fp32 vectors in one launch (the conv-bias gradients: exactly 0 before a train-mode BatchNorm)
 struct ZeroJobs {
@@ -320,24 +353,6 @@ struct ZeroJobs {
 __global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
     float *p = z.ptr[blockIdx.x];
     for (int i = threadIdx.x; i < z.len[blockIdx.x]; i += 256) p[i] = 0.f;
-}
-
-// a small ring of timing-less events for the fork/join of the side stream (re-recording an event that an earlier
-// hipStreamWaitEvent has consumed is well defined: the wait captured the record that preceded it)
-hipEvent_t next_event() {
-    static hipEvent_t ring[64];
-    static std::atomic<unsigned> made{0}, next{0};
-    static std::mutex mu;
-    if (made.load() < 64) {
-        std::lock_guard<std::mutex> g(mu);
-        while (made.load() < 64) {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-            ring[made.load()] = e;
-            made.fetch_add(1);
-        }
-    }
-    return ring[next.fetch_add(1) % 64];
 }
 
 int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, vnStream st) {
@@ -388,19 +403,20 @@ static int net_prepare(const vnNetConfig *cfg, const Plan &P, const vnLayerParam
     return VN_OK;
 }
 
-extern "C" int vn_net_prepare(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const int64_t *coord,
-                              int64_t K, void *workspace, size_t workspace_bytes, vnStream stream) {
-    VN_CHECK_ARG(cfg && L && heads_w && workspace && K >= 0 && (!cfg->sparse_first || coord));
+extern "C" int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w,
+                              const int64_t *coord, int64_t K, void *workspace, size_t workspace_bytes, vnStream stream) {
+    VN_CHECK_ARG(net && cfg && L && heads_w && workspace && K >= 0 && (!cfg->sparse_first || coord));
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
     if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
     return net_prepare(cfg, P, L, heads_w, coord, K, stream);
 }
 
-extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const float *heads_b,
-                              const void *dense, const int64_t *coord, const void *vw_rows, int64_t K, void *workspace,
-                              size_t workspace_bytes, float *prob, float *reg, vnStream stream, vnStream side_stream) {
-    VN_CHECK_ARG(cfg && L && heads_w && heads_b && workspace && prob && reg && K >= 0);
+extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w,
+                              const float *heads_b, const void *dense, const int64_t *coord, const void *vw_rows, int64_t K,
+                              void *workspace, size_t workspace_bytes, float *prob, float *reg, vnStream stream,
+                              vnStream side_stream) {
+    VN_CHECK_ARG(net && cfg && L && heads_w && heads_b && workspace && prob && reg && K >= 0);
     VN_CHECK_ARG(cfg->sparse_first ? (coord && vw_rows) : dense != nullptr);
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
@@ -420,7 +436,7 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
         const Spec &sp = P.spec[l];
         const bool on_side = ss != hs && (l == L_D1 || l == L_D2);
         if (on_side) {   // fork: the block output this deconv reads exists at this point of the main stream
-            hipEvent_t e = next_event();
+            hipEvent_t e = net->next_event();
             if (!e) return VN_EINVAL;
             VN_HIP(hipEventRecord(e, hs));
             VN_HIP(hipStreamWaitEvent(ss, e, 0));
@@ -474,7 +490,7 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
         if (l == L_D2 - 1) x2 = a;
     }
     if (ss != hs) {   // join before the heads read the concat
-        hipEvent_t e = next_event();
+        hipEvent_t e = net->next_event();
         if (!e) return VN_EINVAL;
         VN_HIP(hipEventRecord(e, ss));
         VN_HIP(hipStreamWaitEvent(hs, e, 0));
@@ -491,12 +507,13 @@ extern "C" int vn_net_forward(const vnNetConfig *cfg, const vnLayerParams *L, co
     return VN_OK;
 }
 
-extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w, const float *d_prob,
-                               const float *d_reg, const float *prob, const void *dense, const int64_t *coord,
+extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w,
+                               const float *d_prob, const float *d_reg, const float *prob, const void *dense, const int64_t *coord,
                                const void *vw_rows, int64_t K, void *workspace, size_t workspace_bytes,
                                const vnLayerGrads *G, float *d_heads_w, float *d_heads_b, void *d_input,
                                int32_t seg_begin, int32_t seg_end, vnStream stream, vnStream side_stream) {
-    VN_CHECK_ARG(cfg && L && heads_w && d_prob && d_reg && prob && workspace && G && d_heads_w && d_heads_b);
+    VN_CHECK_ARG(net && cfg && L && heads_w && d_prob && d_reg && prob && workspace && G && d_heads_w && d_heads_b);
+    if (!cfg->training) return VN_EUNSUPPORTED;   // train-mode BatchNorm backward only; the forward made no dgrad packs
     VN_CHECK_ARG(cfg->sparse_first ? (coord && vw_rows && d_input) : dense != nullptr);
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
@@ -519,7 +536,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     const vnStream wstream = side_stream ? side_stream : stream;
     auto fork = [&]() -> int {
         if (ws == hs) return VN_OK;
-        hipEvent_t e = next_event();
+        hipEvent_t e = net->next_event();
         if (!e) return VN_EINVAL;
         VN_HIP(hipEventRecord(e, hs));
         VN_HIP(hipStreamWaitEvent(ws, e, 0));
@@ -686,11 +703,11 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     if (early) {
         if (!heads_forked) RT(fork());
         RT(do_layer(L_D2, wstream, true, false));
-        ev_d2 = next_event();
+        ev_d2 = net->next_event();
         if (!ev_d2) return VN_EINVAL;
         VN_HIP(hipEventRecord(ev_d2, ws));
         RT(do_layer(L_D1, wstream, true, false));
-        ev_d1 = next_event();
+        ev_d1 = net->next_event();
         if (!ev_d1) return VN_EINVAL;
         VN_HIP(hipEventRecord(ev_d1, ws));
     }
@@ -698,7 +715,6 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     // block3 | deconv2+block2+deconv1 | block1 | middle_layer) the group's weight gradients are unpacked on the SIDE
     // stream and two events mark "final" — the main stream never waits for the side stream (vn_net_wait_bucket).
     const bool bucket_ev = cfg->bucket_events && ws != hs && seg_begin == 0 && seg_end == NL + 1;
-    if (bucket_ev && !bucket_events_ready()) return VN_EINVAL;
     int u_done = 0, z_done = 0;
     auto bucket_done = [&](int b) -> int {
         RT(flush());
@@ -713,8 +729,8 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
             VN_LAUNCH_STATUS();
             z_done = zj.n;
         }
-        VN_HIP(hipEventRecord(g_bucket_ev[b][1], ws));
-        VN_HIP(hipEventRecord(g_bucket_ev[b][0], hs));   // (the BatchNorm gradients of the group: written on the main stream)
+        VN_HIP(hipEventRecord(net->bucket_ev[b][1], ws));
+        VN_HIP(hipEventRecord(net->bucket_ev[b][0], hs));   // (the BatchNorm gradients of the group: written on the main stream)
         return VN_OK;
     };
     for (int oi = 0; oi < NL; ++oi) {
@@ -756,7 +772,7 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
         return VN_OK;
     }
     if (ws != hs) {   // join: the segment's weight-gradient partials are complete before they are summed / unpacked
-        hipEvent_t e = next_event();
+        hipEvent_t e = net->next_event();
         if (!e) return VN_EINVAL;
         VN_HIP(hipEventRecord(e, ws));
         VN_HIP(hipStreamWaitEvent(hs, e, 0));
@@ -769,10 +785,9 @@ extern "C" int vn_net_backward(const vnNetConfig *cfg, const vnLayerParams *L, c
     return VN_OK;
 }
 
-extern "C" int vn_net_wait_bucket(int32_t bucket, vnStream stream) {
-    VN_CHECK_ARG(bucket >= 0 && bucket < 4);
-    if (!bucket_events_ready()) return VN_EINVAL;
-    VN_HIP(hipStreamWaitEvent(vn_stream(stream), g_bucket_ev[bucket][0], 0));
-    VN_HIP(hipStreamWaitEvent(vn_stream(stream), g_bucket_ev[bucket][1], 0));
+extern "C" int vn_net_wait_bucket(vnNet *net, int32_t bucket, vnStream stream) {
+    VN_CHECK_ARG(net && bucket >= 0 && bucket < 4);
+    VN_HIP(hipStreamWaitEvent(vn_stream(stream), net->bucket_ev[bucket][0], 0));
+    VN_HIP(hipStreamWaitEvent(vn_stream(stream), net->bucket_ev[bucket][1], 0));
     return VN_OK;
 }

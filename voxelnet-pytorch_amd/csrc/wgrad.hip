@@ -633,6 +633,17 @@ extern "C" size_t vn_conv_wgrad_workspace_bytes(const vnConv *g, int32_t split, 
     return (size_t)chunks * (size_t)w.dw_elems * sizeof(float);   // (>= one chunk: vn_conv_wgrad_partials always uses it)
 }
 
+// Which kernel vn_conv_wgrad / vn_conv_wgrad_partials pick for a geometry: 200 = k_wgrad_patch; else
+// 1000 * (three-tap mode) + 10 * TN + TK of k_wgrad<TN, TK, ., .> (tile = 32 TN x 32 TK channels).
+extern "C" int32_t vn_conv_wgrad_plan_id(const vnConv *g, int32_t split, int64_t n_rows) {
+    if (!g || g->B <= 0 || g->Dr <= 0 || g->Hr <= 0 || g->Wr <= 0 || g->Cs <= 0 || g->Cr <= 0) return -1;
+    const int64_t M = n_rows > 0 ? n_rows : (int64_t)g->B * g->Dr * g->Hr * g->Wr;
+    if (wgrad_patch_plan(g, split, n_rows > 0).ok) return 200;
+    const WGPlan w = wgrad_plan(g, split, M);
+    if (w.tri) return 1000 + 10 * 2 + (w.k128 ? 4 : 2);
+    return 10 * (w.n128 ? 4 : 2) + (w.k128 ? 4 : 2);
+}
+
 extern "C" int vn_conv_wgrad(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
                              void *workspace, size_t workspace_bytes, vnStream stream) {
     return wgrad_impl(src, rows, dw_packed, g, split, nullptr, 0, workspace, workspace_bytes, stream);

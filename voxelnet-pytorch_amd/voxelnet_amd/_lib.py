@@ -77,6 +77,18 @@ SIGNATURES = {
     "vn_voxelize_workspace_bytes": (c_sz, [c_i64, _P(VnGrid)]),
     "vn_voxelize_index": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_vp, c_vp]),
     "vn_voxelize_gather": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vn_voxelize_host_workspace_bytes": (c_sz, [c_i64, _P(VnGrid)]),
+    "vn_voxelize_host_index": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, _P(c_i64)]),
+    "vn_voxelize_host_gather": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp]),
+    "vn_vfe_layer_workspace_bytes": (c_sz, [c_i64, c_i32, c_i32, c_i32]),
+    "vn_vfe_layer_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_f32, c_f32,
+                                 c_vp, c_vp, c_sz, c_vp]),
+    "vn_vfe_layer_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
+                                 c_sz, c_vp]),
+    "vn_comm_unique_id": (c_i32, [c_vp]),
+    "vn_comm_create": (c_i32, [_P(c_vp), c_vp, c_i32, c_i32]),
+    "vn_comm_destroy": (c_i32, [c_vp]),
+    "vn_allreduce_bucket": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "vn_vfe_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "vn_vfe_fwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "vn_vfe_bwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_vp, c_vp, _P(VnVfeGrads), c_vp, c_sz, c_i32, c_vp]),
@@ -87,16 +99,20 @@ SIGNATURES = {
     "vn_scatter_dense_bwd": (c_i32, [c_vp, c_i32, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vn_conv_gather_gemm": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_i32, c_vp, c_vp]),
     "vn_net_workspace_bytes": (c_sz, [_P(VnNetConfig), c_i64]),
-    "vn_net_forward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
+    "vn_net_create": (c_i32, [_P(c_vp)]),
+    "vn_net_destroy": (c_i32, [c_vp]),
+    "vn_net_forward": (c_i32, [c_vp, _P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
                                c_vp, c_vp, c_vp]),
-    "vn_net_wait_bucket": (c_i32, [c_i32, c_vp]),
-    "vn_net_prepare": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "vn_net_wait_bucket": (c_i32, [c_vp, c_i32, c_vp]),
+    "vn_net_prepare": (c_i32, [c_vp, _P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_i64, c_vp, c_sz, c_vp]),
     "vn_voxel_index_grid": (c_i32, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "vn_rulebook_slab_rows": (c_i64, [c_i64]),
     "vn_rulebook_combine": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_vp, _P(VnConv), c_vp, c_vp, c_i32, c_vp, c_vp]),
-    "vn_net_backward": (c_i32, [_P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+    "vn_net_backward": (c_i32, [c_vp, _P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                                 c_vp, c_sz, _P(VnLayerGrads), c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "vn_conv_stats_slab_rows": (c_i64, [_P(VnConv)]),
+    "vn_conv_plan_id": (c_i32, [_P(VnConv)]),
+    "vn_conv_wgrad_plan_id": (c_i32, [_P(VnConv), c_i32, c_i64]),
     "vn_bn_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
     "vn_conv_wgrad_workspace_bytes": (c_sz, [_P(VnConv), c_i32, c_i64]),
     "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_sz, c_vp]),

@@ -246,7 +246,7 @@ def layer_forward(spec, x, params, buffers, training, mode, out=None, y_dtype=No
     if y_dtype is None:
         y_dtype = plain_dtype_of(mode)
     y = Rows(torch.empty((B,) + odims + (spec.cout,), dtype=y_dtype, device=dev), spec.cout)
-    fuse_stats = spec.bn and training and not spec.transposed
+    fuse_stats = spec.bn and training       # (residue-class launches of a ConvTranspose2d included, as in csrc/runtime.hip)
     slab = None
     if spec.transposed:
         mul, tmul, pad, div = (1, 1, 1), (-1, -1, -1), tuple(-p for p in spec.pad), spec.stride

@@ -51,6 +51,15 @@ def _need_cuda(*ts):
             raise _lib.VoxelnetHipError("voxelnet_amd modules need CUDA(HIP) tensors; there is no CPU path")
 
 
+def _need_training(training):
+    """The backward kernels implement the TRAIN-mode BatchNorm backward (batch statistics, zero gradient for the conv
+    bias in front of it); the data-gradient weight packs are only made by a train-mode forward.  A backward through an
+    eval-mode forward (frozen-BN fine-tuning, saliency maps) is not built: fail loudly instead of returning numbers."""
+    if not training:
+        raise _lib.VoxelnetHipError("backward through an eval-mode forward is not supported on the HIP path "
+                                    "(train-mode BatchNorm backward only); call model.train() before the forward")
+
+
 def _act_to_nchw(a, dim):
     out = E.rows_to_nchw(Rows(a.t[..., :a.C], a.C), dim)
     if a.lo_off:
@@ -78,11 +87,13 @@ class _LayerFn(torch.autograd.Function):
             out = _act_to_nchw(a, spec.dim) if spec.bn else E.rows_to_nchw(a, spec.dim)
         ctx.st, ctx.P, ctx.mode, ctx.spec = st, P, mode, spec
         ctx.need_dx = x.requires_grad
+        ctx.training = bool(training) or not spec.bn
         return out
 
     @staticmethod
     def backward(ctx, dout):
         spec, mode = ctx.spec, ctx.mode
+        _need_training(ctx.training)
         with torch.cuda.device(dout.device):
             if spec.bn:
                 da = E.nchw_to_plain_rows(dout, E.plain_dtype_of(mode))
@@ -157,9 +168,52 @@ class DeConv2d(nn.Module):
 # ---------------------------------------------------------------------------------------------
 # feature net (VFE x2 + voxel-wise max + sparse->dense)
 # ---------------------------------------------------------------------------------------------
+class _VFELayerFn(torch.autograd.Function):
+    """VFELayer.forward (model.py:74-82) as one layer through vn_vfe_layer_fwd / vn_vfe_layer_bwd (csrc/vfe_layer.hip)."""
+
+    @staticmethod
+    def forward(ctx, inputs, mask, weight, bias, gamma, beta, bn_mod, training):
+        _need_cuda(inputs, mask, weight)
+        if inputs.dim() != 3 or mask.shape[:2] != inputs.shape[:2]:
+            raise ValueError(f"VFELayer: inputs {tuple(inputs.shape)} / mask {tuple(mask.shape)} do not belong together")
+        K, T, cin = inputs.shape
+        units = weight.shape[0]
+        x = inputs.detach().contiguous().float()
+        mk = mask.detach().reshape(K, T).ne(0).to(torch.uint8).contiguous()
+        w = weight.detach().contiguous()
+        with torch.cuda.device(x.device):
+            ws_bytes = _lib.load().vn_vfe_layer_workspace_bytes(K, T, cin, units)
+            if ws_bytes == 0:
+                raise _lib.VoxelnetHipError(f"VFELayer({cin}, {2 * units}): cin and cout/2 must be <= 64 on the HIP path")
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device)
+            out = torch.empty((K, T, 2 * units), dtype=torch.float32, device=x.device)
+            _lib.call("vn_vfe_layer_fwd", x.data_ptr(), mk.data_ptr(), K, T, cin, units, w.data_ptr(), bias.data_ptr(),
+                      gamma.data_ptr(), beta.data_ptr(), bn_mod.running_mean.data_ptr(), bn_mod.running_var.data_ptr(),
+                      int(training), E.BN_MOMENTUM, E.BN_EPS, out.data_ptr(), ws.data_ptr(), ws_bytes, E.stream())
+        ctx.saved = (x, mk, w, ws, ws_bytes, int(training))
+        ctx.need_dx = inputs.requires_grad
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, mk, w, ws, ws_bytes, training = ctx.saved
+        K, T, cin = x.shape
+        units = w.shape[0]
+        d_out = d_out.contiguous().float()
+        with torch.cuda.device(x.device):
+            dx = torch.empty_like(x) if ctx.need_dx else None
+            dw = torch.empty_like(w)
+            db, dg, dbe = (torch.empty(units, dtype=torch.float32, device=x.device) for _ in range(3))
+            _lib.call("vn_vfe_layer_bwd", x.data_ptr(), mk.data_ptr(), d_out.data_ptr(), K, T, cin, units, w.data_ptr(), training,
+                      dx.data_ptr() if dx is not None else None, dw.data_ptr(), db.data_ptr(), dg.data_ptr(), dbe.data_ptr(),
+                      ws.data_ptr(), ws_bytes, E.stream())
+        return dx, None, dw, db, dg, dbe, None, None
+
+
 class VFELayer(nn.Module):
-    """model.py:60-82.  Holds fcn (Linear+ReLU) and bn exactly like the reference; the
-    arithmetic of both VFE layers runs fused inside FeatureLearningNet (csrc/vfe.hip)."""
+    """model.py:60-82.  Holds fcn (Linear+ReLU) and bn exactly like the reference.  Inside FeatureLearningNet both
+    layers and the voxel max run fused (csrc/vfe.hip); called on its own — forward(inputs (K,T,cin), mask (K,T,1)) ->
+    (K,T,cout) — the layer runs through its stand-alone kernels (csrc/vfe_layer.hip), forward and backward."""
 
     def __init__(self, cin, cout):
         super().__init__()
@@ -168,8 +222,11 @@ class VFELayer(nn.Module):
         self.bn = nn.BatchNorm1d(cout // 2)
 
     def forward(self, inputs, mask):
-        raise _lib.VoxelnetHipError(
-            "VFELayer runs fused inside FeatureLearningNet.forward on the HIP path (no standalone kernel)")
+        out = _VFELayerFn.apply(inputs, mask, self.fcn[0].weight, self.fcn[0].bias, self.bn.weight, self.bn.bias, self.bn,
+                                self.training)
+        if self.training:
+            self.bn.num_batches_tracked += 1
+        return out
 
 
 VFE_KEYS = ["feature_net.vfe_1.fcn.0.weight", "feature_net.vfe_1.fcn.0.bias", "feature_net.vfe_1.bn.weight",
@@ -248,10 +305,12 @@ class _FeatureNetFn(torch.autograd.Function):
             _lib.call("vn_scatter_dense_fwd", vw.data_ptr(), coord.data_ptr(), vw.shape[0], 128, B, D, H, W,
                       dense.data_ptr(), _lib.VN_F32, 128, 0, E.stream())
         ctx.saved = (feature, coord, stats, wst, params)
+        ctx.training = bool(training)
         return dense
 
     @staticmethod
     def backward(ctx, d_dense):
+        _need_training(ctx.training)
         feature, coord, stats, wst, params = ctx.saved
         with torch.cuda.device(d_dense.device):
             d_vw = gather_rows(Rows(d_dense.contiguous(), 128), coord, feature.shape[0], 128)
@@ -347,10 +406,12 @@ class _MiddleFn(torch.autograd.Function):
             prob, reg, st = N.middle_forward(dense, P, Bf, mod._block1_stride, training, mode)
         ctx.st, ctx.P, ctx.names = st, P, names
         ctx.need_dx = x.requires_grad
+        ctx.training = bool(training)
         return prob, reg
 
     @staticmethod
     def backward(ctx, d_prob, d_reg):
+        _need_training(ctx.training)
         with torch.cuda.device(d_prob.device):
             G, d_dense = N.middle_backward(ctx.st, d_prob.float(), d_reg.float(), ctx.P, need_dx=ctx.need_dx)
             dx = None
@@ -385,6 +446,12 @@ class MiddleConvNet(nn.Module):
         # config.py FEATURE_HEIGHT/WIDTH: car 200x176; ped/cyc 100x120 (although the network emits 200x240,
         # SURVEY.md §8a a8 — kept as the reference has it)
         self.output_shape = [g.H // 2, g.W // 2]
+
+    def __getstate__(self):               # (see RPN3D.__getstate__: runtime caches do not travel with a pickle / deepcopy)
+        d = self.__dict__.copy()
+        d.pop("_native_arrays", None)
+        d.pop("_nbt", None)
+        return d
 
     def _tick(self):
         if self.training:
@@ -446,17 +513,18 @@ def _native_layer_arrays(mid, grad_views=None):
 HEADS_W, HEADS_B = "__heads_weight_fused__", "__heads_bias_fused__"
 
 
-def _grad_views(rpn):
+def _grad_views(rpn, fresh=False):
     """name -> gradient tensor the kernels write into: the DDP buckets' views when a reducer is attached, else
-    views of one persistent flat buffer owned by the module (no per-step allocation of 104 tensors)."""
-    if rpn.grad_reducer is not None:
+    views of one persistent flat buffer owned by the module (no per-step allocation of 104 tensors).
+    fresh=True: a new, uncached buffer (gradient accumulation: the persistent one may BE the parameters' .grad)."""
+    if rpn.grad_reducer is not None and not fresh:
         out = {}
         for b in rpn.grad_reducer.buckets:
             out.update(b["views"])
         return out
     named = list(rpn.named_parameters())
     key = tuple((n, p.data_ptr()) for n, p in named[:2]) + (named[0][1].device,)
-    cache = rpn.__dict__.get("_flat_grads")
+    cache = None if fresh else rpn.__dict__.get("_flat_grads")
     if cache is None or cache[0] != key:
         total = sum(p.numel() for _, p in named)
         flat = torch.zeros(total, dtype=torch.float32, device=named[0][1].device)
@@ -475,7 +543,8 @@ def _grad_views(rpn):
         views[HEADS_W] = flat[start[hw[0]]:start[hw[0]] + 16 * 768].view(16, 768, 1, 1)
         views[HEADS_B] = flat[start[hb[0]]:start[hb[0]] + 16]
         cache = (key, flat, views)
-        rpn.__dict__["_flat_grads"] = cache
+        if not fresh:
+            rpn.__dict__["_flat_grads"] = cache
     return cache[2]
 
 
@@ -515,7 +584,7 @@ class _DetectorFn(torch.autograd.Function):
                     # grid / bias fill) runs on the side stream beside the VFE forward
                     side_t = rpn.__dict__["_side"]
                     side_t.wait_stream(torch.cuda.current_stream())
-                    _lib.call("vn_net_prepare", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), coord.data_ptr(), K,
+                    _lib.call("vn_net_prepare", rpn._net_handle(dev_), ctypes.byref(cfg), arr, heads["weight"].data_ptr(), coord.data_ptr(), K,
                               ws.data_ptr(), ws_bytes, side)
                     cfg.prepared = 1
                 vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
@@ -533,7 +602,7 @@ class _DetectorFn(torch.autograd.Function):
                 hf, wf = H // mid._block1_stride, W // mid._block1_stride
                 prob = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=vw.device)
                 reg = torch.empty((B, 14, hf, wf), dtype=torch.float32, device=vw.device)
-                _lib.call("vn_net_forward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), heads["bias"].data_ptr(),
+                _lib.call("vn_net_forward", rpn._net_handle(dev_), ctypes.byref(cfg), arr, heads["weight"].data_ptr(), heads["bias"].data_ptr(),
                           dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K, ws.data_ptr(),
                           ws_bytes, prob.data_ptr(), reg.data_ptr(), E.stream(), side)
             ctx.saved = (feature, coord, stats, wst, vparams, (cfg, ws, ws_bytes, dense, vw_rows, heads, prob.detach()), None, None)
@@ -541,6 +610,7 @@ class _DetectorFn(torch.autograd.Function):
             ctx.reducer = rpn.grad_reducer
             ctx.rpn = rpn
             ctx.native = True
+            ctx.training = bool(training)
             if not any(ctx.needs_input_grad):      # forward-only call: nothing will read the arena again
                 rpn._ws_release(ws)
             return prob, reg
@@ -560,10 +630,12 @@ class _DetectorFn(torch.autograd.Function):
             prob, reg, st = N.middle_forward(dense, P, Bf, mid._block1_stride, training, mode, sparse=sparse)
         ctx.saved = (feature, coord, stats, wst, vparams, st, P, names)
         ctx.reducer = rpn.grad_reducer
+        ctx.training = bool(training)
         return prob, reg
 
     @staticmethod
     def backward(ctx, d_prob, d_reg):
+        _need_training(ctx.training)
         feature, coord, stats, wst, vparams, st, P, names = ctx.saved
         red = ctx.reducer
         if ctx.native:
@@ -606,7 +678,7 @@ def _detector_backward_segments(cfg, arr, heads, dp, dr, prob, dense, coord, vw_
         # the executor leaves the join to us (cfg.defer_join), we wait for the side stream after featnet_backward
         cfg.defer_join = int(side is not None and red is None)
         for sb, se in segments:
-            _lib.call("vn_net_backward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
+            _lib.call("vn_net_backward", rpn._net_handle(dp.device), ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
                       prob.data_ptr(), dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K,
                       ws.data_ptr(), ws_bytes, garr,
                       dhw.data_ptr(), dhb.data_ptr(), d_in.data_ptr(), sb, se, E.stream(), side)
@@ -657,8 +729,14 @@ def _detector_backward_native(ctx, d_prob, d_reg):
     mid = rpn.middle_rpn
     K = feature.shape[0]
     dev = d_prob.device
-    views = _grad_views(rpn)
-    accumulate = any(p.grad is not None for p in rpn.parameters())   # someone wants sums: hand out copies
+    # Some parameter already has a .grad (a second backward() before zero_grad, or zero_grad(set_to_none=False)): the
+    # caller wants SUMS.  The persistent flat buffer may BE those .grad tensors (direct_grads), so the kernels must not
+    # overwrite it: this step's gradients go to a fresh buffer and are handed to autograd, whose AccumulateGrad adds.
+    accumulate = any(p.grad is not None for p in rpn.parameters())
+    if accumulate and red is not None:
+        raise _lib.VoxelnetHipError("gradient accumulation over several backward() calls is not supported with a "
+                                    "grad_reducer attached: call zero_grad(set_to_none=True) after every step")
+    views = _grad_views(rpn, fresh=accumulate)
     with torch.cuda.device(dev):
         arr, garr = _native_layer_arrays(mid, views)
         fused_heads = HEADS_W in views          # flat buffer: the fused heads gradient is written in place
@@ -675,12 +753,12 @@ def _detector_backward_native(ctx, d_prob, d_reg):
             # weight gradients on the side stream and records "group final" events; the comm stream waits for them
             # (vn_net_wait_bucket) — the compute streams never stall for the reducer.
             cfg.bucket_events, cfg.defer_join = 1, 1
-            _lib.call("vn_net_backward", ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
+            _lib.call("vn_net_backward", rpn._net_handle(dev), ctypes.byref(cfg), arr, heads["weight"].data_ptr(), dp.data_ptr(), dr.data_ptr(),
                       prob.data_ptr(), dense.ptr() if dense is not None else None, coord.data_ptr(), vw_rows.data_ptr(), K,
                       ws.data_ptr(), ws_bytes, garr, dhw.data_ptr(), dhb.data_ptr(), d_in.data_ptr(), 0, 24, E.stream(), side)
 
             def waiter(bi):
-                return lambda st: _lib.call("vn_net_wait_bucket", bi, ctypes.c_void_p(st.cuda_stream))
+                return lambda st: _lib.call("vn_net_wait_bucket", rpn._net_handle(dev), bi, ctypes.c_void_p(st.cuda_stream))
             dhw.record_stream(red.comm_stream)       # read there (prelude) after this function has returned
             dhb.record_stream(red.comm_stream)
             red.launch_bucket(0, wait_fn=waiter(0), prelude=lambda: _split_heads_grads(views, dhw, dhb))
@@ -711,7 +789,7 @@ def _detector_backward_native(ctx, d_prob, d_reg):
     ctx.saved = None          # drop the dense grid etc. now, not when the graph node is collected
     out = list(vg) + mg
     if accumulate:
-        return (None, None, None, None, None) + tuple(g.clone() for g in out)
+        return (None, None, None, None, None) + tuple(out)        # (views of a buffer nobody else holds)
     if rpn.direct_grads:
         # hand the gradients to the parameters directly: returning the (shared) views through autograd would make
         # AccumulateGrad clone all 104 of them every step
@@ -723,16 +801,6 @@ def _detector_backward_native(ctx, d_prob, d_reg):
 
 
 _DetectorFn._backward_native = staticmethod(_detector_backward_native)
-
-
-def smooth_L1_loss(deltas, targets, sigma=3.0):
-    """loss.py:3-13, quirk included (option1 * option2, loss.py:9)."""
-    sigma2 = sigma * sigma
-    diffs = deltas - targets
-    smooth_l1_signs = torch.lt(torch.abs(diffs), 1.0 / sigma2).float()
-    option1 = torch.mul(diffs, diffs) * 0.5 * sigma2
-    option2 = torch.abs(diffs) - 0.5 / sigma2
-    return torch.mul(option1, option2) + torch.mul(option2, 1 - smooth_l1_signs)
 
 
 class _LossFn(torch.autograd.Function):
@@ -790,6 +858,40 @@ class RPN3D(nn.Module):
         self.native_executor = True      # C++ step executor (csrc/runtime.hip) instead of per-launch Python calls
         self.grad_reducer = None  # parallel.GradAllReducer: bucketed all-reduce overlapped with backward
         self.overlap_wgrad = True # native path: weight-gradient launches on a side stream beside the data-gradient ones
+
+    # Runtime caches kept in the instance __dict__ (ctypes arrays, HIP streams, the ~1.5 GB executor arenas, the flat
+    # gradient buffer, device-side target / decode helpers).  They are rebuilt on demand and must not travel with
+    # `torch.save(model)` (the reference's checkpoint format, train.py:24/27) or `copy.deepcopy(model)`.
+    _RUNTIME_KEYS = ("_side", "_ws_pool", "_flat_grads", "_targets", "_decoder", "_nbt", "_flat_param_list", "_net_ctx")
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k in self._RUNTIME_KEYS:
+            d.pop(k, None)
+        d["grad_reducer"] = None          # process groups / comm streams are per process
+        return d
+
+    def _net_handle(self, device):
+        """the executor context (vn_net_create: fork/join and bucket events) of this module on `device`"""
+        device = torch.device(device)
+        ctx = self.__dict__.get("_net_ctx")
+        if ctx is None or ctx[0] != device:
+            if ctx is not None:
+                _lib.load().vn_net_destroy(ctx[1])
+            h = ctypes.c_void_p()
+            with torch.cuda.device(device):
+                _lib.call("vn_net_create", ctypes.byref(h))
+            ctx = (device, h)
+            self.__dict__["_net_ctx"] = ctx
+        return ctx[1]
+
+    def __del__(self):
+        ctx = self.__dict__.get("_net_ctx")
+        if ctx is not None:
+            try:
+                _lib.load().vn_net_destroy(ctx[1])
+            except Exception:   # noqa: BLE001 - interpreter shutdown
+                pass
 
     def _side_stream(self, device):
         """HIP stream handle (ctypes) of the module-owned side stream for the native backward"""

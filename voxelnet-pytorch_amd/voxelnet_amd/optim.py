@@ -16,27 +16,46 @@ from . import _lib
 CHUNK = 4096    # VN_OPT_CHUNK (include/voxelnet_hip.h)
 
 
-class ClipSGD:
+class ClipSGD(torch.optim.Optimizer):
     """`ClipSGD(params, lr, max_norm).step()` == `clip_grad_norm_(params, max_norm); SGD(params, lr).step()`.
-    step() returns the total gradient norm before clipping (a device scalar, clip_grad_norm_'s return value)."""
+    step() returns the total gradient norm before clipping (a device scalar, clip_grad_norm_'s return value).
+
+    A torch.optim.Optimizer: `param_groups` / `state_dict()` / `load_state_dict()` / `zero_grad()` are the base class's, so
+    the reference's `MultiStepLR(optimizer, ...)` (train.py:131) attaches and its lr changes are honoured: the learning
+    rate is read from `param_groups[0]["lr"]` at every step.  The norm is taken over ALL parameters together (as
+    train.py:153 does), so every group must carry the same lr / max_norm."""
 
     def __init__(self, params, lr, max_norm, scale_grads=False):
-        self.params = [p for p in params]
-        if not self.params:
+        defaults = dict(lr=float(lr), max_norm=float(max_norm), scale_grads=bool(scale_grads))
+        super().__init__(params, defaults)
+        if not any(len(g["params"]) for g in self.param_groups):
             raise ValueError("ClipSGD got an empty parameter list")
-        self.lr, self.max_norm, self.scale_grads = float(lr), float(max_norm), bool(scale_grads)
         self._key = None
         self._table = self._ws = self._norm = None
         self._n_chunks = 0
 
-    def zero_grad(self, set_to_none=True):
-        for p in self.params:
-            if p.grad is None:
-                continue
-            if set_to_none:
-                p.grad = None
-            else:
-                p.grad.detach_().zero_()
+    # (kept for callers of the round-1 class)
+    @property
+    def params(self):
+        return [p for g in self.param_groups for p in g["params"]]
+
+    @property
+    def lr(self):
+        return float(self.param_groups[0]["lr"])
+
+    @property
+    def max_norm(self):
+        return float(self.param_groups[0]["max_norm"])
+
+    @property
+    def scale_grads(self):
+        return bool(self.param_groups[0]["scale_grads"])
+
+    def __setstate__(self, state):        # (the base class pickles defaults / state / param_groups only)
+        super().__setstate__(state)
+        self._key = None                  # device chunk table / workspace: rebuilt on the first step
+        self._table = self._ws = self._norm = None
+        self._n_chunks = 0
 
     def _build(self, pairs, dev):
         rows = []
@@ -53,7 +72,12 @@ class ClipSGD:
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
+        if closure is not None:
+            raise _lib.VoxelnetHipError("ClipSGD.step: closures are not supported")
+        for g in self.param_groups[1:]:
+            if g["lr"] != self.param_groups[0]["lr"] or g["max_norm"] != self.param_groups[0]["max_norm"]:
+                raise _lib.VoxelnetHipError("ClipSGD: one lr / max_norm for all parameter groups (the clip norm is global)")
         pairs = [(p, p.grad) for p in self.params if p.grad is not None]
         if not pairs:
             return None

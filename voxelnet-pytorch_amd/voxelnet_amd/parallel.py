@@ -14,6 +14,9 @@ starts the all-reduce.  xGMI is point-to-point (7 links/GPU), so a handful of mu
 is the right granularity: each all-reduce is large enough to be bandwidth-bound and the last,
 small bucket (the layers that finish last) is what is left exposed.
 """
+import ctypes
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -39,9 +42,13 @@ def group_of(param_name):
 class GradAllReducer:
     """Flat-bucket gradient averaging.  Works with any backend (gloo on CPU in the tests)."""
 
-    def __init__(self, named_params, process_group=None, plan=BUCKET_PLAN, use_side_stream=True):
+    def __init__(self, named_params, process_group=None, plan=BUCKET_PLAN, use_side_stream=True, direct_rccl=None):
+        """direct_rccl: all-reduce through the library's own RCCL wrapper (vn_allreduce_bucket on a communicator made by
+        vn_comm_create; csrc/comm.hip) instead of torch.distributed's all_reduce.  Default: the environment variable
+        VN_DIRECT_RCCL=1; torch.distributed (backend "nccl" == RCCL) otherwise.  Same collective either way."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
         named_params = list(named_params)
         self.buckets = []          # dicts: flat, views{name: tensor}, pending(set), handle
         self.where = {}            # param name -> bucket index
@@ -63,7 +70,46 @@ class GradAllReducer:
         self.cuda = self.buckets[0]["flat"].is_cuda
         self.comm_stream = torch.cuda.Stream() if (self.cuda and use_side_stream) else None
         self.defer_allreduce = False   # True: grad_ready only fills the buckets (HIP-graph capture); allreduce_all() later
+        self.comm = None               # ncclComm_t of the direct path
+        if direct_rccl is None:
+            direct_rccl = os.environ.get("VN_DIRECT_RCCL") == "1"
+        if direct_rccl and self.cuda:
+            self._init_direct()
         self.reset()
+
+    def _init_direct(self):
+        """one RCCL communicator over the ranks of the process group: rank 0's unique id travels through
+        torch.distributed's object broadcast (any backend), then every rank calls vn_comm_create on its device"""
+        from . import _lib
+        ident = (ctypes.c_ubyte * 128)()
+        if self.rank == 0:
+            _lib.call("vn_comm_unique_id", ident)
+        if self.world > 1:
+            box = [bytes(ident)]
+            dist.broadcast_object_list(box, src=0, group=self.pg)
+            ident = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
+        h = ctypes.c_void_p()
+        with torch.cuda.device(self.buckets[0]["flat"].device):
+            _lib.call("vn_comm_create", ctypes.byref(h), ident, self.world, self.rank)
+        self.comm = h
+
+    def close(self):
+        if self.comm is not None:
+            from . import _lib
+            torch.cuda.synchronize()
+            _lib.load().vn_comm_destroy(self.comm)
+            self.comm = None
+
+    def _reduce(self, b):
+        """mean over the ranks of bucket b, in place, on the CURRENT stream; returns a work handle or None"""
+        flat = b["flat"]
+        if self.comm is not None:
+            from . import _lib
+            _lib.call("vn_allreduce_bucket", self.comm, flat.data_ptr(), flat.numel(), 1.0 / self.world,
+                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+            return None
+        flat.div_(self.world)
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
 
     def reset(self):
         for b in self.buckets:
@@ -80,19 +126,16 @@ class GradAllReducer:
             self._launch(b)
 
     def _launch(self, b):
-        if self.world == 1 or self.defer_allreduce:
+        if (self.world == 1 and self.comm is None) or self.defer_allreduce:
             return
-        flat = b["flat"]
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             self.comm_stream.wait_event(ev)
             with torch.cuda.stream(self.comm_stream):
-                flat.div_(self.world)
-                b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                b["handle"] = self._reduce(b)
         else:
-            flat.div_(self.world)
-            b["handle"] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            b["handle"] = self._reduce(b)
 
     def launch_bucket(self, bi, wait_fn=None, after_event=None, prelude=None):
         """All-reduce bucket bi on the comm stream once (a) wait_fn(comm_stream) has made the comm stream wait for whatever
@@ -105,9 +148,8 @@ class GradAllReducer:
         if st is None:                       # CPU tensors / no side stream: plain, in order
             if prelude is not None:
                 prelude()
-            if self.world > 1 and not self.defer_allreduce:
-                b["flat"].div_(self.world)
-                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if (self.world > 1 or self.comm is not None) and not self.defer_allreduce:
+                b["handle"] = self._reduce(b)
             return
         with torch.cuda.stream(st):
             if after_event is not None:
@@ -116,20 +158,17 @@ class GradAllReducer:
                 wait_fn(st)
             if prelude is not None:
                 prelude()
-            if self.world > 1 and not self.defer_allreduce:
-                b["flat"].div_(self.world)
-                b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            if (self.world > 1 or self.comm is not None) and not self.defer_allreduce:
+                b["handle"] = self._reduce(b)
 
     def allreduce_all(self):
         """deferred mode: all-reduce every (already filled) bucket now, largest first, and wait"""
-        if self.world == 1:
+        if self.world == 1 and self.comm is None:
             return
-        hs = []
-        for b in self.buckets:
-            b["flat"].div_(self.world)
-            hs.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+        hs = [self._reduce(b) for b in self.buckets]
         for h in hs:
-            h.wait()
+            if h is not None:
+                h.wait()
 
     def finish(self, named_params, launch_deferred=False):
         """wait for every bucket and point .grad of each parameter at its averaged view"""

@@ -13,6 +13,7 @@ import ctypes
 
 import numpy as np
 import torch
+import torch.utils.data
 
 from . import _lib
 from .config import grid_config
@@ -124,17 +125,50 @@ def voxelize_device_async(points, grid, batch_index=0, coord_cols=4, buffers=Non
     return AsyncVoxels(feature, coord, number, k_host, ev)
 
 
-def pcl_to_voxels(pcl, target, verbose=False, device="cuda:0"):
-    """Drop-in for utils.pcl_to_voxels (utils.py:10-100): numpy in, dict of numpy out."""
+def voxelize_host(points, grid, batch_index=0, coord_cols=3):
+    """points: (N,4) float32 numpy array in processing order -> (feature (K,T,7) f32, coord (K,coord_cols) i64, number
+    (K,) i64) numpy arrays, through the library's HOST entry points (vn_voxelize_host_index / _gather): no GPU is
+    touched, so this is what runs inside forked DataLoader workers (dataset.py:58)."""
+    pts = np.ascontiguousarray(points[:, :4], dtype=np.float32)
+    n = pts.shape[0]
+    gs = _grid_struct(grid)
+    lib = _lib.load()
+    ws_bytes = lib.vn_voxelize_host_workspace_bytes(n, ctypes.byref(gs))
+    if ws_bytes == 0:
+        raise _lib.VoxelnetHipError("vn_voxelize_host_workspace_bytes: unsupported grid / point count")
+    ws = np.empty(ws_bytes, dtype=np.uint8)
+    k = ctypes.c_int64(0)
+    _lib.call("vn_voxelize_host_index", pts.ctypes.data, n, ctypes.byref(gs), ws.ctypes.data, ws_bytes, ctypes.byref(k))
+    K = int(k.value)
+    feature = np.empty((K, grid.T, 7), dtype=np.float32)
+    coord = np.empty((K, coord_cols), dtype=np.int64)
+    number = np.empty((K,), dtype=np.int64)
+    _lib.call("vn_voxelize_host_gather", pts.ctypes.data, n, ctypes.byref(gs), ws.ctypes.data, ws_bytes, K, int(batch_index),
+              coord_cols, feature.ctypes.data, coord.ctypes.data, number.ctypes.data)
+    return feature, coord, number
+
+
+def pcl_to_voxels(pcl, target, verbose=False, device=None):
+    """Drop-in for utils.pcl_to_voxels (utils.py:10-100): numpy in, dict of numpy out.
+    device: "cuda[:i]" -> the HIP voxelizer; "cpu" -> the library's host entry (vn_voxelize_host_*).  None (default, the
+    reference's signature): the host entry inside a DataLoader worker process (where the reference calls it,
+    dataset.py:58: a forked worker must not touch the GPU), the HIP voxelizer on cuda:0 otherwise.  Both give the same
+    bits."""
     grid = grid_config("Car" if target == "Car" else "Pedestrian")   # utils.py:24-33: 'Car' else ped/cyc
     np.random.shuffle(pcl)                                           # utils.py:35, in place
-    pts = torch.from_numpy(np.ascontiguousarray(pcl[:, :4], dtype=np.float32)).to(device)
-    feature, coord, number = voxelize_device(pts, grid, 0, coord_cols=3)
-    voxel_dict = {
-        "feature_buffer": feature.cpu().numpy(),
-        "coordinate_buffer": coord.cpu().numpy(),
-        "number_buffer": number.cpu().numpy(),
-    }
+    if device is None:
+        device = "cpu" if torch.utils.data.get_worker_info() is not None else "cuda:0"
+    if str(device) == "cpu":
+        feature, coord, number = voxelize_host(pcl, grid, 0, coord_cols=3)
+        voxel_dict = {"feature_buffer": feature, "coordinate_buffer": coord, "number_buffer": number}
+    else:
+        pts = torch.from_numpy(np.ascontiguousarray(pcl[:, :4], dtype=np.float32)).to(device)
+        feature, coord, number = voxelize_device(pts, grid, 0, coord_cols=3)
+        voxel_dict = {
+            "feature_buffer": feature.cpu().numpy(),
+            "coordinate_buffer": coord.cpu().numpy(),
+            "number_buffer": number.cpu().numpy(),
+        }
     if verbose:
         print(f"Coordinate buffer shape: {voxel_dict['coordinate_buffer'].shape}")
         print(f"Feature buffer shape: {voxel_dict['feature_buffer'].shape}")
