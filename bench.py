@@ -2,19 +2,31 @@
 """Benchmark of the VoxelNet training hot path on MI355X (BASELINE.json metric:
 point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2 per GPU).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W                      (default workload: BASELINE configs[1])
+    python bench.py --config ped | dense                               (BASELINE configs[2] / configs[4])
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One step = the reference's train step (train.py:148-155) on one batch of synthetic KITTI-shaped
-frames whose raw (N,4) point clouds are already resident in HBM:
+One step = the reference's train step (train.py:148-155) on one batch of synthetic KITTI-shaped frames whose raw (N,4)
+point clouds are already resident in HBM:
     voxelize (HIP) -> VFE x2 + max (HIP) -> [sparse->dense scatter folded into the rulebook first Conv3d] -> 3 Conv3d +
     RPN (MFMA implicit GEMM) -> loss (model.py:310-352) -> backward of all of it -> [N>1: bucketed RCCL all-reduce
     overlapped with backward] -> clip_grad_norm_(5) + SGD(lr=0.01) step (fused: vn_clip_sgd) -> zero_grad.
-Rank 0 prints ONE JSON line.  `roofline` is measured live (HIP events around every launch of the
-MFMA kernels in eager steps right after the timed region); `cpu_baseline` times the oracle (PyTorch-CPU restatement of the
-reference's op sequence + the C voxelizer) on this box's host cores, on a bounded sample.
+(ped: the reference's loss cannot run for Pedestrian / Cyclist — its anchor grid does not match the network's output,
+SURVEY.md 8a-a8 — so the backward starts from a fixed seeded upstream gradient)
+
+Rank 0 prints ONE JSON line.
+  roofline      the dominant kernel family — the implicit-GEMM convolutions (k_conv_patch + k_gather_gemm: forward and data
+                gradient of every layer) — measured live: HIP events around every launch ON THE STREAM IT IS LAUNCHED ON,
+                inside the same native executor path the timed region runs (vn_net_timing_begin/_read), in
+                `--timer-steps` steps on the same inputs right after the timed region (events inside the timed region
+                would cost host time there).  achieved = algorithmic FLOPs (2 x MACs of the layer
+                definition; a data gradient counts the layer's forward FLOPs) / summed launch time.
+  kernels       the same for every family of the step; HBM-bound families carry algorithmic bytes and GB/s.
+  cpu_baseline  the oracle (PyTorch-CPU restatement of the reference's op sequence + the C voxelizer) timed on this
+                box's host cores on a bounded sample.
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -30,7 +42,19 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_BF16_DENSE_TFLOPS = 2500.0   # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
-FLOP_PER_PC_FWD_BWD = 1732.3e9    # dense-equivalent conv/deconv/head FLOPs, fwd + bwd (x3)
+PEAK_F32_MATRIX_TFLOPS = 157.3    # v_mfma_f32_16x16x4_f32 (the fp32 parity mode)
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# dense-equivalent conv/deconv/head FLOPs per point cloud, forward + backward (x3)
+FLOP_PER_PC = {"car": 1732.3e9, "dense": 1732.3e9, "ped": 929.0e9}
+
+CONFIGS = {
+    # name: (BASELINE.json configs index, synth workload id, class, T, default batch, description)
+    "car": (1, 2, "Car", 35, 2, "KITTI car config (voxel 0.2x0.2x0.4 m, grid 10x400x352, T=35)"),
+    "ped": (2, 3, "Pedestrian", 45, 2, "KITTI pedestrian/cyclist config (grid 10x200x240, T=45)"),
+    "dense": (4, 5, "Car", 64, 4, "dense synthetic scene (~300k pts/frame, 40k voxels, T=64, car grid)"),
+}
+KIND_NAMES = ["conv_fwd", "conv_dgrad", "wgrad", "bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "bn_finalize", "unpack_wgrads",
+              "pack_weights", "first_layer_sparse", "misc"]
 
 
 def synthetic_targets(B, h, w, seed, device):
@@ -42,24 +66,55 @@ def synthetic_targets(B, h, w, seed, device):
     return tuple(torch.from_numpy(a).to(device) for a in (pos, neg, tgt))
 
 
-def cpu_baseline(frames_np, threads):
-    """oracle (kind 'port'): C voxelizer + PyTorch-CPU fwd+bwd of the reference's op sequence, 1 frame"""
+def cpu_model_string():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(frames_np, cls, T, threads):
+    """oracle (kind 'port') on the host cores: B=2 fwd+bwd after one warm step (the metric's shape) and B=1 forward only
+    (BASELINE configs[0]); C voxelizer + PyTorch-CPU restatement of the reference's op sequence."""
     from oracle import torch_ref as tr
     from oracle import voxelize as ov
+    from voxelnet_amd.config import grid_config
     torch.set_num_threads(threads)
-    cloud = frames_np[0]
-    t0 = time.perf_counter()
-    v = ov.voxelize(cloud, "Car")
-    f, _, c = ov.prepare_voxel([v])
-    feats, coords = [torch.from_numpy(f[0])], [torch.from_numpy(c[0])]
+    grid = grid_config(cls, T=T)
+    hw = (grid.H // grid.block1_stride, grid.W // grid.block1_stride)
+    nb = min(2, len(frames_np))
     rng = np.random.default_rng(1)
-    dp = torch.from_numpy((rng.standard_normal((1, 2, 200, 176)) * 1e-2).astype(np.float32))
-    dr = torch.from_numpy((rng.standard_normal((1, 14, 200, 176)) * 1e-2).astype(np.float32))
-    tr.forward_backward(feats, coords, tr.make_state_dict("Car"), (10, 400, 352), "Car", dp, dr)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "point-clouds/s", "cores": threads, "kind": "port",
-            "sample": "1 step on 1 car frame (batch=1): C voxelizer + PyTorch-CPU fwd+bwd of the reference op "
-                      "sequence, %.1f s" % dt}
+    dp = torch.from_numpy((rng.standard_normal((nb, 2) + hw) * 1e-2).astype(np.float32))
+    dr = torch.from_numpy((rng.standard_normal((nb, 14) + hw) * 1e-2).astype(np.float32))
+
+    def step(nfr, backward):
+        vs = [ov.voxelize(frames_np[b], cls, T=T) for b in range(nfr)]
+        f, _, c = ov.prepare_voxel(vs)
+        feats, coords = [torch.from_numpy(x) for x in f], [torch.from_numpy(x) for x in c]
+        sd = tr.make_state_dict(cls)
+        if backward:
+            tr.forward_backward(feats, coords, sd, grid.dims, cls, dp[:nfr], dr[:nfr])
+        else:
+            with torch.no_grad():
+                tr.middle_rpn(tr.feature_net(feats, coords, sd, grid.dims, True), sd, cls, True)
+
+    step(nb, True)                       # warm (allocator, thread pool, oneDNN primitive caches)
+    t0 = time.perf_counter()
+    step(nb, True)
+    t_fb = time.perf_counter() - t0
+    step(1, False)
+    t0 = time.perf_counter()
+    step(1, False)
+    t_f = time.perf_counter() - t0
+    return {"value": nb / t_fb, "unit": "point-clouds/s", "cores": threads, "kind": "port", "cpu": cpu_model_string(),
+            "sample": "1 warm + 1 timed step, batch=%d fwd+bwd (%.1f s): C voxelizer + PyTorch-CPU restatement of the reference "
+                      "op sequence; also batch=1 forward only (BASELINE configs[0]): %.2f point-clouds/s (%.1f s)"
+                      % (nb, t_fb, 1.0 / t_f, t_f),
+            "fwd_only_b1_value": 1.0 / t_f}
 
 
 def main():
@@ -67,17 +122,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="car", choices=sorted(CONFIGS),
+                    help="car = BASELINE configs[1] (the metric's workload, default), ped = configs[2], dense = configs[4]")
     ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
-    ap.add_argument("--batch", type=int, default=2, help="frames per GPU (BASELINE configs[1]: 2)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: 2, 2, 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="experimental: replay the post-voxelizer part of the step from captured HIP graphs")
+    ap.add_argument("--no-parity-mode", action="store_true", help="skip the short fp32 (parity mode) throughput run")
     ap.add_argument("--torch-optim", action="store_true",
                     help="torch's clip_grad_norm_ + SGD instead of the fused vn_clip_sgd tail (same arithmetic)")
     ap.add_argument("--timer-steps", type=int, default=3)
     ap.add_argument("--force-reducer", action="store_true",
-                    help="diagnostic: run the DDP bucket path (flat buckets, segmented backward) on one GPU")
+                    help="diagnostic: run the DDP bucket path (flat buckets, bucket events) on one GPU")
     ap.add_argument("--static-voxels", action="store_true",
                     help="diagnostic: voxelize once, outside the timed steps (NOT the benchmark configuration)")
     args = ap.parse_args()
@@ -87,7 +143,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
     # rehearsal aid (NOT a benchmark configuration): VN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, so
-    # the N>1 code path (broadcast, bucketed all-reduce overlapped with the segmented backward, MAX over ranks) can be
+    # the N>1 code path (broadcast, bucketed all-reduce overlapped with the backward, MAX over ranks) can be
     # exercised on a one-GPU box
     share = os.environ.get("VN_BENCH_SHARE_GPU") == "1"
     if share:
@@ -102,19 +158,29 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
+    from voxelnet_amd import _lib
     from voxelnet_amd import engine as E
     from voxelnet_amd import model as M
     from voxelnet_amd import parallel, synth
     from voxelnet_amd.config import GRADIENT_CLIP, LR, grid_config
+    from voxelnet_amd.optim import ClipSGD
     from voxelnet_amd.voxelize import VoxelBuffers, voxelize_device_async
 
-    M.set_precision(args.precision)
-    torch.manual_seed(1234)                      # same initial weights on every rank
-    model = M.RPN3D("Car").to(dev)
-    model.train(True)                            # train.py:148
+    cfg_index, workload_id, cls, T, default_batch, cfg_desc = CONFIGS[args.config]
+    B = args.batch or default_batch
+    grid = grid_config(cls, T=T)
+    with_loss = cls == "Car"
+
+    def build_model(precision):
+        M.set_precision(precision)
+        torch.manual_seed(1234)                      # same initial weights on every rank
+        m = M.RPN3D(cls).to(dev)
+        m.train(True)                                # train.py:148
+        return m
+
+    model = build_model(args.precision)
     named = list(model.named_parameters())
     params = [p for _, p in named]
-    from voxelnet_amd.optim import ClipSGD
     # train.py:130 + 153-154: clip_grad_norm_(5) + SGD(lr=0.01) as two HIP launches (csrc/optim.hip);
     # --torch-optim runs torch's own clip_grad_norm_ + SGD instead (same arithmetic, ~12 launches)
     opt = torch.optim.SGD(params, lr=LR) if args.torch_optim else ClipSGD(params, LR, GRADIENT_CLIP)
@@ -124,22 +190,25 @@ def main():
     if world > 1 or args.force_reducer:
         model.grad_reducer = parallel.GradAllReducer(named)
 
-    B = args.batch
-    grid = grid_config("Car")
-    frames_np = synth.workload_frames(2, batch=B, frame0=rank * B)   # weak scaling: own frames per rank
-    frames = [torch.from_numpy(f).to(dev) for f in frames_np]       # resident in HBM before timing
-    h, w = model.rpn_output_shape
-    targets = synthetic_targets(B, h, w, 99 + rank, dev)
+    frames_np = synth.workload_frames(workload_id, batch=B, frame0=rank * B)   # weak scaling: own frames per rank
+    frames = [torch.from_numpy(f).to(dev) for f in frames_np]                  # resident in HBM before timing
+    hf, wf = grid.H // grid.block1_stride, grid.W // grid.block1_stride
 
-    # Voxelization is software-pipelined one step ahead on its own HIP stream (the input-pipeline stage of the
-    # step): the K read-back that sizes its outputs (utils.py:69-71 returns (K,T,7)/(K,3)/(K,) arrays) then only
-    # never stalls the training queue (capacity-sized outputs, K read by the gather kernel from device memory,
-    # asynchronous K copy to pinned memory: voxelize_device_async).  Every timed step still runs one
-    # voxelization of its B frames (for the next step) and one train step (on the buffers voxelized during the
-    # previous one).
+    def make_targets():
+        if with_loss:
+            return synthetic_targets(B, hf, wf, 99 + rank, dev), None
+        rng = np.random.default_rng(4100 + rank)     # seeded N(0,1) * 1e-3 upstream gradient
+        return None, (torch.from_numpy((rng.standard_normal((B, 2, hf, wf)) * 1e-3).astype(np.float32)).to(dev),
+                      torch.from_numpy((rng.standard_normal((B, 14, hf, wf)) * 1e-3).astype(np.float32)).to(dev))
+    targets, upstream = make_targets()
+
+    # Voxelization is software-pipelined one step ahead on its own HIP stream (the input-pipeline stage of the step): the
+    # K read-back that sizes its outputs (utils.py:69-71 returns (K,T,7)/(K,3)/(K,) arrays) never stalls the training
+    # queue (capacity-sized outputs, K read by the gather kernel from device memory, asynchronous K copy to pinned memory:
+    # voxelize_device_async).  Every timed step still runs one voxelization of its B frames (for the next step) and one
+    # train step (on the buffers voxelized during the previous one).
     vox_stream = torch.cuda.Stream()
     pending = {}
-
     slots = [[VoxelBuffers(pts.shape[0], grid, 4, dev) for pts in frames] for _ in range(3)]   # 3-deep ring
     ring = {"i": 0, "use": 0}
     slot_free = [None, None, None]     # event recorded on the training stream after the last consumer of the slot
@@ -174,20 +243,17 @@ def main():
             pending["static"] = (feats, coords)
         return feats, coords
 
+    state = {"model": model, "opt": opt, "params": params, "named": named}
+
     def fwd_bwd(feats, coords):
-        batch = (None, None, feats, None, coords, None, None)
-        out = model(batch, dev, targets=targets)
-        out[2].backward()                                                  # train.py:151
-        return out[2]
-
-    def reduce_grads():
-        if model.grad_reducer is not None:
-            model.grad_reducer.finish(named)
-
-    def optim():
-        if args.torch_optim:
-            torch.nn.utils.clip_grad_norm_(params, GRADIENT_CLIP)          # train.py:153
-        opt.step()                                                         # train.py:154 (ClipSGD: both lines)
+        m = state["model"]
+        if with_loss:
+            out = m((None, None, feats, None, coords, None, None), dev, targets=targets)
+            out[2].backward()                                              # train.py:151
+            return out[2]
+        prob, reg = m.detect(feats, coords)
+        torch.autograd.backward([prob, reg], list(upstream))
+        return prob.flatten()[0]
 
     def step_eager():
         feats, coords = voxelize_batch()
@@ -198,9 +264,13 @@ def main():
             ev = slot_free[si] if slot_free[si] is not None else torch.cuda.Event()
             ev.record()
             slot_free[si] = ev
-        reduce_grads()
-        optim()
-        opt.zero_grad(set_to_none=True)                                    # train.py:155
+        m = state["model"]
+        if m.grad_reducer is not None:
+            m.grad_reducer.finish(state["named"])
+        if args.torch_optim:
+            torch.nn.utils.clip_grad_norm_(state["params"], GRADIENT_CLIP)  # train.py:153
+        state["opt"].step()                                                # train.py:154 (ClipSGD: both lines)
+        state["opt"].zero_grad(set_to_none=True)                           # train.py:155
         return loss
 
     def sync_all():
@@ -212,68 +282,10 @@ def main():
     for _ in range(max(1, args.warmup)):
         loss = step_eager()
     sync_all()
-
-    # ---- HIP-graph mode: everything after the voxelizer is replayed from two captured graphs ----------
-    # (voxelization reads K back to size its outputs, so it stays eager; the RCCL all-reduce runs between
-    #  the fwd+bwd graph and the clip+SGD graph).  Shapes are static because the frames of this benchmark
-    #  are; a change of K re-captures.
-    mode = "eager"
-    step = step_eager
-    if args.graph:
-        try:
-            feats0, coords0 = voxelize_batch()
-            st_feats = [f.clone() for f in feats0]
-            st_coords = [c.clone() for c in coords0]
-            opt.zero_grad(set_to_none=True)
-            if model.grad_reducer is not None:
-                model.grad_reducer.defer_allreduce = True          # bucket copies are captured, collectives are not
-            torch.cuda.synchronize()
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                st_loss = fwd_bwd(st_feats, st_coords)
-            if model.grad_reducer is not None:
-                model.grad_reducer.finish(named, launch_deferred=True)   # p.grad -> static bucket views
-            g2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g2):
-                optim()
-            torch.cuda.synchronize()
-
-            def step_graph():
-                feats, coords = voxelize_batch()
-                for s_, f_ in zip(st_feats, feats):
-                    if s_.shape != f_.shape:
-                        raise RuntimeError("voxel count changed: static-shape graph is stale")
-                    s_.copy_(f_)
-                for s_, c_ in zip(st_coords, coords):
-                    s_.copy_(c_)
-                g1.replay()
-                if model.grad_reducer is not None:
-                    model.grad_reducer.allreduce_all()
-                g2.replay()
-                return st_loss
-            step = step_graph
-            for _ in range(2):
-                loss = step()
-            sync_all()
-            mode = "hipgraph"
-        except Exception as e:   # noqa: BLE001 - report and fall back to the eager step
-            if rank == 0:
-                import traceback
-                traceback.print_exc()
-                print(f"[bench] graph capture failed ({type(e).__name__}); running eager", file=sys.stderr)
-            torch.cuda.synchronize()
-            if model.grad_reducer is not None:
-                model.grad_reducer.defer_allreduce = False
-                model.grad_reducer.reset()
-            opt.zero_grad(set_to_none=True)
-            step = step_eager
-            mode = "eager"
-
-    sync_all()
     t0 = time.perf_counter()
     step_events = []
     for _ in range(args.steps):
-        loss = step()
+        loss = step_eager()
         if os.environ.get("VN_BENCH_STEP_TIMES"):
             ev = torch.cuda.Event(enable_timing=True)
             ev.record()
@@ -285,87 +297,155 @@ def main():
         print("[bench] per-step ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(step_events, step_events[1:])),
               file=sys.stderr)
     assert torch.isfinite(loss).item(), "non-finite loss"
-    ranks_in_sync = None
+    ranks_in_sync, grad_checksums_equal = None, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # self-check of the data-parallel path (outside the timed region): every rank started from rank 0's weights
-        # and applied the same averaged gradients, so the parameters must still be bit-identical on all ranks
+        # and applied the same averaged gradients, so the parameters must still be bit-identical on all ranks ...
         with torch.no_grad():
             cs = torch.stack([torch.stack([p.double().sum(), p.double().abs().sum()]) for p in params]).sum(0)
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         ranks_in_sync = bool(torch.equal(lo, hi))
-        if not ranks_in_sync and rank == 0:
-            print("[bench] WARNING: parameter checksums differ between ranks", file=sys.stderr)
+        # ... and so must the averaged gradients of the last step (they are still in the reducer's buckets)
+        gcs = torch.tensor([model.grad_reducer.checksum()], dtype=torch.float64, device=dev)
+        glo, ghi = gcs.clone(), gcs.clone()
+        dist.all_reduce(glo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(ghi, op=dist.ReduceOp.MAX)
+        grad_checksums_equal = bool(torch.equal(glo, ghi))
+        if not (ranks_in_sync and grad_checksums_equal) and rank == 0:
+            print("[bench] WARNING: parameter / gradient checksums differ between ranks", file=sys.stderr)
 
-    # ---- per-kernel durations: HIP events around every MFMA-kernel launch, eager steps on the same inputs
-    timer = None
-    if not args.no_kernel_timer and rank == 0 or (not args.no_kernel_timer and world > 1):
-        if mode == "hipgraph":
-            if model.grad_reducer is not None:
-                model.grad_reducer.defer_allreduce = False
-                model.grad_reducer.reset()
-            opt.zero_grad(set_to_none=True)
-        timer = E.KernelTimer()
-        E.TIMER = timer
-        native = model.native_executor
-        model.native_executor = False      # per-launch events need the per-launch (Python) orchestration:
-        for _ in range(args.timer_steps):  # same kernels, same shapes, same inputs
+    # ---- per-kernel durations: the native executor's own HIP events around every launch (same path as the timed region),
+    #      torch events around the launch groups the Python side issues (voxelizer, VFE, loss, optimizer)
+    recs, sect = None, None
+    native_timed = model.native_executor and args.precision in ("bf16", "fp32")
+    if not args.no_kernel_timer and (rank == 0 or world > 1):
+        sect = E.KernelTimer()
+        E.SECTIONS = sect
+        recs = []
+        buf = (_lib.VnTimingRecord * 4096)()
+        n_rec = ctypes.c_int32(0)
+        for _ in range(args.timer_steps):
+            if native_timed:
+                _lib.call("vn_net_timing_begin", model._net_handle(dev), 4096)
             step_eager()
+            torch.cuda.synchronize()
+            if native_timed:
+                _lib.call("vn_net_timing_read", model._net_handle(dev), buf, 4096, ctypes.byref(n_rec))
+                recs += [(r.kind, r.layer, r.ms, r.flops, r.bytes) for r in buf[:n_rec.value]]
         sync_all()
-        model.native_executor = native
-        E.TIMER = None
+        E.SECTIONS = None
+
+    # ---- the same step in the fp32 parity mode (the mode the <= 1e-3 parity tests run in), a few steps
+    parity = None
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_parity_mode:
+        pm = build_model("fp32")
+        state.update(model=pm, params=list(pm.parameters()), named=list(pm.named_parameters()),
+                     opt=ClipSGD(list(pm.parameters()), LR, GRADIENT_CLIP))
+        for _ in range(2):
+            step_eager()
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(5):
+            step_eager()
+        torch.cuda.synchronize()
+        tpe = time.perf_counter() - tp
+        parity = {"dtype": "f32", "value": B * 5 / tpe, "unit": "point-clouds/s", "ms_per_step": 1e3 * tpe / 5,
+                  "note": "fp32 operands on v_mfma_f32_16x16x4_f32: the mode of the <= 1e-3 parity tests"}
+        state.update(model=model, params=params, named=named, opt=opt)
+        M.set_precision(args.precision)
+        del pm
 
     if rank == 0:
         value = world * B * args.steps / dt
+        peak = PEAK_BF16_DENSE_TFLOPS if args.precision != "fp32" else PEAK_F32_MATRIX_TFLOPS
+        metric = "point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2"
+        if args.config != "car":
+            metric = "point-clouds/sec fwd+bwd, %s, batch=%d" % (cfg_desc, B)
         res = {
-            "metric": "point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2",
+            "metric": metric,
             "value": value, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
-            "config": {"workload": "KITTI car config (voxel 0.2x0.2x0.4 m, grid 10x400x352, T=35), batch=%d per GPU, "
-                                   "fwd+bwd train step (BASELINE configs[1])" % B,
+            "config": {"workload": "%s, batch=%d per GPU, fwd+bwd train step (BASELINE configs[%d])" % (cfg_desc, B, cfg_index),
                        "global_batch": world * B, "points_per_frame": int(frames_np[0].shape[0]),
                        "parallelism": "dp%d" % world,
-                       "step": "voxelize+VFE+scatter+Conv3d+RPN fwd, loss, bwd, clip_grad_norm, SGD",
-                       "launch_mode": mode + ("+native-executor" if model.native_executor else "")},
+                       "step": "voxelize+VFE+scatter+Conv3d+RPN fwd, %s, bwd, clip_grad_norm, SGD"
+                               % ("loss" if with_loss else "seeded upstream gradient (the reference's loss is undefined for this class)"),
+                       "launch_mode": "eager" + ("+native-executor" if model.native_executor else "")},
             "host_enqueue_ms_per_step": 1e3 * t_enq / args.steps,
-            "model_flops_fraction_of_bf16_peak": value / world * FLOP_PER_PC_FWD_BWD / (PEAK_BF16_DENSE_TFLOPS * 1e12),
+            # dense-equivalent model FLOPs (the first Conv3d's skipped zeros NOT subtracted) over the whole step
+            "model_flops_fraction_of_peak": value / world * FLOP_PER_PC[args.config] / (peak * 1e12),
         }
         if ranks_in_sync is not None:
             res["ranks_in_sync"] = ranks_in_sync       # parameters bit-identical on all ranks after the timed steps
-        if timer is not None:
-            summ = timer.summary()
+            res["grad_checksums_equal"] = grad_checksums_equal
+        if recs is not None:
+            ns = float(args.timer_steps)
+            fam = {}
+            for kind, layer, ms, fl, by in recs:
+                n, t, f, b = fam.get(kind, (0, 0.0, 0.0, 0.0))
+                fam[kind] = (n + 1, t + ms, f + fl, b + by)
             kern = {}
-            for k, (n, fl, ms) in summ.items():
-                kern[k] = {"launches_per_step": n / args.timer_steps, "ms_per_step": ms / args.timer_steps,
-                           "achieved_tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
-            dom = max(summ, key=lambda k: summ[k][2])
-            n, fl, ms = summ[dom]
-            ach = fl / (ms * 1e-3) / 1e12
-            peak = PEAK_BF16_DENSE_TFLOPS if args.precision != "fp32" else 157.3
-            # HBM-side bytes per launch of the convolution family: NOT measurable here (PMC counters need rocprofv3);
-            # taken from the committed counter passes on this same command (profiles/, tools/pmc_family.py), bf16/B=2 only
-            traffic = None
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-            if dom == "k_gather_gemm" and args.precision == "bf16" and args.batch == 2 and os.path.exists(pmc):
-                with open(pmc) as fh:
-                    traffic = json.load(fh).get("traffic_bytes_per_launch")
-            res["roofline"] = {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": traffic,
-                               "avg_launch_us": 1e3 * ms / n, "launches": n,
-                               "note": "algorithmic (dense-equivalent) FLOPs of all launches / summed HIP-event time, "
-                                       "%d eager steps on the same inputs right after the timed region" % args.timer_steps}
+            for kind, (n, t, f, b) in sorted(fam.items()):
+                e = {"launches_per_step": n / ns, "ms_per_step": t / ns, "avg_launch_us": 1e3 * t / n}
+                if f > 0:
+                    e["gflop_per_step"] = f / ns / 1e9
+                    e["achieved_tflops"] = f / (t * 1e-3) / 1e12
+                    e["frac_of_mfma_peak"] = e["achieved_tflops"] / peak
+                if b > 0:
+                    e["algorithmic_mb_per_step"] = b / ns / 1e6
+                    e["achieved_gbs"] = b / (t * 1e-3) / 1e9
+                    e["frac_of_hbm_peak"] = e["achieved_gbs"] / PEAK_HBM_GBS
+                kern[KIND_NAMES[kind]] = e
+            for name, (n, by, ms) in sect.summary().items():
+                extra = 0.0
+                if name == "voxelize":               # outputs: 28*K*T + 40*K per frame (K known on the host by now)
+                    extra = sum((28.0 * T + 40.0) * s.k_host.item() for s in slots[0]) * (n / len(frames))
+                kern[name] = {"launches_per_step": n / ns, "ms_per_step": ms / ns, "avg_launch_us": 1e3 * ms / n,
+                              "algorithmic_mb_per_step": (by + extra) / ns / 1e6,
+                              "achieved_gbs": (by + extra) / (ms * 1e-3) / 1e9,
+                              "frac_of_hbm_peak": (by + extra) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
             res["kernels"] = kern
+            if fam:
+                # dominant family: the implicit-GEMM convolutions (forward + data gradient share the two kernels)
+                n = fam.get(0, (0, 0, 0, 0))[0] + fam.get(1, (0, 0, 0, 0))[0]
+                t = fam.get(0, (0, 0, 0, 0))[1] + fam.get(1, (0, 0, 0, 0))[1]
+                f = fam.get(0, (0, 0, 0, 0))[2] + fam.get(1, (0, 0, 0, 0))[2]
+                ach = f / (t * 1e-3) / 1e12
+                # HBM-side bytes per launch of that family: PMC counters cannot be read in-process; taken from the committed
+                # rocprofv3 --pmc passes of this same command (profiles/, tools/pmc_family.py), car / bf16 / batch 2 only
+                traffic = None
+                pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+                if args.config == "car" and args.precision == "bf16" and B == 2 and os.path.exists(pmc):
+                    with open(pmc) as fh:
+                        traffic = json.load(fh).get("traffic_bytes_per_launch")
+                res["roofline"] = {
+                    "kernel": "k_conv_patch + k_gather_gemm (implicit-GEMM convolutions: forward + data gradient)",
+                    "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+                    "traffic": traffic, "avg_launch_us": 1e3 * t / n, "launches_per_step": n / ns,
+                    "gflop_per_step": f / ns / 1e9, "ms_per_step": t / ns,
+                    "note": "algorithmic FLOPs (SURVEY.md 8d; the rulebook first layer with its executed FLOPs) / summed "
+                            "HIP-event time of every launch of the family, events on the launch's own stream inside the "
+                            "native executor, %d steps on the same inputs right after the timed region" % args.timer_steps}
+                # FLOPs the MFMA pipes actually execute in a step (first layer: rulebook, not dense-equivalent)
+                fx = sum(fam.get(k, (0, 0, 0, 0))[2] for k in (0, 1, 2)) / ns
+                res["executed_mfma_flops_fraction_of_peak"] = fx / (1e-3 * res["ms_per_step"]) / (peak * 1e12)
+                res["roofline_hbm"] = [dict(family=k, **{kk: v[kk] for kk in ("ms_per_step", "algorithmic_mb_per_step",
+                                                                              "achieved_gbs", "frac_of_hbm_peak")})
+                                       for k, v in kern.items() if "achieved_gbs" in v and "achieved_tflops" not in v]
+        if parity is not None:
+            res["parity_mode"] = parity
         if world == 1 and not args.no_cpu_baseline:
             try:
                 ncpu = len(os.sched_getaffinity(0))
             except AttributeError:
                 ncpu = os.cpu_count() or 1
-            res["cpu_baseline"] = cpu_baseline(frames_np, max(1, min(ncpu, 16)))   # a 1-GPU box's CPU share is 16
+            res["cpu_baseline"] = cpu_baseline(frames_np, cls, T, max(1, min(ncpu, 16)))   # a 1-GPU box's CPU share is 16
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

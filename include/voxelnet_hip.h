@@ -352,6 +352,23 @@ size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K);
 typedef struct vnNet vnNet;
 int vn_net_create(vnNet **out);
 int vn_net_destroy(vnNet *net);
+/* Optional per-launch timing of the executor (bench.py's live roofline measurement, taken on the SAME native path it
+ * times): after vn_net_timing_begin every launch of vn_net_prepare / vn_net_forward / vn_net_backward on this context
+ * is bracketed by two HIP timing events on the stream the kernel is launched on; vn_net_timing_read stops the timing,
+ * waits for the events and returns one record per launch in issue order (*count = launches recorded; at most `cap`
+ * are written).  flops / bytes are the ALGORITHMIC work of the launch (2 x MACs of the layer definition
+ * for forward, data gradient and weight gradient alike; tensor bytes read + written once), 0 where not defined. */
+enum { VN_T_CONV_FWD = 0, VN_T_CONV_DGRAD = 1, VN_T_WGRAD = 2, VN_T_BN_APPLY = 3, VN_T_BN_BWD_REDUCE = 4,
+       VN_T_BN_BWD_APPLY = 5, VN_T_BN_FINALIZE = 6, VN_T_UNPACK = 7, VN_T_PACK = 8, VN_T_FIRST = 9, VN_T_MISC = 10 };
+typedef struct {
+    int32_t kind;    /* VN_T_* */
+    int32_t layer;   /* execution-order index 0..22, 23 = heads, -1 = all layers */
+    float ms;        /* event-to-event duration of the launch */
+    float reserved;
+    double flops, bytes;
+} vnTimingRecord;
+int vn_net_timing_begin(vnNet *net, int32_t max_records);
+int vn_net_timing_read(vnNet *net, vnTimingRecord *out, int32_t cap, int32_t *count);
 /* Make `stream` wait until parameter group `bucket` (0: heads+deconv3+block3, 1: deconv2+block2+deconv1, 2: block1,
  * 3: middle_layer) of the most recent vn_net_backward issued with cfg->bucket_events has its final gradients. */
 int vn_net_wait_bucket(vnNet *net, int32_t bucket, vnStream stream);

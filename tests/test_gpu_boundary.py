@@ -126,7 +126,7 @@ def test_gradient_accumulation_and_zero_grad_in_place(golden):
         want = singles[0][k] + singles[1][k]
         assert torch.allclose(p.grad, want, rtol=1e-5, atol=1e-6 * float(want.abs().max()) + 1e-12), k
     for p in m.parameters():
-        p.grad.detach_().zero_()                # == optimizer.zero_grad(set_to_none=False)
+        p.grad.zero_()                          # == optimizer.zero_grad(set_to_none=False)
     run(m, ups[0])
     for k, p in m.named_parameters():
         assert torch.allclose(p.grad, singles[0][k], rtol=1e-5, atol=1e-6 * float(singles[0][k].abs().max()) + 1e-12), k

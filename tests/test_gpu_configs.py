@@ -1,0 +1,194 @@
+"""GPU: BASELINE.json configs[2] (Pedestrian / Cyclist grid 10 x 200 x 240, T = 45, batch 2) and configs[4] (dense
+scene: ~300k points / frame, 40k voxels, T = 64, batch 4) on the HIP path at their REAL sizes.
+
+  ped   /root/reference/voxelnet/model.py:220-227 (stride-1 block1: 200 x 240 maps at 128 channels), config.py:61-92
+        fp32 parity mode: RPN maps vs the CPU oracle on the same voxel buffers, <= 1e-3 of the map maximum
+        (BASELINE.json north_star); bf16 (the benchmarked mode): a full forward + backward step, finite and
+        bit-reproducible.
+  dense /root/reference/voxelnet/utils.py:63-88 (no cap on K; T = 64), model.py:91-100
+        voxelizer bit-exact vs the oracle on one 300k-point frame (tests/test_gpu_voxelize.py), here: both VFE layers +
+        voxel max at the full K = 160k, T = 64 vs a float64 oracle (1e-4), then one whole bf16 train step at batch 4
+        (finite loss and gradients) with the peak device memory reported."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import torch_ref as tr
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+BN_EPS = 1e-5
+
+
+def rel_err(a, b):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp(min=1e-12))
+
+
+def voxelize_frames(frames, grid):
+    from voxelnet_amd.voxelize import voxelize_device
+    feats, coords = [], []
+    for b, f in enumerate(frames):
+        fb, cb, _ = voxelize_device(torch.from_numpy(f).to(DEV), grid, b, coord_cols=4)
+        feats.append(fb)
+        coords.append(cb)
+    return feats, coords
+
+
+def test_ped_full_size_fp32_maps_and_bf16_step():
+    from voxelnet_amd import model as M
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import grid_config
+    grid = grid_config("Pedestrian")
+    assert grid.dims == (10, 200, 240) and grid.T == 45 and grid.block1_stride == 1
+    frames = synth.workload_frames(3, batch=2)                    # BASELINE configs[2]
+    feats, coords = voxelize_frames(frames, grid)
+    assert feats[0].shape[1:] == (45, 7)
+    # --- oracle: the reference op sequence on this box's CPU (fp32), same voxel buffers, train-mode BatchNorm
+    sd = tr.make_state_dict("Pedestrian")
+    with torch.no_grad():
+        dense = tr.feature_net([f.cpu() for f in feats], [c.cpu() for c in coords], dict(sd), grid.dims, True)
+        rp, rr = tr.middle_rpn(dense, dict(sd), "Pedestrian", True)
+    assert rp.shape == (2, 2, 200, 240) and rr.shape == (2, 14, 200, 240)      # model.py:220-227: block1 keeps 200 x 240
+    M.set_precision("fp32")
+    m = M.RPN3D("Pedestrian")
+    m.load_state_dict(tr.make_state_dict("Pedestrian"))
+    m = m.to(DEV).train()
+    with torch.no_grad():
+        prob, reg = m.detect(feats, coords)
+    ep, er = rel_err(prob, rp), rel_err(reg, rr)
+    print(f"ped full size, fp32 mode vs CPU oracle: prob {ep:.2e}, reg {er:.2e}")
+    assert ep < 1e-3 and er < 1e-3, (ep, er)
+    # --- bf16: forward + backward of the whole net, twice: finite and bit-identical
+    M.set_precision("bf16")
+    m = M.RPN3D("Pedestrian")
+    m.load_state_dict(tr.make_state_dict("Pedestrian"))
+    m = m.to(DEV).train()
+    rng = np.random.default_rng(3300)
+    dp = torch.from_numpy((rng.standard_normal((2, 2, 200, 240)) * 1e-3).astype(np.float32)).to(DEV)
+    dr = torch.from_numpy((rng.standard_normal((2, 14, 200, 240)) * 1e-3).astype(np.float32)).to(DEV)
+    runs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        prob, reg = m.detect(feats, coords)
+        torch.autograd.backward([prob, reg], [dp, dr])
+        torch.cuda.synchronize()
+        runs.append((prob.detach().clone(), reg.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    assert torch.isfinite(runs[0][0]).all() and torch.isfinite(runs[0][1]).all()
+    assert all(torch.isfinite(g).all() for g in runs[0][2])
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
+    eb = rel_err(runs[0][0], rp), rel_err(runs[0][1], rr)
+    print(f"ped full size, bf16 mode vs CPU oracle: prob {eb[0]:.2e}, reg {eb[1]:.2e} (reported; bars: test_gpu_bf16_parity.py)")
+    assert eb[0] < 0.25 and eb[1] < 0.25
+    M.set_precision("bf16")
+
+
+def vfe_oracle_float64(feature, sd, chunk=4096):
+    """model.py:93-100 (both VFELayers, model.py:74-82, and the voxel max) in float64, evaluated in three passes over
+    chunks of voxels so that the (K,T,128) intermediates of K = 160k, T = 64 never exist at once (train-mode BatchNorm:
+    batch statistics over all K*T rows, padded slots included)."""
+    W1, b1 = sd["feature_net.vfe_1.fcn.0.weight"].double(), sd["feature_net.vfe_1.fcn.0.bias"].double()
+    g1, be1 = sd["feature_net.vfe_1.bn.weight"].double(), sd["feature_net.vfe_1.bn.bias"].double()
+    W2, b2 = sd["feature_net.vfe_2.fcn.0.weight"].double(), sd["feature_net.vfe_2.fcn.0.bias"].double()
+    g2, be2 = sd["feature_net.vfe_2.bn.weight"].double(), sd["feature_net.vfe_2.bn.bias"].double()
+    K, T = feature.shape[0], feature.shape[1]
+    n = float(K * T)
+
+    def chunks():
+        for i in range(0, K, chunk):
+            x = feature[i:i + chunk].double()
+            yield i, x, (x.max(dim=2, keepdim=True)[0] != 0).double()         # model.py:95-96
+
+    def layer(h, mean, var, g, be, mask):
+        p = (h - mean) / torch.sqrt(var + BN_EPS) * g + be
+        agg = p.max(dim=1, keepdim=True)[0]
+        return torch.cat([p, agg.expand(-1, T, -1)], dim=2) * mask
+
+    s1 = torch.zeros(16, dtype=torch.float64); q1 = torch.zeros(16, dtype=torch.float64)
+    for _, x, _m in chunks():
+        h = F.relu(x @ W1.t() + b1)
+        s1 += h.sum(dim=(0, 1)); q1 += (h * h).sum(dim=(0, 1))
+    m1, v1 = s1 / n, q1 / n - (s1 / n) ** 2
+    s2 = torch.zeros(64, dtype=torch.float64); q2 = torch.zeros(64, dtype=torch.float64)
+    for _, x, mk in chunks():
+        o1 = layer(F.relu(x @ W1.t() + b1), m1, v1, g1, be1, mk)
+        h = F.relu(o1 @ W2.t() + b2)
+        s2 += h.sum(dim=(0, 1)); q2 += (h * h).sum(dim=(0, 1))
+    m2, v2 = s2 / n, q2 / n - (s2 / n) ** 2
+    out = torch.empty((K, 128), dtype=torch.float64)
+    for i, x, mk in chunks():
+        o1 = layer(F.relu(x @ W1.t() + b1), m1, v1, g1, be1, mk)
+        o2 = layer(F.relu(o1 @ W2.t() + b2), m2, v2, g2, be2, mk)
+        out[i:i + x.shape[0]] = o2.max(dim=1)[0]                               # model.py:100
+    return out, (m1, v1, m2, v2)
+
+
+def test_vfe_oracle_float64_chunked_equals_the_pinned_oracle():
+    """the chunked float64 evaluation above == oracle/torch_ref.voxel_features (which tests/test_oracle_model.py pins to
+    the imported reference) on a small input"""
+    rng = np.random.default_rng(17)
+    K, T = 300, 9
+    x = torch.from_numpy(rng.standard_normal((K, T, 7)).astype(np.float32))
+    npts = rng.integers(1, T + 1, size=K)
+    x = x * torch.from_numpy((np.arange(T)[None, :] < npts[:, None])[..., None])
+    sd = tr.make_state_dict("Car")
+    sd64 = {k: (v.double().clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    ref = tr.voxel_features(x.double(), sd64, True)
+    got, _ = vfe_oracle_float64(x, sd, chunk=64)
+    assert float((got - ref).abs().max()) < 1e-10
+
+
+def test_dense_config_vfe_full_K_and_train_step():
+    from voxelnet_amd import model as M
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import GRADIENT_CLIP, LR, grid_config
+    from voxelnet_amd.optim import ClipSGD
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    grid = grid_config("Car", T=64)
+    frames = synth.workload_frames(5, batch=4)                    # BASELINE configs[4]: ~300k points, K0 = 40k, T = 64
+    assert all(250000 < f.shape[0] < 400000 for f in frames)
+    feats, coords = voxelize_frames(frames, grid)
+    K = sum(f.shape[0] for f in feats)
+    assert all(f.shape[0] <= 40000 and f.shape[1:] == (64, 7) for f in feats) and K > 150000
+    sd = tr.make_state_dict("Car")
+    # --- VFE x2 + voxel max at the full K against float64
+    M.set_precision("bf16")
+    m = M.RPN3D("Car")
+    m.load_state_dict(tr.make_state_dict("Car"))
+    m = m.to(DEV).train()
+    feature = torch.cat(feats)
+    fn = m.feature_net
+    vw, _stats, _h = M.featnet_forward(feature, [p.detach() for p in M._vfe_weights(fn)], fn._bufs(), True)
+    ref, (m1, v1, m2, v2) = vfe_oracle_float64(feature.cpu(), sd)
+    e = rel_err(vw, ref)
+    print(f"dense config: K = {K}, T = 64, voxel features vs float64 oracle {e:.2e}")
+    assert e < 1e-4
+    n = float(K * 64)
+    assert rel_err(fn.vfe_2.bn.running_mean, 0.1 * m2) < 1e-4
+    assert rel_err(fn.vfe_2.bn.running_var, 0.9 + 0.1 * v2 * n / (n - 1)) < 1e-4
+    # --- one whole train step at batch 4 (voxel buffers -> loss -> backward -> clip + SGD), bf16
+    m.load_state_dict(tr.make_state_dict("Car"))
+    h, w = m.rpn_output_shape
+    rng = np.random.default_rng(5500)
+    pos = (rng.random((4, h, w, 2)) < 0.002).astype(np.float32)
+    neg = ((rng.random((4, h, w, 2)) < 0.98) & (pos == 0)).astype(np.float32)
+    tgt = (rng.standard_normal((4, h, w, 14)) * 0.1).astype(np.float32)
+    opt = ClipSGD(list(m.parameters()), LR, GRADIENT_CLIP)
+    before = [p.detach().clone() for p in m.parameters()]
+    out = m((None, None, feats, None, coords, None, None), DEV, targets=tuple(torch.from_numpy(a).to(DEV) for a in (pos, neg, tgt)))
+    assert out[0].shape == (4, 2, 200, 176)
+    out[2].backward()
+    norm = opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out[2]).item() and torch.isfinite(norm).item() and float(norm) > 0
+    assert all(torch.isfinite(p).all() for p in m.parameters())
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, m.parameters()))
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print(f"dense config: one bf16 train step at batch 4, loss {float(out[2]):.4f}, |g| {float(norm):.3f}, "
+          f"peak device memory {peak:.1f} GiB")
+    assert peak < 48.0

@@ -295,6 +295,33 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
 }
 
 #define RT(call) do { int rc_ = (call); if (rc_ != VN_OK) return rc_; } while (0)
+// a launch of the executor, bracketed by timing events on ITS stream when the context is in timing mode
+#define RTT(kind, layer, flops, bytes, st, call) do {                                                           \
+        vnTimeSlot *ts_ = nullptr;                                                                              \
+        if (net->timing && !(ts_ = net->time_begin((kind), (layer), (double)(flops), (double)(bytes), vn_stream(st)))) \
+            return VN_EINVAL;                                                                                   \
+        RT(call);                                                                                               \
+        if (ts_) VN_HIP(hipEventRecord(ts_->e1, vn_stream(st)));                                                \
+    } while (0)
+
+enum { T_CONV_FWD = VN_T_CONV_FWD, T_CONV_DGRAD = VN_T_CONV_DGRAD, T_WGRAD = VN_T_WGRAD, T_BN_APPLY = VN_T_BN_APPLY,
+       T_BN_BWD_REDUCE = VN_T_BN_BWD_REDUCE, T_BN_BWD_APPLY = VN_T_BN_BWD_APPLY, T_BN_FINALIZE = VN_T_BN_FINALIZE,
+       T_UNPACK = VN_T_UNPACK, T_PACK = VN_T_PACK, T_FIRST = VN_T_FIRST, T_MISC = VN_T_MISC };
+
+// Algorithmic work of a layer: 2 x MACs of the reference's layer definition; the data gradient and the
+// weight gradient of a layer count the same FLOPs as its forward.  rows = output sites (input sites for a deconv).
+double layer_flops(const Spec &sp, const int in_dims[3], const int odims[3], int B) {
+    const int *d = sp.transposed ? in_dims : odims;
+    return 2.0 * B * d[0] * d[1] * d[2] * (double)sp.cin * sp.cout * sp.k[0] * sp.k[1] * sp.k[2];
+}
+double rows_bytes(const Rows &r) { return (double)r.M() * r.C * (r.dtype == VN_F32 ? 4 : 2); }
+// algorithmic bytes of the gradient unpack: every weight gradient read once and written once (the row-chunk partials it
+// also sums are an implementation artefact: not counted)
+double unpack_bytes(const vnUnpackJob *j, int n) {
+    double b = 0.0;
+    for (int i = 0; i < n; ++i) b += 8.0 * j[i].c_out * j[i].c_in * j[i].taps;
+    return b;
+}
 
 }  // namespace
 
@@ -306,11 +333,34 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
 //   ring: timing-less events for the fork / join of the side stream (re-recording an event that an earlier
 //     hipStreamWaitEvent has consumed is well defined: the wait captured the record that preceded it).
 // Calls that share a context must not run concurrently on the host (they never do: one step = one thread).
+//   timing (vn_net_timing_begin / _read): optional HIP-event pairs around every launch of the executor, on the stream
+//     the kernel is launched on — bench.py's live per-kernel measurement of the SAME native path it times.
+struct vnTimeSlot {
+    hipEvent_t e0, e1;
+    int32_t kind, layer;
+    double flops, bytes;
+};
 struct vnNet {
     hipEvent_t bucket_ev[4][2];
     hipEvent_t ring[64];
     unsigned next;
     hipEvent_t next_event() { return ring[next++ & 63]; }
+    bool timing;
+    int32_t t_cap, t_made, t_used;
+    vnTimeSlot *slots;
+    // start of a timed launch: the slot whose e1 the caller records after the launch, or NULL (table full / HIP error)
+    vnTimeSlot *time_begin(int kind, int layer, double flops, double bytes, hipStream_t st) {
+        if (t_used >= t_cap) return nullptr;
+        vnTimeSlot &t = slots[t_used];
+        if (t_used >= t_made) {
+            if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess) return nullptr;
+            t_made = t_used + 1;
+        }
+        t.kind = kind; t.layer = layer; t.flops = flops; t.bytes = bytes;
+        if (hipEventRecord(t.e0, st) != hipSuccess) return nullptr;
+        ++t_used;
+        return &t;
+    }
 };
 
 extern "C" int vn_net_create(vnNet **out) {
@@ -338,7 +388,48 @@ extern "C" int vn_net_destroy(vnNet *n) {
             if (n->bucket_ev[b][w]) (void)hipEventDestroy(n->bucket_ev[b][w]);
     for (int i = 0; i < 64; ++i)
         if (n->ring[i]) (void)hipEventDestroy(n->ring[i]);
+    for (int i = 0; i < n->t_made; ++i) {
+        (void)hipEventDestroy(n->slots[i].e0);
+        (void)hipEventDestroy(n->slots[i].e1);
+    }
+    delete[] n->slots;
     delete n;
+    return VN_OK;
+}
+
+// From now on every launch of vn_net_prepare / vn_net_forward / vn_net_backward on this context is bracketed by two
+// timing events on its stream, up to max_records launches (further calls fail with VN_EINVAL rather than drop records).
+extern "C" int vn_net_timing_begin(vnNet *n, int32_t max_records) {
+    VN_CHECK_ARG(n && max_records > 0 && max_records <= (1 << 20));
+    if (max_records > n->t_cap) {
+        vnTimeSlot *s = new (std::nothrow) vnTimeSlot[max_records];
+        if (!s) return VN_EINVAL;
+        memset(s, 0, sizeof(vnTimeSlot) * (size_t)max_records);
+        if (n->slots) memcpy(s, n->slots, sizeof(vnTimeSlot) * (size_t)n->t_made);
+        delete[] n->slots;
+        n->slots = s;
+        n->t_cap = max_records;
+    }
+    n->t_used = 0;
+    n->timing = true;
+    return VN_OK;
+}
+
+// Stops the timing, waits for the recorded events (the caller has queued nothing behind them that could deadlock) and
+// returns one record per launch in issue order: duration in milliseconds between the two events of the launch.
+extern "C" int vn_net_timing_read(vnNet *n, vnTimingRecord *out, int32_t cap, int32_t *count) {
+    VN_CHECK_ARG(n && count && (out || cap == 0));
+    n->timing = false;
+    const int m = n->t_used < cap ? n->t_used : cap;
+    for (int i = 0; i < m; ++i) {
+        vnTimeSlot &t = n->slots[i];
+        VN_HIP(hipEventSynchronize(t.e1));
+        float ms = 0.f;
+        VN_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
+        out[i] = vnTimingRecord{t.kind, t.layer, ms, 0.f, t.flops, t.bytes};
+    }
+    *count = n->t_used;
+    n->t_used = 0;
     return VN_OK;
 }
 
@@ -371,7 +462,7 @@ extern "C" size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K) {
 // orientations) and, for the sparse first layer, the active-site list, the voxel index grid and the bias fill of its
 // output.  vn_net_forward does it itself unless cfg->prepared says vn_net_prepare already did (on another stream,
 // beside the VFE forward).
-static int net_prepare(const vnNetConfig *cfg, const Plan &P, const vnLayerParams *L, const float *heads_w,
+static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const vnLayerParams *L, const float *heads_w,
                        const int64_t *coord, int64_t K, vnStream stream) {
     const int training = cfg->training;
     {   // every layer's weights -> MFMA operand layout, forward and (training) data-gradient orientation: one launch
@@ -389,16 +480,19 @@ static int net_prepare(const vnNetConfig *cfg, const Plan &P, const vnLayerParam
         }
         jobs[nj++] = vnPackJob{heads_w, P.hwp_f, 16, 768, 1, 0, 0, 1, P.adt, 0};
         if (training) jobs[nj++] = vnPackJob{heads_w, P.hwp_d, 16, 768, 1, 1, 0, 1, P.adt, 0};
-        RT(vn_pack_weights_batch(jobs, nj, stream));
+        double pbytes = 0.0;
+        for (int j = 0; j < nj; ++j) pbytes += (double)jobs[j].c_out * jobs[j].c_in * jobs[j].taps * (4 + P.esz);
+        RTT(T_PACK, -1, 0.0, pbytes, stream, vn_pack_weights_batch(jobs, nj, stream));
     }
     if (cfg->sparse_first) {
         const Spec &sp = P.spec[0];
         const Rows &y = P.y[0];
         const Rows xin = dense_rows(nullptr, P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
         vnConv g = fwd_geom(sp, xin, P.odims[0], y);
-        RT(vn_fill_rows(y.ptr, (vnDtype)y.dtype, y.M(), sp.cout, sp.cout, L[0].bias, stream));
-        RT(vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
-        RT(vn_voxel_index_grid(coord, K, cfg->B, cfg->D, cfg->H, cfg->W, P.igrid, stream));
+        RTT(T_FIRST, 0, 0.0, rows_bytes(y), stream, vn_fill_rows(y.ptr, (vnDtype)y.dtype, y.M(), sp.cout, sp.cout, L[0].bias, stream));
+        RTT(T_FIRST, 0, 0.0, 0.0, stream, vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
+        RTT(T_FIRST, 0, 0.0, 4.0 * cfg->B * cfg->D * cfg->H * cfg->W, stream,
+            vn_voxel_index_grid(coord, K, cfg->B, cfg->D, cfg->H, cfg->W, P.igrid, stream));
     }
     return VN_OK;
 }
@@ -409,7 +503,7 @@ extern "C" int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerP
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
     if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
-    return net_prepare(cfg, P, L, heads_w, coord, K, stream);
+    return net_prepare(net, cfg, P, L, heads_w, coord, K, stream);
 }
 
 extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w,
@@ -425,7 +519,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
     const int training = cfg->training;
     const float mom = 0.1f, eps = 1e-5f;
     // (no memset: every statistics buffer of the forward is a per-workgroup slab written with plain stores)
-    if (!cfg->prepared) RT(net_prepare(cfg, P, L, heads_w, coord, K, stream));
+    if (!cfg->prepared) RT(net_prepare(net, cfg, P, L, heads_w, coord, K, stream));
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
     Rows x1{}, x2{};
     // deconv1 / deconv2 only feed the concat: with a side stream they run beside block2 / block3 (whose 100x88 and
@@ -462,16 +556,20 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
                 q.divD = q.divH = q.divW = 1;
                 q.src_sB = q.src_sD = q.src_sH = K * sp.cin; q.src_sW = sp.cin;
                 q.out_sB = q.out_sD = q.out_sH = K * q.Cr; q.out_sW = q.Cr;
-                RT(vn_conv_gather_gemm(vw_rows, P.wp_f[l], nullptr, P.rbP, VN_F32, &q, 0, nullptr, stream));
+                RTT(T_CONV_FWD, l, 2.0 * K * sp.cin * 27.0 * sp.cout, (double)K * (sp.cin * P.esz + 27.0 * sp.cout * 4), stream,
+                    vn_conv_gather_gemm(vw_rows, P.wp_f[l], nullptr, P.rbP, VN_F32, &q, 0, nullptr, stream));
             }
-            RT(vn_rulebook_combine(P.rbP, P.igrid, P.alist, P.acap, P.acount, &g, L[l].bias, y.ptr, (vnDtype)y.dtype, slab,
-                                   stream));
+            RTT(T_FIRST, l, 0.0, 0.0, stream,
+                vn_rulebook_combine(P.rbP, P.igrid, P.alist, P.acap, P.acount, &g, L[l].bias, y.ptr, (vnDtype)y.dtype, slab,
+                                    stream));
         } else {
-            RT(vn_conv_gather_gemm(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, &g, 0, slab, stream));
+            RTT(T_CONV_FWD, l, layer_flops(sp, P.in_dims[l], P.odims[l], cfg->B), rows_bytes(x) + rows_bytes(y), stream,
+                vn_conv_gather_gemm(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, &g, 0, slab, stream));
         }
         if (slab) {
-            RT(vn_bn_finalize_slab(slab, P.slab_rows[l], M, sp.cout, L[l].bias, L[l].gamma, L[l].beta, L[l].running_mean,
-                                   L[l].running_var, mom, eps, P.stats[l], stream));
+            RTT(T_BN_FINALIZE, l, 0.0, 8.0 * P.slab_rows[l] * sp.cout, stream,
+                vn_bn_finalize_slab(slab, P.slab_rows[l], M, sp.cout, L[l].bias, L[l].gamma, L[l].beta, L[l].running_mean,
+                                    L[l].running_var, mom, eps, P.stats[l], stream));
         } else {
             if (training)
                 RT(vn_bn_stats(y.ptr, (vnDtype)y.dtype, M, sp.cout, y.sW, 1, L[l].bias, P.fsums[l], stream));
@@ -480,10 +578,11 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
         }
         const Rows &a = P.a[l];
         if (l == L_M2) {   // BEV fold: channel d*64 + c of the (B,1,H,W,128) activation
-            RT(vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], 1, a.ptr,
-                               (vnDtype)a.dtype, 128, stream));
+            RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream,
+                vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], 1, a.ptr,
+                                (vnDtype)a.dtype, 128, stream));
         } else {
-            RT(bn_apply_rows(y, P.stats[l], a, sp.cout, stream));
+            RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream, bn_apply_rows(y, P.stats[l], a, sp.cout, stream));
         }
         if (!sp.transposed) x = a;
         if (l == L_D1 - 1) x1 = a;
@@ -500,9 +599,11 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
         const int od[3] = {1, P.hf, P.wf};
         vnConv g = fwd_geom(hs16, P.cat, od, P.hy);
-        RT(vn_conv_gather_gemm(P.cat.ptr, P.hwp_f, heads_b, P.hy.ptr, VN_F32, &g, 0, nullptr, stream));
         const int64_t S = (int64_t)P.hf * P.wf;
-        RT(vn_heads_to_nchw(reinterpret_cast<const float *>(P.hy.ptr), cfg->B, S, prob, reg, stream));
+        RTT(T_CONV_FWD, NL, 2.0 * cfg->B * S * 768 * 16, rows_bytes(P.cat) + rows_bytes(P.hy), stream,
+            vn_conv_gather_gemm(P.cat.ptr, P.hwp_f, heads_b, P.hy.ptr, VN_F32, &g, 0, nullptr, stream));
+        RTT(T_MISC, NL, 0.0, 2.0 * rows_bytes(P.hy), stream,
+            vn_heads_to_nchw(reinterpret_cast<const float *>(P.hy.ptr), cfg->B, S, prob, reg, stream));
     }
     return VN_OK;
 }
@@ -546,8 +647,9 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // ---- heads
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
-        RT(vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows.ptr, (vnDtype)P.adt, 16, 0, stream));
-        RT(vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, stream));
+        RTT(T_MISC, NL, 0.0, 0.0, stream, vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows.ptr, (vnDtype)P.adt, 16, 0, stream));
+        RTT(T_MISC, NL, 0.0, 0.0, stream,
+            vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, stream));
         const int od[3] = {1, P.hf, P.wf};
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
@@ -556,10 +658,12 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
         // the heads' weight gradient goes to the side stream behind ONE fork that also serves the early deconv
         // branches (which need the data gradient): one event record less on the main stream (483 vs 480 pc/s)
-        RT(vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.pdt, &gd, 0, nullptr, stream));
+        RTT(T_CONV_DGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.d_cat), stream,
+            vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.pdt, &gd, 0, nullptr, stream));
         RT(fork());
         heads_forked = true;
-        RT(vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, &gw, 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
+        RTT(T_WGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.cat), wstream,
+            vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, &gw, 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
         unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
     }
     auto cat_slice = [&](int off) {
@@ -593,17 +697,20 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
-            RT(vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+            RTT(T_WGRAD, l, 2.0 * K * sp.cin * 27.0 * C, 0.0, wstream,
+                vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
             return VN_OK;
         }
         const Rows x = input_of(l);
         const vnConv gw = wgrad_geom(P, l, x);
         if (sp.transposed) {
-            RT(vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+            RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(x) + rows_bytes(dy), wstream,
+                vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, wch, dw_elems};
         } else {
-            RT(vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+            RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(x) + rows_bytes(dy), wstream,
+                vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, wch, dw_elems};
         }
         return VN_OK;
@@ -648,24 +755,31 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         const Rows &dy = P.dy[l];
         if (l == L_M2) {   // da is the BEV gradient (B,1,H,W,128): channel d*64+c
             const int64_t hw = (int64_t)P.odims[l][1] * P.odims[l][2];
-            RT(vn_bn_bwd_reduce_slab_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], 1,
-                                         P.bslab[l], ls));
-            RT(vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
-                                       G[l].beta, ls));
-            RT(vn_bn_bwd_apply_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], P.coef[l], 1,
-                                   dy.ptr, (vnDtype)dy.dtype, ls));
+            RTT(T_BN_BWD_REDUCE, l, 0.0, 2.0 * rows_bytes(y), ls,
+                vn_bn_bwd_reduce_slab_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], 1,
+                                          P.bslab[l], ls));
+            RTT(T_BN_FINALIZE, l, 0.0, 8.0 * P.bslab_rows[l] * C, ls,
+                vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
+                                        G[l].beta, ls));
+            RTT(T_BN_BWD_APPLY, l, 0.0, 3.0 * rows_bytes(y), ls,
+                vn_bn_bwd_apply_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], P.coef[l], 1,
+                                    dy.ptr, (vnDtype)dy.dtype, ls));
         } else {
-            RT(vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
-                                     P.bslab[l], ls));
-            RT(vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
-                                       G[l].beta, ls));
+            RTT(T_BN_BWD_REDUCE, l, 0.0, 2.0 * rows_bytes(y), ls,
+                vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
+                                      P.bslab[l], ls));
+            RTT(T_BN_FINALIZE, l, 0.0, 8.0 * P.bslab_rows[l] * C, ls,
+                vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
+                                        G[l].beta, ls));
             if (l == 0 && cfg->sparse_first)   // dy is only gathered at the active sites (flags: the forward's vn_active_sites)
-                RT(vn_bn_bwd_apply_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
-                                           P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW,
-                                           static_cast<const uint8_t *>(P.aws), ls));
+                RTT(T_BN_BWD_APPLY, l, 0.0, 0.0, ls,     // (bytes depend on the number of active sites, known on the device only)
+                    vn_bn_bwd_apply_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
+                                            P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW,
+                                            static_cast<const uint8_t *>(P.aws), ls));
             else
-                RT(vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
-                                   P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, ls));
+                RTT(T_BN_BWD_APPLY, l, 0.0, 3.0 * rows_bytes(y), ls,
+                    vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
+                                    P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, ls));
         }
         zj.ptr[zj.n] = G[l].bias; zj.len[zj.n] = C; ++zj.n;          // bias before a train-mode BN: gradient exactly 0
         const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
@@ -676,8 +790,8 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
-            RT(vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr,
-                                        ls));
+            RTT(T_CONV_DGRAD, l, 2.0 * K * sp.cin * 27.0 * C, 0.0, ls,
+                vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr, ls));
             return VN_OK;
         }
         // data gradient
@@ -689,8 +803,8 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         const int64_t os[4] = {dx.sB, dx.sD, dx.sH, dx.sW};
         vnConv gd = sp.transposed ? geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, os)
                                   : geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, os);
-        RT(vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr,
-                               ls));
+        RTT(T_CONV_DGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(dy) + rows_bytes(dx), ls,
+            vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr, ls));
         return VN_OK;
     };
     // Single-call backward with a side stream: deconv2 / deconv1 only depend on the heads' data gradient, so their
@@ -719,7 +833,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     auto bucket_done = [&](int b) -> int {
         RT(flush());
         if (b == 3 && m0_on_main) RT(fork());     // the first layer's partials come from the main stream
-        RT(vn_unpack_wgrads_batch(unpack + u_done, nu - u_done, wstream));
+        RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack + u_done, nu - u_done), wstream, vn_unpack_wgrads_batch(unpack + u_done, nu - u_done, wstream));
         u_done = nu;
         if (zj.n > z_done) {   // (bias gradients in front of a train-mode BatchNorm: zero; off the main chain)
             ZeroJobs part{};
@@ -748,7 +862,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             // measure nothing: 470) and after each Conv3d
             if ((l >= L_B1 && l < L_D1) || l == L_B2 || l == L_B3 || l <= L_M2) RT(flush());
             if (l == L_B1 && tail_balance && early_unpack_on) {
-                RT(vn_unpack_wgrads_batch(unpack, nu, wstream));
+                RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack, nu), wstream, vn_unpack_wgrads_batch(unpack, nu, wstream));
                 u_early = nu;
             }
         }
@@ -764,7 +878,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     if (ws != hs && cfg->defer_join && seg_end == NL + 1) {
         // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream
         if (m0_on_main) RT(fork());     // the first layer's partials come from the main stream
-        RT(vn_unpack_wgrads_batch(unpack + u_early, nu - u_early, wstream));
+        RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack + u_early, nu - u_early), wstream, vn_unpack_wgrads_batch(unpack + u_early, nu - u_early, wstream));
         if (zj.n > 0) {
             k_zero_many<<<zj.n, 256, 0, ws>>>(zj);
             VN_LAUNCH_STATUS();
@@ -777,7 +891,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         VN_HIP(hipEventRecord(e, ws));
         VN_HIP(hipStreamWaitEvent(hs, e, 0));
     }
-    RT(vn_unpack_wgrads_batch(unpack, nu, stream));
+    RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack, nu), stream, vn_unpack_wgrads_batch(unpack, nu, stream));
     if (zj.n > 0) {
         k_zero_many<<<zj.n, 256, 0, hs>>>(zj);
         VN_LAUNCH_STATUS();

@@ -47,6 +47,11 @@ class VnNetConfig(ctypes.Structure):
     _fields_ = [(n, c_i32) for n in ("B", "D", "H", "W", "block1_stride", "mode", "training", "sparse_first", "prepared", "bucket_events", "defer_join")]
 
 
+class VnTimingRecord(ctypes.Structure):
+    _fields_ = [("kind", c_i32), ("layer", c_i32), ("ms", c_f32), ("reserved", c_f32), ("flops", ctypes.c_double),
+                ("bytes", ctypes.c_double)]
+
+
 class VnLayerParams(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in ("weight", "bias", "gamma", "beta", "running_mean", "running_var")]
 
@@ -101,6 +106,8 @@ SIGNATURES = {
     "vn_net_workspace_bytes": (c_sz, [_P(VnNetConfig), c_i64]),
     "vn_net_create": (c_i32, [_P(c_vp)]),
     "vn_net_destroy": (c_i32, [c_vp]),
+    "vn_net_timing_begin": (c_i32, [c_vp, c_i32]),
+    "vn_net_timing_read": (c_i32, [c_vp, c_vp, c_i32, _P(c_i32)]),
     "vn_net_forward": (c_i32, [c_vp, _P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
                                c_vp, c_vp, c_vp]),
     "vn_net_wait_bucket": (c_i32, [c_vp, c_i32, c_vp]),

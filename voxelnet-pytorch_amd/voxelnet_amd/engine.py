@@ -186,7 +186,14 @@ class KernelTimer:
         return out
 
 
-TIMER = None   # set to a KernelTimer by bench.py
+TIMER = None   # set to a KernelTimer by bench.py (per-launch Python orchestration only)
+SECTIONS = None   # set to a KernelTimer by bench.py: event pairs around the launch groups the Python side issues itself
+#                   (voxelizer, VFE forward / backward, loss, optimizer) with their algorithmic HBM bytes
+
+
+def section(name, nbytes):
+    """bench.py's live measurement of the HBM-bound launch groups outside the native executor"""
+    return SECTIONS.time(name, nbytes) if SECTIONS is not None else _NoCtx()
 
 
 class _NoCtx:

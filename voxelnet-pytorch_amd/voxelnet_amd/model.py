@@ -252,8 +252,9 @@ def featnet_forward(feature, params, bufs, training):
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     vw = torch.empty((K, 128), dtype=torch.float32, device=dev)
     stats = torch.empty(320, dtype=torch.float32, device=dev)
-    _lib.call("vn_vfe_fwd", feature.data_ptr(), K, T, ctypes.byref(w), int(training), E.BN_MOMENTUM, E.BN_EPS,
-              vw.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws_bytes, E.stream())
+    with E.section("vfe_fwd", 28.0 * K * T + 512.0 * K):          # (K,T,7) read, (K,128) written
+        _lib.call("vn_vfe_fwd", feature.data_ptr(), K, T, ctypes.byref(w), int(training), E.BN_MOMENTUM, E.BN_EPS,
+                  vw.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws_bytes, E.stream())
     return vw, stats, (w, ws, ws_bytes)
 
 
@@ -264,8 +265,9 @@ def featnet_backward(feature, wstruct, stats, d_vw, params, out=None):
     g = _lib.VnVfeGrads(*[t.data_ptr() for t in grads])
     d_vw = d_vw.contiguous()
     # (ws is the forward's workspace, kept alive and untouched by the saved handle: its work list is reused)
-    _lib.call("vn_vfe_bwd", feature.data_ptr(), K, T, ctypes.byref(w), stats.data_ptr(), d_vw.data_ptr(),
-              ctypes.byref(g), ws.data_ptr(), ws_bytes, 1, E.stream())
+    with E.section("vfe_bwd", 2.0 * (28.0 * K * T + 512.0 * K)):
+        _lib.call("vn_vfe_bwd", feature.data_ptr(), K, T, ctypes.byref(w), stats.data_ptr(), d_vw.data_ptr(),
+                  ctypes.byref(g), ws.data_ptr(), ws_bytes, 1, E.stream())
     return grads
 
 
@@ -820,8 +822,9 @@ class _LossFn(torch.autograd.Function):
             ws_bytes = _lib.load().vn_rpn_loss_workspace_bytes(B, H, W)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=prob.device)
             out = torch.empty(5, dtype=torch.float32, device=prob.device)
-            _lib.call("vn_rpn_loss_fwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
-                      B, H, W, alpha, beta, sigma, ws.data_ptr(), ws_bytes, out.data_ptr(), E.stream())
+            with E.section("loss_fwd", 4.0 * B * H * W * 34):
+                _lib.call("vn_rpn_loss_fwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
+                          B, H, W, alpha, beta, sigma, ws.data_ptr(), ws_bytes, out.data_ptr(), E.stream())
         ctx.saved = (prob, delta, pos, neg, tgt, ws, (B, H, W, alpha, beta, sigma))
         ctx.set_materialize_grads(False)          # unused outputs arrive as None in backward, not as zero tensors
         return tuple(out[i] for i in range(5))    # five scalars (views of one buffer): loss, cls, reg, cls_pos, cls_neg
@@ -832,9 +835,10 @@ class _LossFn(torch.autograd.Function):
         gs = [None if g is None else g.contiguous().float() for g in gs]
         with torch.cuda.device(prob.device):
             d_prob, d_delta = torch.empty_like(prob), torch.empty_like(delta)
-            _lib.call("vn_rpn_loss_bwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
-                      B, H, W, alpha, beta, sigma, ws.data_ptr(), *[None if g is None else g.data_ptr() for g in gs],
-                      d_prob.data_ptr(), d_delta.data_ptr(), E.stream())
+            with E.section("loss_bwd", 4.0 * B * H * W * 50):
+                _lib.call("vn_rpn_loss_bwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
+                          B, H, W, alpha, beta, sigma, ws.data_ptr(), *[None if g is None else g.data_ptr() for g in gs],
+                          d_prob.data_ptr(), d_delta.data_ptr(), E.stream())
         return d_prob, d_delta, None, None, None, None, None, None
 
 

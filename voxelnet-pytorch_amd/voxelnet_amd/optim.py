@@ -93,6 +93,8 @@ class ClipSGD(torch.optim.Optimizer):
             self._key = key
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-            _lib.call("vn_clip_sgd", self._table.data_ptr(), self._n_chunks, self.max_norm, self.lr, int(self.scale_grads),
-                      self._ws.data_ptr(), self._ws.numel(), self._norm.data_ptr(), stream)
+            from . import engine as E
+            with E.section("clip_sgd", 16.0 * sum(p.numel() for p, _ in pairs)):      # grad read twice, param read + written
+                _lib.call("vn_clip_sgd", self._table.data_ptr(), self._n_chunks, self.max_norm, self.lr, int(self.scale_grads),
+                          self._ws.data_ptr(), self._ws.numel(), self._norm.data_ptr(), stream)
         return self._norm[0]

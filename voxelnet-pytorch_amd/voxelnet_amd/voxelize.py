@@ -113,11 +113,13 @@ def voxelize_device_async(points, grid, batch_index=0, coord_cols=4, buffers=Non
             coord = torch.empty((cap, coord_cols), dtype=torch.int64, device=dev)
             number = torch.empty((cap,), dtype=torch.int64, device=dev)
         st = _stream()
-        _lib.call("vn_voxelize_index", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes,
-                  k_dev.data_ptr(), st)
-        _lib.call("vn_voxelize_gather", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes, cap,
-                  int(batch_index), coord_cols, feature.data_ptr(), coord.data_ptr(), number.data_ptr(),
-                  k_dev.data_ptr(), st)
+        from . import engine as E
+        with E.section("voxelize", 16.0 * n):      # + 28*K*T + 40*K written, added by the caller once K is known
+            _lib.call("vn_voxelize_index", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes,
+                      k_dev.data_ptr(), st)
+            _lib.call("vn_voxelize_gather", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes, cap,
+                      int(batch_index), coord_cols, feature.data_ptr(), coord.data_ptr(), number.data_ptr(),
+                      k_dev.data_ptr(), st)
         k_host = buffers.k_host if buffers is not None else torch.empty(1, dtype=torch.int32, pin_memory=True)
         k_host.copy_(k_dev, non_blocking=True)
         ev = torch.cuda.Event()
