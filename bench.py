@@ -411,6 +411,14 @@ def main():
                               "achieved_gbs": (by + extra) / (ms * 1e-3) / 1e9,
                               "frac_of_hbm_peak": (by + extra) / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
             res["kernels"] = kern
+            if os.environ.get("VN_BENCH_LAYER_TIMES"):       # diagnostic: per (family, layer) mean duration
+                per = {}
+                for kind, layer, ms, fl, by in recs:
+                    n, t = per.get((kind, layer), (0, 0.0))
+                    per[(kind, layer)] = (n + 1, t + ms)
+                for (kind, layer), (n, t) in sorted(per.items()):
+                    print("[bench] %-18s layer %3d  x%.1f/step  %8.1f us each" % (KIND_NAMES[kind], layer, n / ns, 1e3 * t / n),
+                          file=sys.stderr)
             if fam:
                 # dominant family: the implicit-GEMM convolutions (forward + data gradient share the two kernels)
                 n = fam.get(0, (0, 0, 0, 0))[0] + fam.get(1, (0, 0, 0, 0))[0]

@@ -468,6 +468,21 @@ int vn_bn_bwd_reduce_slab_bev(const void *da, vnDtype da_dtype, int64_t wide_str
 int vn_bn_bwd_apply_bev(const void *da, vnDtype da_dtype, int64_t wide_stride, const void *y,
                         vnDtype y_dtype, int64_t M, int32_t C, int64_t hw, const float *stats,
                         const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, vnStream stream);
+/* Sparse-aware BatchNorm passes of the FIRST middle layer (model.py:207 on the ~99 % empty grid): every output site
+ * without an occupied voxel in its receptive field holds exactly the conv bias (`inactive`, float[C]); row_flags are the
+ * uint8 site flags vn_active_sites leaves at the head of its workspace.  vn_bn_apply_flagged / _reduce_slab_flagged do
+ * not read y at rows with flag 0 (same results as the dense calls); vn_bn_bwd_apply_list writes dy only at the sites of
+ * vn_active_sites' list ((b,d,h,w) int64 rows, *count valid, dense contiguous (B,D,H,W,C) tensors). */
+int vn_bn_apply_flagged(const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                        int32_t relu, void *a, vnDtype a_dtype, int64_t a_stride, const uint8_t *row_flags,
+                        const float *inactive, vnStream stream);
+int vn_bn_bwd_reduce_slab_flagged(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y,
+                                  vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                                  int32_t relu, float *slab, const uint8_t *row_flags, const float *inactive,
+                                  vnStream stream);
+int vn_bn_bwd_apply_list(const void *da, vnDtype da_dtype, const void *y, vnDtype y_dtype, int32_t C, int32_t D,
+                         int32_t H, int32_t W, const float *stats, const float *coef, int32_t relu, void *dy,
+                         vnDtype dy_dtype, const int64_t *list, const int32_t *count, int64_t cap, vnStream stream);
 /* Row-flag variant for the first middle layer: row_flags = the uint8 site flags vn_active_sites leaves at the head
  * of its workspace ((B,Dr,Hr,Wr) order, 1 = some occupied voxel in the receptive field).  Rows with flag 0 are
  * skipped: that layer's weight- and data-gradient (the row-list kernels) only gather dy at flagged sites. */

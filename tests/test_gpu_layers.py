@@ -276,3 +276,49 @@ def test_bn_bwd_apply_flagged_skips_unflagged_rows():
     f = flags.bool()
     assert torch.equal(part[f].view(torch.int16), full[f].view(torch.int16))
     assert bool((part[~f] == 5.0).all())
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+def test_first_layer_sparse_batchnorm_passes_equal_the_dense_ones(dt):
+    """vn_bn_apply_flagged / vn_bn_bwd_reduce_slab_flagged / vn_bn_bwd_apply_list (first middle layer: rows without an
+    occupied voxel in reach hold the conv bias and are not read) == the dense passes, bit for bit"""
+    from voxelnet_amd import _lib, engine as E
+    DEV = "cuda:0"
+    lib = _lib.load()
+    torch.manual_seed(9)
+    B, D, H, W, C = 2, 3, 20, 24, 64
+    M = B * D * H * W
+    vdt = _lib.VN_BF16 if dt == torch.bfloat16 else _lib.VN_F32
+    bias = torch.randn(C, device=DEV) * 0.3
+    flags = (torch.rand(M, device=DEV) < 0.15).to(torch.uint8)
+    y = (torch.randn(M, C, device=DEV) * 1.5).to(dt)
+    y[flags == 0] = bias.to(dt)                      # what the first layer's bias fill leaves at the inactive sites
+    da = torch.randn(M, C, device=DEV).to(dt)
+    stats = torch.cat([torch.randn(C) * 0.2, torch.rand(C) + 0.5, torch.rand(C) + 0.5, torch.randn(C) * 0.2]).to(DEV)
+    coef = torch.randn(3 * C, device=DEV)
+    a0, a1 = torch.empty_like(y), torch.empty_like(y)
+    _lib.call("vn_bn_apply", y.data_ptr(), vdt, C, M, C, stats.data_ptr(), 1, a0.data_ptr(), vdt, C, 0, E.stream())
+    _lib.call("vn_bn_apply_flagged", y.data_ptr(), vdt, C, M, C, stats.data_ptr(), 1, a1.data_ptr(), vdt, C, flags.data_ptr(),
+              bias.data_ptr(), E.stream())
+    assert torch.equal(a0, a1)
+    rows = lib.vn_bn_bwd_slab_rows(M, C)
+    s0 = torch.empty((rows, 2, C), device=DEV)
+    s1 = torch.empty_like(s0)
+    _lib.call("vn_bn_bwd_reduce_slab", da.data_ptr(), vdt, C, y.data_ptr(), vdt, C, M, C, stats.data_ptr(), 1, s0.data_ptr(),
+              E.stream())
+    _lib.call("vn_bn_bwd_reduce_slab_flagged", da.data_ptr(), vdt, C, y.data_ptr(), vdt, C, M, C, stats.data_ptr(), 1,
+              s1.data_ptr(), flags.data_ptr(), bias.data_ptr(), E.stream())
+    assert torch.equal(s0, s1)
+    full = torch.empty_like(y)
+    _lib.call("vn_bn_bwd_apply", da.data_ptr(), vdt, C, y.data_ptr(), vdt, C, M, C, stats.data_ptr(), coef.data_ptr(), 1,
+              full.data_ptr(), vdt, C, 0, E.stream())
+    idx = torch.nonzero(flags).flatten()
+    lst = torch.stack([idx // (D * H * W), (idx // (H * W)) % D, (idx // W) % H, idx % W], 1).contiguous()
+    cap = int(lst.shape[0]) + 37                     # capacity launch: entries past *count are ignored
+    lst = torch.cat([lst, torch.zeros((37, 4), dtype=torch.int64, device=DEV)])
+    cnt = torch.tensor([int(idx.numel())], dtype=torch.int32, device=DEV)
+    part = torch.full_like(y, 5.0)
+    _lib.call("vn_bn_bwd_apply_list", da.data_ptr(), vdt, y.data_ptr(), vdt, C, D, H, W, stats.data_ptr(), coef.data_ptr(), 1,
+              part.data_ptr(), vdt, lst.data_ptr(), cnt.data_ptr(), cap, E.stream())
+    f = flags.bool()
+    assert torch.equal(part[f], full[f]) and bool((part[~f] == 5.0).all())

@@ -184,16 +184,27 @@ __global__ void __launch_bounds__(256) k_bn_finalize_slab(const float *__restric
     }
 }
 
+// value a y tensor of dtype ydt holds where the conv wrote the plain fp32 value x (the first Conv3d's bias fill)
+__device__ __forceinline__ float as_stored(float x, int ydt) { return ydt == VN_F32 ? x : (float)(bf16_t)x; }
+
+// flags / inactive (first middle layer only, else NULL): rows with flag 0 hold inactive[c] in every channel (the conv bias:
+// no occupied voxel in their receptive field) — their y is not read
 __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, int ydt, int64_t ystride, int64_t M, int C,
                                                   const float *__restrict__ stats, int relu, void *__restrict__ a,
-                                                  int adt, int64_t astride, int64_t lo_off, int64_t fold) {
+                                                  int adt, int64_t astride, int64_t lo_off, int64_t fold,
+                                                  const uint8_t *__restrict__ flags, const float *__restrict__ inactive) {
     const int groups = C >> 3;
     const int64_t total = M * groups;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / groups;
         const int c = (int)(i - m * groups) << 3;
         float v[8];
-        load8(y, ydt, m * ystride + c, v);
+        if (flags && !flags[m]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = as_stored(inactive[c + j], ydt);
+        } else {
+            load8(y, ydt, m * ystride + c, v);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float z = fmaf(stats[2 * C + c + j], v[j] - stats[c + j], stats[3 * C + c + j]);
@@ -206,14 +217,16 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ da, int dadt, int64_t dastride,
                                                        const void *__restrict__ y, int ydt, int64_t ystride, int64_t M,
                                                        int C, const float *__restrict__ stats, int relu,
-                                                       double *__restrict__ sums, float *__restrict__ slab, int64_t fold) {
+                                                       double *__restrict__ sums, float *__restrict__ slab, int64_t fold,
+                                                       const uint8_t *__restrict__ flags, const float *__restrict__ inactive) {
     const int groups = C >> 3, rpb = 256 / groups;
     const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
-    float mean[8], invstd[8], S[8], be[8];
+    float mean[8], invstd[8], S[8], be[8], yin[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = g * 8 + j;
         mean[j] = stats[c]; invstd[j] = stats[C + c]; S[j] = stats[2 * C + c]; be[j] = stats[3 * C + c];
+        yin[j] = flags ? as_stored(inactive[c], ydt) : 0.f;      // what y holds in the rows with flag 0 (not read there)
     }
     float s1[8] = {0}, s2[8] = {0};
     if (rr < rpb) {
@@ -225,7 +238,12 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int64_t mu = m + u * step;
-                load8(y, ydt, mu * ystride + g * 8, yv[u]);
+                if (flags && !flags[mu]) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) yv[u][j] = yin[j];
+                } else {
+                    load8(y, ydt, mu * ystride + g * 8, yv[u]);
+                }
                 load8(da, dadt, (fold ? fold_off(mu, fold, dastride, C) : mu * dastride) + g * 8, dv[u]);
             }
 #pragma unroll
@@ -241,7 +259,12 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
         }
         for (; m < M; m += step) {
             float yv[8], dv[8];
-            load8(y, ydt, m * ystride + g * 8, yv);
+            if (flags && !flags[m]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) yv[j] = yin[j];
+            } else {
+                load8(y, ydt, m * ystride + g * 8, yv);
+            }
             load8(da, dadt, (fold ? fold_off(m, fold, dastride, C) : m * dastride) + g * 8, dv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -365,6 +388,42 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const void *__restrict__ d
     }
 }
 
+// dy = c0 dz + c1 (y - mean) + c2 at the rows of an explicit list only ((b,d,h,w) int64 coordinates of the dense
+// (B,D,H,W,C) tensors, *count valid entries): the first middle layer's gradient kernels read dy at its active sites only
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_list(const void *__restrict__ da, int dadt, const void *__restrict__ y,
+                                                           int ydt, int C, int D, int H, int W,
+                                                           const float *__restrict__ stats, const float *__restrict__ coef,
+                                                           int relu, void *__restrict__ dy, int dydt,
+                                                           const int64_t *__restrict__ list, const int32_t *__restrict__ count,
+                                                           int64_t cap) {
+    const int groups = C >> 3, rpb = 256 / groups;
+    const int c = (threadIdx.x % groups) << 3, rr = threadIdx.x / groups;
+    if (rr >= rpb) return;
+    int64_t n = count ? (int64_t)count[0] : cap;
+    if (n > cap) n = cap;
+    float mean[8], S[8], be[8], c0[8], c1[8], c2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mean[j] = stats[c + j]; S[j] = stats[2 * C + c + j]; be[j] = stats[3 * C + c + j];
+        c0[j] = coef[c + j]; c1[j] = coef[C + c + j]; c2[j] = coef[2 * C + c + j];
+    }
+    for (int64_t e = (int64_t)blockIdx.x * rpb + rr; e < n; e += (int64_t)gridDim.x * rpb) {
+        const int64_t *rc = list + e * 4;
+        const int64_t m = ((rc[0] * D + rc[1]) * H + rc[2]) * W + rc[3];
+        float yv[8], dv[8], o[8];
+        load8(y, ydt, m * C + c, yv);
+        load8(da, dadt, m * C + c, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d0 = yv[j] - mean[j];
+            const float z = fmaf(S[j], d0, be[j]);
+            const float dz = (!relu || z > 0.f) ? dv[j] : 0.f;
+            o[j] = fmaf(c0[j], dz, fmaf(c1[j], d0, c2[j]));
+        }
+        store8(dy, dydt, 0, m * C + c, o);
+    }
+}
+
 inline unsigned gs_blocks(int64_t total, int per_block, int cap) {
     int64_t b = vn_ceil_div(total, per_block);
     if (b < 1) b = 1;
@@ -425,7 +484,24 @@ extern "C" int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t y_stride, int
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(y && a && stats);
     k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
-                                                                                   relu, a, (int)a_dtype, a_stride, lo_off, 0);
+                                                                                   relu, a, (int)a_dtype, a_stride, lo_off, 0,
+                                                                                   nullptr, nullptr);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+// vn_bn_apply for a conv output whose rows with row_flags[m] == 0 all hold `inactive` (float[C], e.g. the conv bias of
+// the first middle layer at the ~90 % of sites without an occupied voxel in reach): those rows are written without
+// reading y.  Same values as vn_bn_apply.
+extern "C" int vn_bn_apply_flagged(const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                                   int32_t relu, void *a, vnDtype a_dtype, int64_t a_stride, const uint8_t *row_flags,
+                                   const float *inactive, vnStream stream) {
+    VN_CHECK_ARG(M >= 0 && rows_ok(C, y_stride) && (a_stride & 7) == 0);
+    if (M == 0) return VN_OK;
+    VN_CHECK_ARG(y && a && stats && row_flags && inactive);
+    k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
+                                                                                   relu, a, (int)a_dtype, a_stride, 0, 0,
+                                                                                   row_flags, inactive);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -439,7 +515,7 @@ extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_str
     const int rpb = 256 / (C >> 3);
     k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
-                                                                                 relu, sums, nullptr, 0);
+                                                                                 relu, sums, nullptr, 0, nullptr, nullptr);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -456,7 +532,22 @@ extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t d
     const int rpb = 256 / (C >> 3);
     k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
-                                                                                 relu, nullptr, slab, 0);
+                                                                                 relu, nullptr, slab, 0, nullptr, nullptr);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+// vn_bn_bwd_reduce_slab for a y whose rows with row_flags[m] == 0 all hold `inactive` (see vn_bn_apply_flagged): y is
+// read at the flagged rows only; da is dense.  Same sums.
+extern "C" int vn_bn_bwd_reduce_slab_flagged(const void *da, vnDtype da_dtype, int64_t da_stride, const void *y,
+                                             vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                                             int32_t relu, float *slab, const uint8_t *row_flags, const float *inactive,
+                                             vnStream stream) {
+    VN_CHECK_ARG(slab && M > 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0 && da && y && stats && row_flags && inactive);
+    const int rpb = 256 / (C >> 3);
+    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+                                                                                 (int)y_dtype, y_stride, M, C, stats,
+                                                                                 relu, nullptr, slab, 0, row_flags, inactive);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -518,7 +609,7 @@ extern "C" int vn_bn_apply_bev(const void *y, vnDtype y_dtype, int64_t M, int32_
     VN_CHECK_ARG(M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
     VN_CHECK_ARG(y && a && stats);
     k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, C, M, C, stats, relu, a,
-                                                                                   (int)a_dtype, wide_stride, 0, hw);
+                                                                                   (int)a_dtype, wide_stride, 0, hw, nullptr, nullptr);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -530,7 +621,7 @@ extern "C" int vn_bn_bwd_reduce_slab_bev(const void *da, vnDtype da_dtype, int64
     VN_CHECK_ARG(da && y && stats);
     const int rpb = 256 / (C >> 3);
     k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, wide_stride, y, (int)y_dtype,
-                                                                                 C, M, C, stats, relu, nullptr, slab, hw);
+                                                                                 C, M, C, stats, relu, nullptr, slab, hw, nullptr, nullptr);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -542,6 +633,23 @@ extern "C" int vn_bn_bwd_apply_bev(const void *da, vnDtype da_dtype, int64_t wid
     VN_CHECK_ARG(da && y && stats && coef && dy);
     k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * apply_epl(M * (C >> 3)), 8192), 256, 0, vn_stream(stream)>>>(
         da, (int)da_dtype, wide_stride, y, (int)y_dtype, C, M, C, stats, coef, relu, dy, (int)dy_dtype, C, 0, nullptr, hw);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+// vn_bn_bwd_apply at the rows of a site list only (vn_active_sites' (b,d,h,w) list and its device-side count): da, y, dy
+// are dense contiguous (B,D,H,W,C) rows.  Rows outside the list are left untouched.
+extern "C" int vn_bn_bwd_apply_list(const void *da, vnDtype da_dtype, const void *y, vnDtype y_dtype, int32_t C, int32_t D,
+                                    int32_t H, int32_t W, const float *stats, const float *coef, int32_t relu, void *dy,
+                                    vnDtype dy_dtype, const int64_t *list, const int32_t *count, int64_t cap,
+                                    vnStream stream) {
+    VN_CHECK_ARG(rows_ok(C, C) && 256 % (C >> 3) == 0 && D > 0 && H > 0 && W > 0 && cap >= 0);
+    if (cap == 0) return VN_OK;
+    VN_CHECK_ARG(da && y && stats && coef && dy && list);
+    const int rpb = 256 / (C >> 3);
+    k_bn_bwd_apply_list<<<gs_blocks(cap, rpb * 2, 4096), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, y, (int)y_dtype, C, D, H, W,
+                                                                                       stats, coef, relu, dy, (int)dy_dtype,
+                                                                                       list, count, cap);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

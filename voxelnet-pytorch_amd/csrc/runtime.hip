@@ -581,6 +581,11 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
             RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream,
                 vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], 1, a.ptr,
                                 (vnDtype)a.dtype, 128, stream));
+        } else if (l == 0 && cfg->sparse_first) {
+            // ~90 % of the first layer's sites hold the bias (no occupied voxel in reach): their y is not read
+            RTT(T_BN_APPLY, l, 0.0, 1.1 * rows_bytes(y), stream,
+                vn_bn_apply_flagged(y.ptr, (vnDtype)y.dtype, y.sW, M, sp.cout, P.stats[l], 1, a.ptr, (vnDtype)a.dtype, a.sW,
+                                    static_cast<const uint8_t *>(P.aws), L[l].bias, stream));
         } else {
             RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream, bn_apply_rows(y, P.stats[l], a, sp.cout, stream));
         }
@@ -765,6 +770,11 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 vn_bn_bwd_apply_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], P.coef[l], 1,
                                     dy.ptr, (vnDtype)dy.dtype, ls));
         } else {
+            if (l == 0 && cfg->sparse_first)   // y is the bias at the ~90 % inactive sites: read at the flagged rows only
+                RTT(T_BN_BWD_REDUCE, l, 0.0, 1.1 * rows_bytes(y), ls,
+                    vn_bn_bwd_reduce_slab_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C,
+                                                  P.stats[l], 1, P.bslab[l], static_cast<const uint8_t *>(P.aws), L[l].bias, ls));
+            else
             RTT(T_BN_BWD_REDUCE, l, 0.0, 2.0 * rows_bytes(y), ls,
                 vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
                                       P.bslab[l], ls));
@@ -773,9 +783,9 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                                         G[l].beta, ls));
             if (l == 0 && cfg->sparse_first)   // dy is only gathered at the active sites (flags: the forward's vn_active_sites)
                 RTT(T_BN_BWD_APPLY, l, 0.0, 0.0, ls,     // (bytes depend on the number of active sites, known on the device only)
-                    vn_bn_bwd_apply_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
-                                            P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW,
-                                            static_cast<const uint8_t *>(P.aws), ls));
+                    vn_bn_bwd_apply_list(da.ptr, (vnDtype)da.dtype, y.ptr, (vnDtype)y.dtype, C, P.odims[0][0], P.odims[0][1],
+                                         P.odims[0][2], P.stats[l], P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, P.alist, P.acount,
+                                         P.acap, ls));
             else
                 RTT(T_BN_BWD_APPLY, l, 0.0, 3.0 * rows_bytes(y), ls,
                     vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],

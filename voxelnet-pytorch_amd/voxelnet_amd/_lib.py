@@ -145,6 +145,11 @@ SIGNATURES = {
     "vn_bn_apply_bev": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
     "vn_bn_bwd_reduce_slab_bev": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_vp]),
     "vn_bn_bwd_apply_bev": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "vn_bn_apply_flagged": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "vn_bn_bwd_reduce_slab_flagged": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,
+                                              c_vp]),
+    "vn_bn_bwd_apply_list": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp,
+                                     c_vp, c_i64, c_vp]),
     "vn_bn_bwd_apply_flagged": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32,
                                         c_i64, c_vp, c_vp]),
     "vn_nchw_to_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_vp]),
