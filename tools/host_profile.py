@@ -38,7 +38,17 @@ for _ in range(n):
     step()
 t1 = time.perf_counter()
 torch.cuda.synchronize()
-print(f"enqueue {1e3 * (t1 - t0) / n:.3f} ms/step (un-profiled)")
+print(f"enqueue {1e3 * (t1 - t0) / n:.3f} ms/step over {n} steps (un-profiled; paced by the GPU once its queue is full)")
+# the host's own cost: a few steps into an EMPTY queue (nothing to wait for), repeated
+best = []
+for _ in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    step(); step()
+    best.append((time.perf_counter() - t0) / 2)
+    torch.cuda.synchronize()
+best.sort()
+print(f"enqueue into an empty queue: median {1e3 * best[len(best) // 2]:.3f} ms/step, min {1e3 * best[0]:.3f} ms/step")
 pr = cProfile.Profile()
 pr.enable()
 for _ in range(n):

@@ -446,6 +446,11 @@ __global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
     for (int i = threadIdx.x; i < z.len[blockIdx.x]; i += 256) p[i] = 0.f;
 }
 
+int m0_bn_knob() {   // tuning aid: VN_M0_BN bit 0 flagged apply, bit 1 flagged reduce, bit 2 list-based backward apply
+    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 7; }();
+    return v;
+}
+
 int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, vnStream st) {
     return vn_bn_apply(y.ptr, (vnDtype)y.dtype, y.sW, y.M(), C, stats, 1, a.ptr, (vnDtype)a.dtype, a.sW, 0, st);
 }
@@ -581,7 +586,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
             RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream,
                 vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], 1, a.ptr,
                                 (vnDtype)a.dtype, 128, stream));
-        } else if (l == 0 && cfg->sparse_first) {
+        } else if (l == 0 && cfg->sparse_first && (m0_bn_knob() & 1)) {
             // ~90 % of the first layer's sites hold the bias (no occupied voxel in reach): their y is not read
             RTT(T_BN_APPLY, l, 0.0, 1.1 * rows_bytes(y), stream,
                 vn_bn_apply_flagged(y.ptr, (vnDtype)y.dtype, y.sW, M, sp.cout, P.stats[l], 1, a.ptr, (vnDtype)a.dtype, a.sW,
@@ -770,7 +775,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 vn_bn_bwd_apply_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], P.coef[l], 1,
                                     dy.ptr, (vnDtype)dy.dtype, ls));
         } else {
-            if (l == 0 && cfg->sparse_first)   // y is the bias at the ~90 % inactive sites: read at the flagged rows only
+            if (l == 0 && cfg->sparse_first && (m0_bn_knob() & 2))   // y is the bias at the ~90 % inactive sites: read at the flagged rows only
                 RTT(T_BN_BWD_REDUCE, l, 0.0, 1.1 * rows_bytes(y), ls,
                     vn_bn_bwd_reduce_slab_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C,
                                                   P.stats[l], 1, P.bslab[l], static_cast<const uint8_t *>(P.aws), L[l].bias, ls));
@@ -781,7 +786,12 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             RTT(T_BN_FINALIZE, l, 0.0, 8.0 * P.bslab_rows[l] * C, ls,
                 vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
                                         G[l].beta, ls));
-            if (l == 0 && cfg->sparse_first)   // dy is only gathered at the active sites (flags: the forward's vn_active_sites)
+            if (l == 0 && cfg->sparse_first && !(m0_bn_knob() & 4))
+                RTT(T_BN_BWD_APPLY, l, 0.0, 0.0, ls,
+                    vn_bn_bwd_apply_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
+                                            P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW,
+                                            static_cast<const uint8_t *>(P.aws), ls));
+            else if (l == 0 && cfg->sparse_first)   // dy is only gathered at the active sites (flags: the forward's vn_active_sites)
                 RTT(T_BN_BWD_APPLY, l, 0.0, 0.0, ls,     // (bytes depend on the number of active sites, known on the device only)
                     vn_bn_bwd_apply_list(da.ptr, (vnDtype)da.dtype, y.ptr, (vnDtype)y.dtype, C, P.odims[0][0], P.odims[0][1],
                                          P.odims[0][2], P.stats[l], P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, P.alist, P.acount,

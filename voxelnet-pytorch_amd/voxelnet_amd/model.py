@@ -370,7 +370,7 @@ def _collect_middle(mod):
 
 
 def _heads_params(flat):
-    pw, pb, rw, rb = flat[-4:]
+    pw, pb, rw, rb = flat[-4:]      # (the last four of the flat parameter list: prob / reg weight and bias)
     return {"weight": torch.cat([pw, rw], 0).contiguous(), "bias": torch.cat([pb, rb], 0).contiguous()}
 
 
@@ -470,6 +470,8 @@ class MiddleConvNet(nn.Module):
         return prob, reg
 
 
+_BWD_ORDER = [22] + list(range(21, 15, -1)) + [15] + list(range(14, 8, -1)) + [8] + list(range(7, 2, -1)) + [2, 1, 0]
+
 # backward segments of the native executor (vn_net_backward steps) that complete a DDP bucket each
 # (parallel.BUCKET_PLAN): heads+deconv3+block3 | deconv2+block2+deconv1 | block1 | middle_layer (+ VFE after it)
 NATIVE_SEGMENTS = [(0, 8), (8, 16), (16, 21), (21, 24)]
@@ -520,11 +522,15 @@ def _grad_views(rpn, fresh=False):
     views of one persistent flat buffer owned by the module (no per-step allocation of 104 tensors).
     fresh=True: a new, uncached buffer (gradient accumulation: the persistent one may BE the parameters' .grad)."""
     if rpn.grad_reducer is not None and not fresh:
-        out = {}
-        for b in rpn.grad_reducer.buckets:
-            out.update(b["views"])
-        return out
-    named = list(rpn.named_parameters())
+        hit = rpn.__dict__.get("_bucket_views")
+        if hit is None or hit[0] is not rpn.grad_reducer:
+            out = {}
+            for b in rpn.grad_reducer.buckets:
+                out.update(b["views"])
+            hit = (rpn.grad_reducer, out)
+            rpn.__dict__["_bucket_views"] = hit
+        return hit[1]
+    named = rpn._named_params()
     key = tuple((n, p.data_ptr()) for n, p in named[:2]) + (named[0][1].device,)
     cache = None if fresh else rpn.__dict__.get("_flat_grads")
     if cache is None or cache[0] != key:
@@ -560,12 +566,20 @@ class _DetectorFn(torch.autograd.Function):
         mode = _mode()
         fn, mid = rpn.feature_net, rpn.middle_rpn
         nv = 8
-        vparams = [p.detach() for p in flat[:nv]]
+        # anchor mode (RPN3D.detect): the 104 parameters do not travel through autograd — a single one-element tensor that
+        # requires grad stands for them, and the backward assigns / adds the gradients to .grad itself (what the direct_grads
+        # mode did anyway): wrapping and unwrapping 104 inputs and their AccumulateGrad edges cost ~0.4 ms of host time a step
+        ctx.anchor = len(flat) == 1
+        if ctx.anchor:
+            flat = rpn._flat_params()
+            vparams = flat[:nv]
+        else:
+            vparams = [p.detach() for p in flat[:nv]]
         native = rpn.native_executor and not E.is_split(mode) and fn._grid.D == 10
         if not native:          # (the per-launch Python orchestration works on name -> tensor dicts)
             names, P, Bf, _ = _collect_middle(mid)
             P = _detached(P)
-            P["heads"] = _heads_params([f.detach() for f in flat[nv:]])
+            P["heads"] = _heads_params([f.detach() for f in flat[-4:]])
         if native:
             with torch.cuda.device(feature.device):
                 dev_ = feature.device
@@ -573,7 +587,7 @@ class _DetectorFn(torch.autograd.Function):
                 D, H, W = fn._grid.dims
                 K = feature.shape[0]
                 cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, 1 if mode == "fp32" else 0, int(training), int(sparse), 0, 0)
-                heads = _heads_params([f.detach() for f in flat[nv:]])
+                heads = _heads_params([f.detach() for f in flat[-4:]])
                 arr, _ = _native_layer_arrays(mid)
                 lib = _lib.load()
                 ws_bytes = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
@@ -734,7 +748,8 @@ def _detector_backward_native(ctx, d_prob, d_reg):
     # Some parameter already has a .grad (a second backward() before zero_grad, or zero_grad(set_to_none=False)): the
     # caller wants SUMS.  The persistent flat buffer may BE those .grad tensors (direct_grads), so the kernels must not
     # overwrite it: this step's gradients go to a fresh buffer and are handed to autograd, whose AccumulateGrad adds.
-    accumulate = any(p.grad is not None for p in rpn.parameters())
+    plist = rpn._flat_params()
+    accumulate = any(p.grad is not None for p in plist)
     if accumulate and red is not None:
         raise _lib.VoxelnetHipError("gradient accumulation over several backward() calls is not supported with a "
                                     "grad_reducer attached: call zero_grad(set_to_none=True) after every step")
@@ -748,7 +763,7 @@ def _detector_backward_native(ctx, d_prob, d_reg):
         dp, dr = d_prob.contiguous().float(), d_reg.contiguous().float()
         d_in = d_vw if cfg.sparse_first else torch.empty_like(dense.t)
         table = N.layer_table(mid._block1_stride)
-        order = [22] + list(range(21, 15, -1)) + [15] + list(range(14, 8, -1)) + [8] + list(range(7, 2, -1)) + [2, 1, 0]
+        order = _BWD_ORDER
         side = rpn._side_stream(dev) if rpn.overlap_wgrad else None
         if red is not None and side is not None and red.comm_stream is not None:
             # Gradient all-reduce overlapped with a SINGLE backward call: the executor unpacks every parameter group's
@@ -779,23 +794,40 @@ def _detector_backward_native(ctx, d_prob, d_reg):
             vg = _detector_backward_segments(cfg, arr, heads, dp, dr, prob, dense, coord, vw_rows, K, ws, ws_bytes, garr,
                                              dhw, dhb, d_in, side, red, views, table, order, rpn, feature, wst, stats, d_vw,
                                              vparams)
-    mg = []
-    for name, spec in table:
-        cv = "deconv" if spec.transposed else "conv"
-        pre = f"middle_rpn.{name}."
-        mg += [views[pre + cv + ".weight"], views[pre + cv + ".bias"], views[pre + "batch_norm.weight"],
-               views[pre + "batch_norm.bias"]]
-    mg += [views["middle_rpn.prob_conv.conv.weight"], views["middle_rpn.prob_conv.conv.bias"],
-           views["middle_rpn.reg_conv.conv.weight"], views["middle_rpn.reg_conv.conv.bias"]]
+    hit = None if accumulate else rpn.__dict__.get("_mg_cache")
+    if hit is None or hit[0] is not views:
+        mg = []
+        for name, spec in table:
+            cv = "deconv" if spec.transposed else "conv"
+            pre = f"middle_rpn.{name}."
+            mg += [views[pre + cv + ".weight"], views[pre + cv + ".bias"], views[pre + "batch_norm.weight"],
+                   views[pre + "batch_norm.bias"]]
+        mg += [views["middle_rpn.prob_conv.conv.weight"], views["middle_rpn.prob_conv.conv.bias"],
+               views["middle_rpn.reg_conv.conv.weight"], views["middle_rpn.reg_conv.conv.bias"]]
+        hit = (views, [views[k] for k in VFE_KEYS] + mg)       # the gradient tensors in _flat_params order
+        if not accumulate:
+            rpn.__dict__["_mg_cache"] = hit
     rpn._ws_release(ws)
     ctx.saved = None          # drop the dense grid etc. now, not when the graph node is collected
-    out = list(vg) + mg
+    out = hit[1]
+    if ctx.anchor:
+        # the parameters are not inputs of this Function: their gradients are assigned (or, when a .grad exists, added:
+        # what AccumulateGrad would do) here
+        if accumulate:
+            have = [(p_, g_) for p_, g_ in zip(plist, out) if p_.grad is not None]
+            torch._foreach_add_([p_.grad for p_, _ in have], [g_ for _, g_ in have])
+            for p_, g_ in zip(plist, out):
+                if p_.grad is None:
+                    p_.grad = g_
+        else:
+            for p_, g_ in zip(plist, out):
+                p_.grad = g_
+        return (None,) * 6
     if accumulate:
         return (None, None, None, None, None) + tuple(out)        # (views of a buffer nobody else holds)
     if rpn.direct_grads:
         # hand the gradients to the parameters directly: returning the (shared) views through autograd would make
         # AccumulateGrad clone all 104 of them every step
-        plist = rpn._flat_params()
         for p_, g_ in zip(plist, out):
             p_.grad = g_
         return (None,) * (5 + len(out))
@@ -866,7 +898,8 @@ class RPN3D(nn.Module):
     # Runtime caches kept in the instance __dict__ (ctypes arrays, HIP streams, the ~1.5 GB executor arenas, the flat
     # gradient buffer, device-side target / decode helpers).  They are rebuilt on demand and must not travel with
     # `torch.save(model)` (the reference's checkpoint format, train.py:24/27) or `copy.deepcopy(model)`.
-    _RUNTIME_KEYS = ("_side", "_ws_pool", "_flat_grads", "_targets", "_decoder", "_nbt", "_flat_param_list", "_net_ctx")
+    _RUNTIME_KEYS = ("_side", "_ws_pool", "_flat_grads", "_targets", "_decoder", "_nbt", "_flat_param_list", "_net_ctx",
+                     "_named_param_list", "_anchor_t", "_bucket_views", "_mg_cache")
 
     def __getstate__(self):
         d = self.__dict__.copy()
@@ -952,6 +985,22 @@ class RPN3D(nn.Module):
                                        scores[:, np.newaxis]], axis=-1))
         return data[0], out
 
+    def _named_params(self):
+        """list(self.named_parameters()), cached (the Parameter objects are stable; see _flat_params)"""
+        np_ = self.__dict__.get("_named_param_list")
+        if np_ is None:
+            np_ = list(self.named_parameters())
+            self.__dict__["_named_param_list"] = np_
+        return np_
+
+    def _anchor(self, device):
+        """the one-element leaf that stands for all parameters in the autograd graph of the native path (_DetectorFn)"""
+        a = self.__dict__.get("_anchor_t")
+        if a is None or a.device != torch.device(device):
+            a = torch.zeros(1, device=device, requires_grad=True)
+            self.__dict__["_anchor_t"] = a
+        return a
+
     def _flat_params(self):
         """the 8 VFE + 96 middle/RPN parameters in the executor's order (the Parameter objects are stable: `.to()` and
         `load_state_dict` change their data in place), cached: the module walk costs ~0.15 ms of host time per call"""
@@ -985,18 +1034,27 @@ class RPN3D(nn.Module):
     def detect(self, voxel_features, voxel_coordinates):
         """feature_net + middle_rpn (model.py:305-306), fused."""
         bs = len(voxel_features)
-        feature = torch.cat(list(voxel_features), dim=0).contiguous().float()
-        coord = torch.cat(list(voxel_coordinates), dim=0).contiguous().long()
+        feature = (voxel_features[0] if bs == 1 else torch.cat(list(voxel_features), dim=0)).contiguous().float()
+        coord = (voxel_coordinates[0] if bs == 1 else torch.cat(list(voxel_coordinates), dim=0)).contiguous().long()
         flat = self._flat_params()
-        prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, *flat)
+        if (self.native_executor and self.direct_grads and torch.is_grad_enabled() and feature.is_cuda
+                and not E.is_split(_mode()) and self._all_need_grad(flat)):
+            prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, self._anchor(feature.device))
+        else:
+            prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, *flat)
         self._tick()
         return prob, reg
+
+    def _all_need_grad(self, flat):
+        return all(p.requires_grad for p in flat)
 
     def loss(self, prob_out, delta_out, pos_equal_one, neg_equal_one, targets):
         """model.py:310-352 -> (loss, cls_loss, reg_loss, cls_pos_loss_rec, cls_neg_loss_rec), fused (csrc/loss.hip)."""
         dev = prob_out.device
 
         def f32(a):
+            if torch.is_tensor(a) and a.dtype == torch.float32 and a.device == dev and a.is_contiguous():
+                return a
             return (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev).float().contiguous()
         return _LossFn.apply(prob_out, delta_out, f32(pos_equal_one), f32(neg_equal_one), f32(targets),
                              float(self.alpha), float(self.beta), float(self.sigma))

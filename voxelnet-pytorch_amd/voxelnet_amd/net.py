@@ -12,8 +12,18 @@ from .engine import Rows, spec2, spec3
 HEADS = spec2("heads", 768, 16, 1, (1, 1), (0, 0), bn=False, relu=False)
 
 
+_TABLES = {}
+
+
 def layer_table(block1_stride):
-    """model.py:206-254 in execution order: [(name, spec)], names = state_dict prefixes."""
+    """model.py:206-254 in execution order: [(name, spec)], names = state_dict prefixes (cached: read-only)."""
+    hit = _TABLES.get(block1_stride)
+    if hit is None:
+        hit = _TABLES[block1_stride] = _layer_table(block1_stride)
+    return hit
+
+
+def _layer_table(block1_stride):
     s1 = (block1_stride, block1_stride)
     t = [("middle_layer.0", spec3("middle_layer.0", 128, 64, 3, (2, 1, 1), (1, 1, 1))),
          ("middle_layer.1", spec3("middle_layer.1", 64, 64, 3, (1, 1, 1), (0, 1, 1))),

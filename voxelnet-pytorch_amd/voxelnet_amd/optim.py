@@ -33,6 +33,7 @@ class ClipSGD(torch.optim.Optimizer):
         self._key = None
         self._table = self._ws = self._norm = None
         self._n_chunks = 0
+        self._plist = self._last_grads = None
 
     # (kept for callers of the round-1 class)
     @property
@@ -56,6 +57,18 @@ class ClipSGD(torch.optim.Optimizer):
         self._key = None                  # device chunk table / workspace: rebuilt on the first step
         self._table = self._ws = self._norm = None
         self._n_chunks = 0
+        self._plist = self._last_grads = None
+
+    def zero_grad(self, set_to_none=True):
+        """torch.optim.Optimizer.zero_grad without its per-parameter foreach bookkeeping (104 small tensors)"""
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for p in self.params:
+            p.grad = None
+
+    def add_param_group(self, group):
+        super().add_param_group(group)
+        self._plist = self._last_grads = None
 
     def _build(self, pairs, dev):
         rows = []
@@ -78,7 +91,21 @@ class ClipSGD(torch.optim.Optimizer):
         for g in self.param_groups[1:]:
             if g["lr"] != self.param_groups[0]["lr"] or g["max_norm"] != self.param_groups[0]["max_norm"]:
                 raise _lib.VoxelnetHipError("ClipSGD: one lr / max_norm for all parameter groups (the clip norm is global)")
-        pairs = [(p, p.grad) for p in self.params if p.grad is not None]
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self._plist = self.params
+        last = self.__dict__.get("_last_grads")
+        if last is not None and self._table is not None and all(p.grad is g for p, g in zip(plist, last)):
+            # the same gradient tensors as in the previous step (the model's flat buffer / bucket views): the chunk table
+            # is still valid, nothing to rebuild or re-check
+            with torch.cuda.device(self._table.device):
+                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                from . import engine as E
+                with E.section("clip_sgd", 16.0 * self._n_elems):
+                    _lib.call("vn_clip_sgd", self._table.data_ptr(), self._n_chunks, self.max_norm, self.lr,
+                              int(self.scale_grads), self._ws.data_ptr(), self._ws.numel(), self._norm.data_ptr(), stream)
+            return self._norm[0]
+        pairs = [(p, p.grad) for p in plist if p.grad is not None]
         if not pairs:
             return None
         dev = pairs[0][0].device
@@ -91,6 +118,8 @@ class ClipSGD(torch.optim.Optimizer):
         if key != self._key:
             self._build(pairs, dev)        # pointers are stable from step to step (flat gradient buffer): built once
             self._key = key
+        self._n_elems = sum(p.numel() for p, _ in pairs)
+        self._last_grads = [p.grad for p in plist] if len(pairs) == len(plist) else None
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             from . import engine as E
