@@ -1,4 +1,7 @@
-# round-end measurement set (run on the GPU box through gpurun): tests, smoke, bench, rocprofv3 stats + PMC passes
+# round-end measurement set (run on the GPU box through gpurun): tests, smoke, bench (three configs), rocprofv3 kernel
+# stats of the SAME command, the two HBM-traffic PMC passes and the MFMA-busy PMC pass (each --pmc pass on its own, never
+# combined with tracing).  Summaries are copied to profiles/ by hand afterwards (gpurun_out/ is scratch).
+R=${R:-r02}
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 set -e
 cd $GRAFT_REPO_ROOT
@@ -8,9 +11,18 @@ python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 
 tail -1 gpurun_out/final_smoke.log
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 cat gpurun_out/final_bench.json
+python bench.py --config ped --no-cpu-baseline > gpurun_out/final_bench_ped.json 2> gpurun_out/final_bench_ped.err
+python bench.py --config dense --no-cpu-baseline > gpurun_out/final_bench_dense.json 2> gpurun_out/final_bench_dense.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/fstats -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/fstats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/fpmc_fetch -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timer > $GRAFT_REPO_ROOT/gpurun_out/fpmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $GRAFT_REPO_ROOT/gpurun_out/fpmc_write -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timer > $GRAFT_REPO_ROOT/gpurun_out/fpmc_write.log 2>&1
+O=$GRAFT_REPO_ROOT/gpurun_out
+rocprofv3 --kernel-trace --stats -d $O/fstats -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $O/fstats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/fpmc_fetch -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer > $O/fpmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/fpmc_write -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer > $O/fpmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/fpmc_mfma -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer > $O/fpmc_mfma.log 2>&1
 cd $GRAFT_REPO_ROOT
-ls gpurun_out/fstats gpurun_out/fpmc_fetch gpurun_out/fpmc_write
+python tools/pmc_traffic.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 > gpurun_out/${R}_pmc_traffic_per_kernel.txt
+python tools/pmc_family.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 gpurun_out/${R}_pmc_traffic.json
+python tools/pmc_mfma.py gpurun_out/fpmc_mfma 3 gpurun_out/${R}_pmc_mfma_per_kernel.txt | head -40
+python tools/trace_summary.py $(ls gpurun_out/fstats/*/*kernel_trace.csv gpurun_out/fstats/*kernel_trace.csv 2>/dev/null | head -1) 10 > gpurun_out/${R}_bench_per_step.txt 2>&1 || true
+cp $(ls gpurun_out/fstats/*/*kernel_stats.csv gpurun_out/fstats/*kernel_stats.csv 2>/dev/null | head -1) gpurun_out/${R}_bench_kernel_stats.csv || true
+ls gpurun_out/fstats gpurun_out/fpmc_fetch gpurun_out/fpmc_write gpurun_out/fpmc_mfma

@@ -187,8 +187,10 @@ __global__ void __launch_bounds__(256) k_bn_finalize_slab(const float *__restric
 // value a y tensor of dtype ydt holds where the conv wrote the plain fp32 value x (the first Conv3d's bias fill)
 __device__ __forceinline__ float as_stored(float x, int ydt) { return ydt == VN_F32 ? x : (float)(bf16_t)x; }
 
-// flags / inactive (first middle layer only, else NULL): rows with flag 0 hold inactive[c] in every channel (the conv bias:
-// no occupied voxel in their receptive field) — their y is not read
+// FLAGGED (first middle layer only): rows with flag 0 hold inactive[c] in every channel (the conv bias: no occupied voxel
+// in their receptive field) — their y is not read.  A template parameter, not a run-time branch: the extra arguments
+// and the per-row test cost the plain instantiation 60 % of its speed when they were folded into one kernel (measured).
+template <bool FLAGGED>
 __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, int ydt, int64_t ystride, int64_t M, int C,
                                                   const float *__restrict__ stats, int relu, void *__restrict__ a,
                                                   int adt, int64_t astride, int64_t lo_off, int64_t fold,
@@ -199,7 +201,9 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
         const int64_t m = i / groups;
         const int c = (int)(i - m * groups) << 3;
         float v[8];
-        if (flags && !flags[m]) {
+        bool inact = false;
+        if constexpr (FLAGGED) inact = !flags[m];
+        if (inact) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = as_stored(inactive[c + j], ydt);
         } else {
@@ -214,6 +218,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
     }
 }
 
+template <bool FLAGGED>
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ da, int dadt, int64_t dastride,
                                                        const void *__restrict__ y, int ydt, int64_t ystride, int64_t M,
                                                        int C, const float *__restrict__ stats, int relu,
@@ -226,7 +231,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
     for (int j = 0; j < 8; ++j) {
         const int c = g * 8 + j;
         mean[j] = stats[c]; invstd[j] = stats[C + c]; S[j] = stats[2 * C + c]; be[j] = stats[3 * C + c];
-        yin[j] = flags ? as_stored(inactive[c], ydt) : 0.f;      // what y holds in the rows with flag 0 (not read there)
+        yin[j] = 0.f;
+        if constexpr (FLAGGED) yin[j] = as_stored(inactive[c], ydt);      // what y holds in the rows with flag 0 (not read there)
     }
     float s1[8] = {0}, s2[8] = {0};
     if (rr < rpb) {
@@ -238,7 +244,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int64_t mu = m + u * step;
-                if (flags && !flags[mu]) {
+                bool inact = false;
+                if constexpr (FLAGGED) inact = !flags[mu];
+                if (inact) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) yv[u][j] = yin[j];
                 } else {
@@ -259,7 +267,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
         }
         for (; m < M; m += step) {
             float yv[8], dv[8];
-            if (flags && !flags[m]) {
+            bool inact = false;
+            if constexpr (FLAGGED) inact = !flags[m];
+            if (inact) {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) yv[j] = yin[j];
             } else {
@@ -483,9 +493,9 @@ extern "C" int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t y_stride, int
     VN_CHECK_ARG(M >= 0 && rows_ok(C, y_stride) && (a_stride & 7) == 0 && (lo_off & 7) == 0 && lo_off >= 0 && (!lo_off || a_dtype == VN_BF16));
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(y && a && stats);
-    k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
-                                                                                   relu, a, (int)a_dtype, a_stride, lo_off, 0,
-                                                                                   nullptr, nullptr);
+    k_bn_apply<false><<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
+                                                                                          relu, a, (int)a_dtype, a_stride, lo_off, 0,
+                                                                                          nullptr, nullptr);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -499,9 +509,9 @@ extern "C" int vn_bn_apply_flagged(const void *y, vnDtype y_dtype, int64_t y_str
     VN_CHECK_ARG(M >= 0 && rows_ok(C, y_stride) && (a_stride & 7) == 0);
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(y && a && stats && row_flags && inactive);
-    k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
-                                                                                   relu, a, (int)a_dtype, a_stride, 0, 0,
-                                                                                   row_flags, inactive);
+    k_bn_apply<true><<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
+                                                                                         relu, a, (int)a_dtype, a_stride, 0, 0,
+                                                                                         row_flags, inactive);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -513,7 +523,7 @@ extern "C" int vn_bn_bwd_reduce(const void *da, vnDtype da_dtype, int64_t da_str
     if (M == 0) return VN_OK;
     VN_CHECK_ARG(da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+    k_bn_bwd_reduce<false><<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, sums, nullptr, 0, nullptr, nullptr);
     VN_LAUNCH_STATUS();
@@ -530,7 +540,7 @@ extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t d
                                      float *slab, vnStream stream) {
     VN_CHECK_ARG(slab && M > 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0 && da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+    k_bn_bwd_reduce<false><<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, nullptr, slab, 0, nullptr, nullptr);
     VN_LAUNCH_STATUS();
@@ -545,7 +555,7 @@ extern "C" int vn_bn_bwd_reduce_slab_flagged(const void *da, vnDtype da_dtype, i
                                              vnStream stream) {
     VN_CHECK_ARG(slab && M > 0 && rows_ok(C, y_stride) && (da_stride & 7) == 0 && da && y && stats && row_flags && inactive);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
+    k_bn_bwd_reduce<true><<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, nullptr, slab, 0, row_flags, inactive);
     VN_LAUNCH_STATUS();
@@ -608,8 +618,8 @@ extern "C" int vn_bn_apply_bev(const void *y, vnDtype y_dtype, int64_t M, int32_
                                int32_t relu, void *a, vnDtype a_dtype, int64_t wide_stride, vnStream stream) {
     VN_CHECK_ARG(M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
     VN_CHECK_ARG(y && a && stats);
-    k_bn_apply<<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, C, M, C, stats, relu, a,
-                                                                                   (int)a_dtype, wide_stride, 0, hw, nullptr, nullptr);
+    k_bn_apply<false><<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, C, M, C, stats, relu, a,
+                                                                                          (int)a_dtype, wide_stride, 0, hw, nullptr, nullptr);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -620,7 +630,7 @@ extern "C" int vn_bn_bwd_reduce_slab_bev(const void *da, vnDtype da_dtype, int64
     VN_CHECK_ARG(slab && M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
     VN_CHECK_ARG(da && y && stats);
     const int rpb = 256 / (C >> 3);
-    k_bn_bwd_reduce<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, wide_stride, y, (int)y_dtype,
+    k_bn_bwd_reduce<false><<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, wide_stride, y, (int)y_dtype,
                                                                                  C, M, C, stats, relu, nullptr, slab, hw, nullptr, nullptr);
     VN_LAUNCH_STATUS();
     return VN_OK;

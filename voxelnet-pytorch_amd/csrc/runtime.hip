@@ -446,8 +446,10 @@ __global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
     for (int i = threadIdx.x; i < z.len[blockIdx.x]; i += 256) p[i] = 0.f;
 }
 
-int m0_bn_knob() {   // tuning aid: VN_M0_BN bit 0 flagged apply, bit 1 flagged reduce, bit 2 list-based backward apply
-    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 7; }();
+// tuning aid: VN_M0_BN bit 0 flagged forward apply (measured SLOWER than the dense pass, 124 vs 86 us: a per-row flag test
+// in a streaming kernel; off), bit 1 flagged backward reduce (90 vs 102 us), bit 2 list-based backward apply (30 vs 87 us)
+int m0_bn_knob() {
+    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 6; }();
     return v;
 }
 
