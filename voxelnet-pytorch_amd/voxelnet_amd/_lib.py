@@ -182,6 +182,9 @@ class VoxelnetHipError(RuntimeError):
     pass
 
 
+ABI_VERSION = 2     # include/voxelnet_hip.h: vn_abi_version()
+
+
 def load():
     """Load the HIP library; loud failure if it was not built."""
     global _lib
@@ -191,6 +194,10 @@ def load():
                 f"{LIB_PATH} is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(make -C voxelnet-pytorch_amd/csrc).  There is no CPU fallback.")
         lib = ctypes.CDLL(LIB_PATH)
+        have = lib.vn_abi_version() if hasattr(lib, "vn_abi_version") else None
+        if have != ABI_VERSION:
+            raise VoxelnetHipError(f"{LIB_PATH} has ABI version {have}, this package binds version {ABI_VERSION}: "
+                                   "rebuild it (make -C voxelnet-pytorch_amd/csrc)")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name, None)
             if fn is not None:
