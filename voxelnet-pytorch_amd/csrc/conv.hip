@@ -667,6 +667,203 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
     gg_store<WM, WN, SM>(p, acc, smem, otab, tile, n0, wm, wn, lane);
 }
 
+// 2-D layers on small images (100 x 88, 50 x 44): the same kernel with an NSB-deep weight pipeline
+template <int WM, int WN, int SM, int TW, int NSB, bool F32>
+__global__ void __launch_bounds__(256, 2) k_conv_patch2d(const GGParams p) {
+    constexpr int ESZ = F32 ? 4 : 2;
+    constexpr int BM = 16 * SM * WM, BN = 64 * WN, TH = BM / TW;
+    static_assert(WM * WN == 4 && BM % TW == 0, "4 waves; whole patch lines");
+    constexpr int PW = TW + 2, PH = TH + 2, PROWS = PH * PW;
+    constexpr int PPIECES = (PROWS + 7) / 8;                 // 1-KiB pieces of the patch
+    constexpr int PA = (PPIECES + 3) / 4;                    // per wave
+    constexpr int PATCH_BYTES = PA * 4 * 1024;
+    constexpr int RB = BN / 32;                              // weight pieces per wave and tap
+    constexpr int B_BYTES = BN * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char *bst = smem + 2 * PATCH_BYTES;                      // two patch buffers, then NSB weight stages
+    static_assert(NSB >= 3 && (NSB - 2) * RB <= 63, "vmcnt is 6 bits");
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const GGClass &cl = p.cls[blockIdx.y];
+    const int ntn = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int tile = bid / ntn, tile_n = bid - tile * ntn;
+    const int n0 = tile_n * BN;
+    const int tiles_x = (cl.qW + TW - 1) / TW, tiles_y = (cl.qH + TH - 1) / TH;
+    int t = tile;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int qd = t % cl.qD;
+    const int b = t / cl.qD;
+    if (b >= p.B) return;                                    // (a residue class with fewer planes than the largest)
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- loader state: patch rows of this lane (fixed over the planes and K chunks) and its weight rows
+    const int a_chunk = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    uint32_t a_row[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int q = (i * 4 + wave) * 8 + (lane >> 3);       // patch row
+        const int qy = q / PW, qx = q - qy * PW;
+        const int sy = y0 - 1 + qy, sx = x0 - 1 + qx;          // H/W: stride 1, offsets -1..1 (checked on the host)
+        a_row[i] = (q < PROWS && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+                       ? (uint32_t)(((int64_t)sy * p.sH + (int64_t)sx * p.sW) * ESZ)
+                       : GG_OOB;
+    }
+    uint32_t b_row[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int rho = (i * 4 + wave) * 8 + (lane >> 3);
+        const int rl = rho & 63;
+        const int n = n0 + (rho & ~63) + (rl & 15) * 4 + (rl >> 4);
+        b_row[i] = n < p.N ? (uint32_t)((int64_t)n * p.Cs * ESZ) : GG_OOB;
+    }
+    const char *src_base = p.src + (int64_t)b * p.sB * ESZ;
+    int64_t src_bytes = p.src_batch_extent * ESZ;
+    if (src_bytes > (int64_t)GG_MAX_WINDOW) src_bytes = GG_MAX_WINDOW;
+    const __amdgpu_buffer_rsrc_t rs_a = vn_uniform_rsrc(src_base, (uint32_t)src_bytes);
+    const __amdgpu_buffer_rsrc_t rs_b = vn_uniform_rsrc(p.w, p.w_bytes);
+    constexpr int BKE = 128 / ESZ, EPC = 16 / ESZ;
+    const int nk = (p.Cs + BKE - 1) / BKE;
+    const int k_lane0 = a_chunk * EPC;
+
+    // ---- fragment geometry: MFMA row (lane & 15) of sub-tile i is output pixel (py, px) -> patch row of tap (0,0)
+    const int fr = lane & 15, fq = lane >> 4;
+    int q0[SM];
+#pragma unroll
+    for (int i = 0; i < SM; ++i) {
+        const int r = wm * (16 * SM) + i * 16 + fr;
+        const int py = r / TW, px = r - py * TW;
+        q0[i] = (py + 1) * PW + (px + 1);
+    }
+    const int bfrag0 = fr * 128 + (((0 + fq) ^ (fr >> 1)) << 4);
+    const int bfrag1 = fr * 128 + (((4 + fq) ^ (fr >> 1)) << 4);
+
+    f32x4_t acc[SM][4];
+#pragma unroll
+    for (int i = 0; i < SM; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // H/W have one class and their taps in kernel order (div 1), so the weight index of tap (id, ih, iw) is that of
+    // (id, 0, 0) plus ih*3 + iw: one scalar load per depth tap, none inside the tap loop
+    const uint32_t tap_bytes = (uint32_t)p.N * (uint32_t)p.Cs * (uint32_t)ESZ;
+    auto wbase_of = [&](int id) { return p.taps[cl.tap_begin + id * 9].widx; };
+    auto stage_b = [&](int wbase, int tap, int kc, int buf) {
+        const int k_lane = kc * BKE + k_lane0;
+        const bool k_ok = k_lane < p.Cs;
+        const uint32_t b_koff = (uint32_t)k_lane * (uint32_t)ESZ;
+        const uint32_t b_soff = __builtin_amdgcn_readfirstlane((uint32_t)(wbase + tap) * tap_bytes);
+        char *lb = bst + buf * B_BYTES + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+            lds_dma16(rs_b, lb + i * 4096, (k_ok && b_row[i] != GG_OOB) ? b_row[i] + b_koff : GG_OOB, b_soff);
+    };
+    auto stage_patch = [&](int sd, int kc, char *patch) {
+        const int k_lane = kc * BKE + k_lane0;
+        const bool k_ok = k_lane < p.Cs;
+        const int k_src = (p.src_wrap > 0 && k_lane >= p.src_wrap) ? k_lane - p.src_wrap : k_lane;
+        const uint32_t off = (uint32_t)(((int64_t)sd * p.sD + k_src) * ESZ);
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            lds_dma16(rs_a, patch + (i * 4 + wave) * 1024, (k_ok && a_row[i] != GG_OOB) ? a_row[i] + off : GG_OOB, 0);
+    };
+
+    // one source plane (2-D layer): steps s = kc*9 + tap.  The weight tile of step s + NSB - 1 is staged while step s is on
+    // the MFMAs and the patch of the next K chunk PT taps into this one (second patch buffer), so that bytes fetched from
+    // HBM / Infinity Cache — in the train step every layer's weights and input are cold — have NSB - 1 tap steps to arrive
+    // instead of one, and a chunk boundary is an ordinary step (no drain)
+    constexpr int PT = 3;
+    const int sd = qd * p.mulD + cl.offD[0];
+    const int total = ((unsigned)sd < (unsigned)p.Ds) ? nk * 9 : 0;
+    const int wbase = wbase_of(0);
+    auto stage_step = [&](int s) {
+        const int kc = s / 9;
+        stage_b(wbase, s - kc * 9, kc, s % NSB);
+    };
+    if (total > 0) stage_patch(sd, 0, smem);
+#pragma unroll
+    for (int s = 0; s < NSB - 1; ++s)
+        if (s < total) stage_step(s);
+    int pbuf = 0;
+    for (int kc = 0; kc < nk && total > 0; ++kc) {
+        const char *patch = smem + pbuf * PATCH_BYTES;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int s = kc * 9 + tap;
+            const int ih = tap / 3, iw = tap - ih * 3;
+            // the tile of step s (and, at tap 0, this chunk's patch: issued before that tile) has landed; the loads issued
+            // after it — the tiles of steps s+1 .. s+NSB-2 — may still be in flight.  lgkmcnt(0): see k_gather_gemm
+            const int after = total - 1 - s < NSB - 2 ? total - 1 - s : NSB - 2;
+            if (after >= 2 && NSB >= 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * RB) : "memory");
+            else if (after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // (the other patch buffer was last read in the previous chunk: PT >= 1 barriers ago)
+            if (tap == PT && kc + 1 < nk) stage_patch(sd, kc + 1, smem + (pbuf ^ 1) * PATCH_BYTES);
+            if (s + NSB - 1 < total) stage_step(s + NSB - 1);
+            const int shift = cl.offH[ih] * PW + cl.offW[iw];
+            const char *lb = bst + (s % NSB) * B_BYTES + wn * (64 * 128);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int fo = ks ? bfrag1 : bfrag0;
+                if constexpr (F32) {
+                    f32x4_t bq[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + fo);
+#pragma unroll
+                    for (int i = 0; i < SM; ++i) {
+                        const int q = q0[i] + shift;
+                        const f32x4_t a = *reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((ks * 4 + fq) ^ ((q >> 1) & 7)) << 4));
+#pragma unroll
+                        for (int t4 = 0; t4 < 4; ++t4)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t4], bq[j][t4], acc[i][j], 0, 0, 0);
+                    }
+                } else {
+                    bf16x8_t bq[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) bq[j] = *reinterpret_cast<const bf16x8_t *>(lb + j * 2048 + fo);
+#pragma unroll
+                    for (int i = 0; i < SM; ++i) {
+                        const int q = q0[i] + shift;
+                        const bf16x8_t a = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((ks * 4 + fq) ^ ((q >> 1) & 7)) << 4));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        pbuf ^= 1;
+    }
+
+    // ---- epilogue: row -> output offset table, then the shared store / statistics code
+    __syncthreads();
+    int32_t *otab = reinterpret_cast<int32_t *>(smem);
+    for (int r = threadIdx.x; r < BM; r += 256) {
+        const int py = r / TW, px = r - py * TW;
+        const int qh = y0 + py, qw = x0 + px;
+        int32_t off = -1;
+        if (qh < cl.qH && qw < cl.qW) {
+            const int od = qd * p.omulD + cl.ooffD, oh = qh * p.omulH + cl.ooffH, ow = qw * p.omulW + cl.ooffW;
+            if (od < p.Do && oh < p.Ho && ow < p.Wo)
+                off = (int32_t)((int64_t)b * p.oB + (int64_t)od * p.oD + (int64_t)oh * p.oH + (int64_t)ow * p.oW);
+        }
+        otab[r] = off;
+    }
+    __syncthreads();
+    gg_store<WM, WN, SM>(p, acc, smem, otab, tile, n0, wm, wn, lane);
+}
+
 inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 inline int posmod(int a, int b) { int r = a % b; return r < 0 ? r + b : r; }
 
@@ -792,7 +989,29 @@ int launch_patch(const GGParams &p, dim3 grid, hipStream_t st) {
     k_conv_patch<WM, WN, SM, TW, F32><<<grid, 256, lds, st>>>(p);
     return 0;
 }
+template <int WM, int WN, int SM, int TW, int NSB, bool F32>
+int launch_patch2d(const GGParams &p, dim3 grid, hipStream_t st) {
+    constexpr int BM = 16 * SM * WM, TH = BM / TW, PROWS = (TH + 2) * (TW + 2);
+    constexpr size_t lds = 2 * ((size_t)((PROWS + 7) / 8 + 3) / 4 * 4096) + NSB * (size_t)(64 * WN) * 128;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch2d<WM, WN, SM, TW, NSB, F32>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (attr != hipSuccess) return (int)attr;
+    k_conv_patch2d<WM, WN, SM, TW, NSB, F32><<<grid, 256, lds, st>>>(p);
+    return 0;
+}
+int patch2d_stages() {   // VN_PATCH2D=0: the two-stage kernel for the small images too; 3 / 4: weight stages
+    static const int v = [] {
+        const char *e = getenv("VN_PATCH2D");
+        return e && *e ? atoi(e) : 3;
+    }();
+    return v;
+}
 int launch_patch_cfg(const PatchCfg &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
+    if (c.id == 2 && p.Ds == 1 && p.nclasses == 1 && p.cls[0].nD == 1 && patch2d_stages() >= 3) {
+        if (patch2d_stages() == 3)
+            return f32 ? launch_patch2d<2, 2, 2, 16, 3, true>(p, grid, st) : launch_patch2d<2, 2, 2, 16, 3, false>(p, grid, st);
+        return f32 ? launch_patch2d<2, 2, 2, 16, 4, true>(p, grid, st) : launch_patch2d<2, 2, 2, 16, 4, false>(p, grid, st);
+    }
     if (c.id == 1) return f32 ? launch_patch<4, 1, 4, 32, true>(p, grid, st) : launch_patch<4, 1, 4, 32, false>(p, grid, st);
     if (c.id == 4) return f32 ? launch_patch<2, 2, 3, 16, true>(p, grid, st) : launch_patch<2, 2, 3, 16, false>(p, grid, st);
     if (c.id == 5) return f32 ? launch_patch<2, 2, 4, 16, true>(p, grid, st) : launch_patch<2, 2, 4, 16, false>(p, grid, st);
@@ -937,10 +1156,13 @@ extern "C" int64_t vn_conv_stats_slab_rows(const vnConv *g) {
 
 // Which kernel / tile vn_conv_gather_gemm picks for a geometry (tests assert that the production instantiations are
 // the ones compared with the oracle): 100 + patch tile id (k_conv_patch: 0 = 10x16, 1 = 8x32, 2 = 4x16, 3 = 6x32,
-// 4 = 6x16, 5 = 8x16 pixels) or the k_gather_gemm tile id (0 = 256x64, 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 160x128).
+// 4 = 6x16, 5 = 8x16 pixels), 120 + weight stages (k_conv_patch2d, 4x16 pixels) or the k_gather_gemm tile id (0 = 256x64,
+// 1 = 128x128, 2 = 64x128, 3 = 64x64, 4 = 160x128).
 extern "C" int32_t vn_conv_plan_id(const vnConv *g) {
     if (!g || g->divD < 1 || g->divH < 1 || g->divW < 1 || g->B <= 0) return -1;
     const PatchCfg pc = patch_config(g);          // (depth residue classes are fine for the patch kernel)
+    if (pc.id == 2 && g->Ds == 1 && g->Dr == 1 && g->kD == 1 && g->divD == 1 && patch2d_stages() >= 3)
+        return 120 + patch2d_stages();            // k_conv_patch2d (4x16 pixels, deep weight pipeline): 123
     if (pc.id >= 0) return 100 + pc.id;
     const int64_t qd = vn_ceil_div(g->Dr, g->divD), qh = vn_ceil_div(g->Hr, g->divH), qw = vn_ceil_div(g->Wr, g->divW);
     const int nd = g->divD < g->Dr ? g->divD : g->Dr, nh = g->divH < g->Hr ? g->divH : g->Hr, nw = g->divW < g->Wr ? g->divW : g->Wr;
