@@ -483,6 +483,33 @@ int vn_bn_bwd_reduce_slab_flagged(const void *da, vnDtype da_dtype, int64_t da_s
 int vn_bn_bwd_apply_list(const void *da, vnDtype da_dtype, const void *y, vnDtype y_dtype, int32_t C, int32_t D,
                          int32_t H, int32_t W, const float *stats, const float *coef, int32_t relu, void *dy,
                          vnDtype dy_dtype, const int64_t *list, const int32_t *count, int64_t cap, vnStream stream);
+
+/* BatchNorm backward of a layer whose output y is the constant inactive[c] outside a site list (the first middle layer,
+ * model.py:207 + 142 over the sparse grid of model.py:102-106) WITHOUT the dense gradient of its activation: da_rows is
+ * the next layer's data gradient at the listed sites only ([cap][C], list order: vn_conv_gather_gemm_rows with
+ * out_linear) and total[c] its sum over ALL sites (vn_dgrad_total).  reduce_list: slab [vn_bn_bwd_list_slab_rows][3][C];
+ * finalize_list: coef / d_gamma / d_beta as vn_bn_bwd_finalize_slab; apply_list_rows: dy at the listed sites (dense
+ * addressing) as vn_bn_bwd_apply_list.  Same sums as the dense passes (tests/test_gpu_layers.py). */
+int64_t vn_bn_bwd_list_slab_rows(int64_t cap, int32_t C);
+int vn_bn_bwd_reduce_list(const void *da_rows, vnDtype da_dtype, const void *y, vnDtype y_dtype, int32_t C, int32_t D,
+                          int32_t H, int32_t W, const float *stats, int32_t relu, float *slab, const int64_t *list,
+                          const int32_t *count, int64_t cap, vnStream stream);
+int vn_bn_bwd_finalize_list(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *gamma,
+                            const float *stats, const float *total, const float *inactive, vnDtype y_dtype,
+                            int32_t relu, float *coef, float *d_gamma, float *d_beta, vnStream stream);
+int vn_bn_bwd_apply_list_rows(const void *da_rows, vnDtype da_dtype, const void *y, vnDtype y_dtype, int32_t C, int32_t D,
+                              int32_t H, int32_t W, const float *stats, const float *coef, int32_t relu, void *dy,
+                              vnDtype dy_dtype, const int64_t *list, const int32_t *count, int64_t cap, vnStream stream);
+/* total[ci] = the sum over ALL input sites of the data gradient of a 3x3x(kD) convolution (stride 1 and padding 1 in
+ * H/W, stride 1 and no padding in D; weight w = the torch (Co,Ci,kD,3,3) fp32 tensor, rounded to bf16 when dy is bf16
+ * as the data-gradient kernels read it) — from nine box sums of its dense output gradient dy (B,D,H,W,Co) instead of
+ * the dense data gradient (ConvMD backward, model.py:111-167).  dy_sums_to_zero != 0: dy comes out of a train-mode
+ * BatchNorm backward (model.py:142), whose per-channel sum over all sites is zero in exact arithmetic: it is taken as
+ * zero and only the edge rows / columns of dy are read. */
+size_t vn_dgrad_total_workspace_bytes(int32_t Co);
+int vn_dgrad_total(const void *dy, vnDtype dy_dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co, int32_t Ci,
+                   int32_t kD, const float *w, int32_t dy_sums_to_zero, void *workspace, size_t workspace_bytes,
+                   float *total, vnStream stream);
 /* Row-flag variant for the first middle layer: row_flags = the uint8 site flags vn_active_sites leaves at the head
  * of its workspace ((B,Dr,Hr,Wr) order, 1 = some occupied voxel in the receptive field).  Rows with flag 0 are
  * skipped: that layer's weight- and data-gradient (the row-list kernels) only gather dy at flagged sites. */

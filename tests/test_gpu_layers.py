@@ -322,3 +322,100 @@ def test_first_layer_sparse_batchnorm_passes_equal_the_dense_ones(dt):
               part.data_ptr(), vdt, lst.data_ptr(), cnt.data_ptr(), cap, E.stream())
     f = flags.bool()
     assert torch.equal(part[f], full[f]) and bool((part[~f] == 5.0).all())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_first_layer_batchnorm_backward_from_the_active_sites_only(dt):
+    """vn_dgrad_total + vn_conv_gather_gemm_rows(out_linear) + vn_bn_bwd_reduce_list / _finalize_list / _apply_list_rows: the
+    first middle layer's BatchNorm backward from middle_layer.1's data gradient at the ACTIVE sites only and box sums of
+    middle_layer.1's dy, against the dense route (dense 3x3x3 data gradient -> dense reduce -> finalize -> apply)."""
+    import ctypes
+    import torch.nn.functional as F
+    from voxelnet_amd import _lib, engine as E, net as N
+    DEV = "cuda:0"
+    lib = _lib.load()
+    torch.manual_seed(11)
+    mode = "bf16" if dt == torch.bfloat16 else "fp32"
+    vdt = _lib.VN_BF16 if dt == torch.bfloat16 else _lib.VN_F32
+    B, D0, H, W, C = 2, 5, 20, 24, 64                # a0 grid (middle_layer.0's output); middle_layer.1: D 5 -> 3
+    D1 = D0 - 2
+    M0 = B * D0 * H * W
+    sp = dict(N.layer_table(2))["middle_layer.1"]
+    assert sp.k == (3, 3, 3) and sp.stride == (1, 1, 1) and sp.pad == (0, 1, 1) and sp.cin == 64 and sp.cout == 64
+    w = torch.randn(64, 64, 3, 3, 3, device=DEV) * 0.05
+    wq = w.to(dt).float()                            # what the data-gradient kernels read
+    dy1 = (torch.randn(B, D1, H, W, 64, device=DEV) * 0.5).to(dt)
+    # ---- total over all sites of the data gradient, against conv_transpose3d in float64
+    ws_bytes = lib.vn_dgrad_total_workspace_bytes(64)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=DEV)
+    tot = torch.empty(64, device=DEV)
+    _lib.call("vn_dgrad_total", dy1.data_ptr(), vdt, B, D1, H, W, 64, 64, 3, w.data_ptr(), 0, ws.data_ptr(), ws_bytes,
+              tot.data_ptr(), E.stream())
+    da_ref = F.conv_transpose3d(dy1.double().permute(0, 4, 1, 2, 3), wq.double(), stride=1, padding=(0, 1, 1))   # (B,64,5,H,W)
+    assert da_ref.shape == (B, 64, D0, H, W)
+    tot_ref = da_ref.sum(dim=(0, 2, 3, 4))
+    scale = float(da_ref.abs().sum(dim=(0, 2, 3, 4)).max())
+    assert float((tot.double() - tot_ref).abs().max()) < 2e-6 * scale
+    # dy_sums_to_zero: the same with the per-channel mean of dy removed first (what a BatchNorm backward's output looks like)
+    dyz = (dy1.float() - dy1.float().mean(dim=(0, 1, 2, 3))).to(dt)
+    totz = torch.empty(64, device=DEV)
+    _lib.call("vn_dgrad_total", dyz.data_ptr(), vdt, B, D1, H, W, 64, 64, 3, w.data_ptr(), 1, ws.data_ptr(), ws_bytes,
+              totz.data_ptr(), E.stream())
+    daz = F.conv_transpose3d(dyz.double().permute(0, 4, 1, 2, 3), wq.double(), stride=1, padding=(0, 1, 1))
+    # (the rounded dyz sums to rounding noise, not to zero: that noise is what the flag drops; bound = its size through the taps)
+    noise = float(dyz.double().sum(dim=(0, 1, 2, 3)).abs().max()) * 27 * 64 * float(wq.abs().max())
+    assert float((totz.double() - daz.sum(dim=(0, 2, 3, 4))).abs().max()) < 2e-6 * scale + noise
+    # ---- the dense route
+    x_dy = E.Rows(dy1, 64)
+    wpd = E.pack_weight(w, sp, 1, mode)
+    dense = E.Rows(torch.empty(B, D0, H, W, 64, dtype=dt, device=DEV), 64)
+    b = ((1, 1, 1), (-1, -1, -1), tuple(-p for p in sp.pad), sp.stride)
+    E.gather_gemm(x_dy, wpd, None, dense, sp.k, 64, 64, *b, (D0, H, W))
+    da = dense.t.reshape(M0, 64)
+    assert float((da.double() - da_ref.permute(0, 2, 3, 4, 1).reshape(M0, 64)).abs().max()) < (3e-2 if dt == torch.bfloat16 else 1e-4)
+    bias = torch.randn(C, device=DEV) * 0.3
+    flags = (torch.rand(M0, device=DEV) < 0.12).to(torch.uint8)
+    y = (torch.randn(M0, C, device=DEV) * 1.5).to(dt)
+    y[flags == 0] = bias.to(dt)
+    stats = torch.cat([torch.randn(C) * 0.2, torch.rand(C) + 0.5, torch.rand(C) + 0.5, torch.randn(C) * 0.2]).to(DEV)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    rows = lib.vn_bn_bwd_slab_rows(M0, C)
+    s0 = torch.empty((rows, 2, C), device=DEV)
+    _lib.call("vn_bn_bwd_reduce_slab", da.data_ptr(), vdt, C, y.data_ptr(), vdt, C, M0, C, stats.data_ptr(), 1, s0.data_ptr(),
+              E.stream())
+    coef0, dg0, db0 = torch.empty(3 * C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.call("vn_bn_bwd_finalize_slab", s0.data_ptr(), rows, M0, C, gamma.data_ptr(), stats.data_ptr(), coef0.data_ptr(),
+              dg0.data_ptr(), db0.data_ptr(), E.stream())
+    full = torch.empty_like(y)
+    _lib.call("vn_bn_bwd_apply", da.data_ptr(), vdt, C, y.data_ptr(), vdt, C, M0, C, stats.data_ptr(), coef0.data_ptr(), 1,
+              full.data_ptr(), vdt, C, 0, E.stream())
+    # ---- the list route
+    idx = torch.nonzero(flags).flatten()
+    n = int(idx.numel())
+    lst = torch.stack([idx // (D0 * H * W), (idx // (H * W)) % D0, (idx // W) % H, idx % W], 1).contiguous()
+    cap = n + 53
+    lst = torch.cat([lst, torch.zeros((53, 4), dtype=torch.int64, device=DEV)])
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    dac = torch.full((cap, 64), 7.0, dtype=dt, device=DEV)
+    g = E._geom(B, x_dy, (D0, H, W), 64, 0, 64, sp.k, *b, (0, 0, 0, 64))
+    _lib.call("vn_conv_gather_gemm_rows", dy1.data_ptr(), wpd.data_ptr(), None, dac.data_ptr(), vdt, ctypes.byref(g), lst.data_ptr(),
+              cap, cnt.data_ptr(), 1, None, E.stream())
+    assert torch.equal(dac[:n], da[idx])             # same kernel arithmetic on the same rows
+    lrows = lib.vn_bn_bwd_list_slab_rows(cap, C)
+    s1 = torch.empty((lrows, 3, C), device=DEV)
+    _lib.call("vn_bn_bwd_reduce_list", dac.data_ptr(), vdt, y.data_ptr(), vdt, C, D0, H, W, stats.data_ptr(), 1, s1.data_ptr(),
+              lst.data_ptr(), cnt.data_ptr(), cap, E.stream())
+    coef1, dg1, db1 = torch.empty(3 * C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    # (total of the kernel-produced dense gradient for the comparison with the dense route: isolates the list kernels from the
+    #  rounding of the dense gradient's elements; the box-sum total was checked against float64 above)
+    tot_k = da.double().sum(0).float()
+    _lib.call("vn_bn_bwd_finalize_list", s1.data_ptr(), lrows, M0, C, gamma.data_ptr(), stats.data_ptr(), tot_k.data_ptr(),
+              bias.data_ptr(), vdt, 1, coef1.data_ptr(), dg1.data_ptr(), db1.data_ptr(), E.stream())
+    sc = float(da.float().abs().sum(0).max())
+    assert float((dg1 - dg0).abs().max()) < 2e-5 * sc * 3 and float((db1 - db0).abs().max()) < 2e-5 * sc
+    assert torch.allclose(coef1, coef0, rtol=1e-4, atol=2e-5 * sc / M0)
+    part = torch.full_like(y, 5.0)
+    _lib.call("vn_bn_bwd_apply_list_rows", dac.data_ptr(), vdt, y.data_ptr(), vdt, C, D0, H, W, stats.data_ptr(), coef0.data_ptr(), 1,
+              part.data_ptr(), vdt, lst.data_ptr(), cnt.data_ptr(), cap, E.stream())
+    f = flags.bool()
+    assert torch.equal(part[f], full[f]) and bool((part[~f] == 5.0).all())

@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_list(const void *__restric
                                                            const float *__restrict__ stats, const float *__restrict__ coef,
                                                            int relu, void *__restrict__ dy, int dydt,
                                                            const int64_t *__restrict__ list, const int32_t *__restrict__ count,
-                                                           int64_t cap) {
+                                                           int64_t cap, int da_compact) {
     const int groups = C >> 3, rpb = 256 / groups;
     const int c = (threadIdx.x % groups) << 3, rr = threadIdx.x / groups;
     if (rr >= rpb) return;
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_list(const void *__restric
         const int64_t m = ((rc[0] * D + rc[1]) * H + rc[2]) * W + rc[3];
         float yv[8], dv[8], o[8];
         load8(y, ydt, m * C + c, yv);
-        load8(da, dadt, m * C + c, dv);
+        load8(da, dadt, (da_compact ? e : m) * C + c, dv);     // da_compact: row e of a [cap][C] matrix in list order
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float d0 = yv[j] - mean[j];
@@ -432,6 +432,229 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_list(const void *__restric
         }
         store8(dy, dydt, 0, m * C + c, o);
     }
+}
+
+// ---- the first middle layer's BatchNorm backward WITHOUT the dense gradient of its activation ------------------------
+// Its output y holds inactive[c] (the conv bias) at the ~90 % of sites no occupied voxel reaches, and its own gradient
+// kernels read dy at the active sites only.  So the next layer's data gradient `da` is computed at the listed (active)
+// sites only ([cap][C] rows in list order: vn_conv_gather_gemm_rows), and the BatchNorm sums over ALL sites are
+//     sum dz       = sum_active dz       + mask_c          (T_c - sum_active da)
+//     sum dz xhat  = sum_active dz xhat  + mask_c xhat_c   (T_c - sum_active da)
+// (mask_c / xhat_c: ReLU mask and normalised value of the constant inactive[c]) with T_c = the sum of da over ALL
+// sites, which is linear in the next layer's dy:  T = sum_taps W_tap^T . (sum of dy over the sites whose tap target
+// lies inside the grid) — nine box sums of dy (vn_box_col_sums) instead of a dense 3x3x3 data gradient.
+
+// slab[block][3][C]: sum_active dz, sum_active dz*xhat, sum_active da
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce_list(const void *__restrict__ da, int dadt, const void *__restrict__ y,
+                                                            int ydt, int C, int D, int H, int W,
+                                                            const float *__restrict__ stats, int relu,
+                                                            float *__restrict__ slab, const int64_t *__restrict__ list,
+                                                            const int32_t *__restrict__ count, int64_t cap) {
+    __shared__ float red[256 * 24];
+    const int groups = C >> 3, rpb = 256 / groups;
+    const int g = threadIdx.x % groups, c = g << 3, rr = threadIdx.x / groups;
+    int64_t n = count ? (int64_t)count[0] : cap;
+    if (n > cap) n = cap;
+    float mean[8], invstd[8], S[8], be[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { mean[j] = stats[c + j]; invstd[j] = stats[C + c + j]; S[j] = stats[2 * C + c + j]; be[j] = stats[3 * C + c + j]; }
+    float s1[8] = {0}, s2[8] = {0}, s3[8] = {0};
+    if (rr < rpb) {
+        for (int64_t e = (int64_t)blockIdx.x * rpb + rr; e < n; e += (int64_t)gridDim.x * rpb) {
+            const int64_t *rc = list + e * 4;
+            const int64_t m = ((rc[0] * D + rc[1]) * H + rc[2]) * W + rc[3];
+            float yv[8], dv[8];
+            load8(y, ydt, m * C + c, yv);
+            load8(da, dadt, e * C + c, dv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d0 = yv[j] - mean[j];
+                const float z = fmaf(S[j], d0, be[j]);
+                const float dz = (!relu || z > 0.f) ? dv[j] : 0.f;
+                s1[j] += dz;
+                s2[j] += dz * (d0 * invstd[j]);
+                s3[j] += dv[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        red[threadIdx.x * 24 + j] = s1[j];
+        red[threadIdx.x * 24 + 8 + j] = s2[j];
+        red[threadIdx.x * 24 + 16 + j] = s3[j];
+    }
+    __syncthreads();
+    float *row = slab + (size_t)blockIdx.x * 3 * C;
+    for (int t = threadIdx.x; t < groups * 24; t += 256) {
+        const int gg = t / 24, slot = t - gg * 24;
+        float acc = 0.f;
+        for (int r = 0; r < rpb; ++r) acc += red[(r * groups + gg) * 24 + slot];
+        row[(slot >> 3) * C + gg * 8 + (slot & 7)] = acc;
+    }
+}
+
+// one workgroup per channel: the three slab columns in double, then the inactive sites' closed form and the coefficients
+__global__ void __launch_bounds__(256) k_bn_bwd_finalize_list(const float *__restrict__ slab, int rows, int64_t M, int C,
+                                                              const float *__restrict__ gamma, const float *__restrict__ stats,
+                                                              const float *__restrict__ total, const float *__restrict__ inactive,
+                                                              int ydt, int relu, float *__restrict__ coef,
+                                                              float *__restrict__ d_gamma, float *__restrict__ d_beta) {
+    __shared__ double r1[256], r2[256], r3[256];
+    const int c = blockIdx.x;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int r = threadIdx.x; r < rows; r += 256) {
+        a1 += (double)slab[((size_t)r * 3 + 0) * C + c];
+        a2 += (double)slab[((size_t)r * 3 + 1) * C + c];
+        a3 += (double)slab[((size_t)r * 3 + 2) * C + c];
+    }
+    r1[threadIdx.x] = a1; r2[threadIdx.x] = a2; r3[threadIdx.x] = a3;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; r3[threadIdx.x] += r3[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float mean = stats[c], invstd = stats[C + c], Sc = stats[2 * C + c], be = stats[3 * C + c];
+        const float d0 = as_stored(inactive[c], ydt) - mean;           // the same fp32 expressions as the row kernels
+        const float z = fmaf(Sc, d0, be);
+        const double rest = (!relu || z > 0.f) ? (double)total[c] - r3[0] : 0.0;   // sum of dz over the inactive sites
+        const double s1 = r1[0] + rest, s2 = r2[0] + rest * (double)(d0 * invstd);
+        const double n = (double)M;
+        const float S = gamma[c] * invstd;
+        if (d_gamma) d_gamma[c] = (float)s2;
+        if (d_beta) d_beta[c] = (float)s1;
+        coef[c] = S;
+        coef[C + c] = -S * invstd * (float)(s2 / n);
+        coef[2 * C + c] = -S * (float)(s1 / n);
+    }
+}
+
+// Box sums of a dense (B,D,H,W,C) rows tensor per channel: blocks [0, nb) sum all rows (grid-stride; slab[b][C]); blocks
+// nb + k*BOX_EB .. +BOX_EB sum edge k: 0 h=0, 1 h=H-1, 2 w=0, 3 w=W-1, 4..7 the corners (0,0) (0,W-1) (H-1,0) (H-1,W-1)
+// (over all b, d).
+constexpr int BOX_EB = 16;
+__global__ void __launch_bounds__(256) k_box_partials(const void *__restrict__ x, int dt, int B, int D, int H, int W, int C,
+                                                      int nb, float *__restrict__ slab) {
+    __shared__ float red[256 * 8];
+    const int groups = C >> 3, rpb = 256 / groups;
+    const int g = threadIdx.x % groups, c = g << 3, rr = threadIdx.x / groups;
+    float s[8] = {0};
+    if (rr < rpb) {
+        if ((int)blockIdx.x < nb) {
+            const int64_t M = (int64_t)B * D * H * W, step = (int64_t)nb * rpb;
+            int64_t m = (int64_t)blockIdx.x * rpb + rr;
+            for (; m + 3 * step < M; m += 4 * step) {      // four rows in flight
+                float v0[8], v1[8], v2[8], v3[8];
+                load8(x, dt, m * C + c, v0);
+                load8(x, dt, (m + step) * C + c, v1);
+                load8(x, dt, (m + 2 * step) * C + c, v2);
+                load8(x, dt, (m + 3 * step) * C + c, v3);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += (v0[j] + v1[j]) + (v2[j] + v3[j]);
+            }
+            for (; m < M; m += step) {
+                float v[8];
+                load8(x, dt, m * C + c, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += v[j];
+            }
+        } else {
+            const int k = (blockIdx.x - nb) / BOX_EB, part = (blockIdx.x - nb) % BOX_EB;     // BOX_EB blocks share an edge
+            const int len = k < 2 ? W : (k < 4 ? H : 1);
+            const int64_t total = (int64_t)B * D * len;
+            for (int64_t i = (int64_t)part * rpb + rr; i < total; i += (int64_t)BOX_EB * rpb) {
+                const int64_t bd = i / len;
+                const int t = (int)(i - bd * len);
+                int h, w;
+                if (k == 0) { h = 0; w = t; } else if (k == 1) { h = H - 1; w = t; }
+                else if (k == 2) { h = t; w = 0; } else if (k == 3) { h = t; w = W - 1; }
+                else { h = (k & 2) ? H - 1 : 0; w = (k & 1) ? W - 1 : 0; }
+                float v[8];
+                load8(x, dt, ((bd * H + h) * W + w) * C + c, v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += v[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[threadIdx.x * 8 + j] = s[j];
+    __syncthreads();
+    for (int t = threadIdx.x; t < C; t += 256) {
+        float acc = 0.f;
+        for (int r = 0; r < rpb; ++r) acc += red[(r * groups + (t >> 3)) * 8 + (t & 7)];
+        slab[(size_t)blockIdx.x * C + t] = acc;
+    }
+}
+
+// T[ci] = sum over taps (kd,kh,kw) and co of  Box(kh,kw)[co] * w[co][ci][kd][kh][kw]   (w: the torch Conv3d weight, fp32), with
+// Box(kh,kw) = Tot - [kh=0] H0 - [kh=2] H1 - [kw=0] W0 - [kw=2] W1 + the corner both exclusions removed twice: the sum of dy
+// over the sites whose tap target (h + kh - 1, w + kw - 1) lies inside the H x W grid (3x3, stride 1, padding 1 in H/W; every
+// depth tap in range: no padding in D).  One workgroup per input channel ci (every workgroup re-reduces the small slab).
+__global__ void __launch_bounds__(256) k_box_total(const float *__restrict__ slab, int nb, int Co, int Ci, int kD,
+                                                   const float *__restrict__ w, int w_bf16, float *__restrict__ total) {
+    __shared__ double part[4][256];    // [row quarter][co]
+    __shared__ double box[9][256];     // [3*hc + wc][co]: hc / wc 0 = exclude first, 1 = all, 2 = exclude last
+    __shared__ double red[256];
+    const int ci = blockIdx.x;
+    // Tot[co]: nb slab rows, four row quarters in parallel (Co <= 64 per pass of 256 threads; Co <= 256 in all)
+    for (int base = 0; base < Co; base += 64) {
+        const int co = base + (threadIdx.x & 63), q = threadIdx.x >> 6;
+        double a = 0.0;
+        if (co < Co) {
+            int r = q;
+            for (; r + 28 < nb; r += 32) {       // eight loads in flight
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(r + 4 * u) * Co + co];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a += (double)v[u];
+            }
+            for (; r < nb; r += 4) a += (double)slab[(size_t)r * Co + co];
+            part[q][co] = a;
+        }
+    }
+    __syncthreads();
+    for (int co = threadIdx.x; co < Co; co += 256) {
+        const double tot = (part[0][co] + part[1][co]) + (part[2][co] + part[3][co]);
+        double e[8];
+        for (int k = 0; k < 8; ++k) {
+            e[k] = 0.0;
+            for (int j = 0; j < BOX_EB; ++j) e[k] += (double)slab[(size_t)(nb + k * BOX_EB + j) * Co + co];
+        }
+        for (int hc = 0; hc < 3; ++hc)
+            for (int wc = 0; wc < 3; ++wc) {
+                double v = tot;
+                if (hc == 0) v -= e[0];
+                if (hc == 2) v -= e[1];
+                if (wc == 0) v -= e[2];
+                if (wc == 2) v -= e[3];
+                if (hc == 0 && wc == 0) v += e[4];
+                if (hc == 0 && wc == 2) v += e[5];
+                if (hc == 2 && wc == 0) v += e[6];
+                if (hc == 2 && wc == 2) v += e[7];
+                box[hc * 3 + wc][co] = v;
+            }
+    }
+    __syncthreads();
+    double t = 0.0;
+    for (int co = threadIdx.x; co < Co; co += 256) {
+        const float *wp = w + ((size_t)co * Ci + ci) * kD * 9;
+        for (int kd = 0; kd < kD; ++kd)
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float wv = wp[(kd * 3 + kh) * 3 + kw];      // (the data-gradient kernels read bf16-rounded weights)
+                    t += box[kh * 3 + kw][co] * (double)(w_bf16 ? (float)(bf16_t)wv : wv);
+                }
+    }
+    red[threadIdx.x] = t;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total[ci] = (float)red[0];
 }
 
 inline unsigned gs_blocks(int64_t total, int per_block, int cap) {
@@ -659,7 +882,66 @@ extern "C" int vn_bn_bwd_apply_list(const void *da, vnDtype da_dtype, const void
     const int rpb = 256 / (C >> 3);
     k_bn_bwd_apply_list<<<gs_blocks(cap, rpb * 2, 4096), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, y, (int)y_dtype, C, D, H, W,
                                                                                        stats, coef, relu, dy, (int)dy_dtype,
-                                                                                       list, count, cap);
+                                                                                       list, count, cap, 0);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+// ---- BatchNorm backward of a layer whose output is constant outside a site list, from the activation gradient at the
+//      listed sites only (see the comment above k_bn_bwd_reduce_list)
+extern "C" int64_t vn_bn_bwd_list_slab_rows(int64_t cap, int32_t C) {
+    if (cap <= 0 || !rows_ok(C, C) || 256 % (C >> 3) != 0) return 0;
+    return gs_blocks(cap, (256 / (C >> 3)) * 4, 1024);
+}
+extern "C" int vn_bn_bwd_reduce_list(const void *da_rows, vnDtype da_dtype, const void *y, vnDtype y_dtype, int32_t C, int32_t D,
+                                     int32_t H, int32_t W, const float *stats, int32_t relu, float *slab, const int64_t *list,
+                                     const int32_t *count, int64_t cap, vnStream stream) {
+    VN_CHECK_ARG(rows_ok(C, C) && 256 % (C >> 3) == 0 && D > 0 && H > 0 && W > 0 && cap > 0);
+    VN_CHECK_ARG(da_rows && y && stats && slab && list);
+    k_bn_bwd_reduce_list<<<(unsigned)vn_bn_bwd_list_slab_rows(cap, C), 256, 0, vn_stream(stream)>>>(
+        da_rows, (int)da_dtype, y, (int)y_dtype, C, D, H, W, stats, relu, slab, list, count, cap);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+extern "C" int vn_bn_bwd_finalize_list(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *gamma,
+                                       const float *stats, const float *total, const float *inactive, vnDtype y_dtype,
+                                       int32_t relu, float *coef, float *d_gamma, float *d_beta, vnStream stream) {
+    VN_CHECK_ARG(slab && gamma && stats && total && inactive && coef && slab_rows > 0 && M > 0 && C > 0);
+    k_bn_bwd_finalize_list<<<C, 256, 0, vn_stream(stream)>>>(slab, (int)slab_rows, M, C, gamma, stats, total, inactive, (int)y_dtype,
+                                                             relu, coef, d_gamma, d_beta);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+extern "C" int vn_bn_bwd_apply_list_rows(const void *da_rows, vnDtype da_dtype, const void *y, vnDtype y_dtype, int32_t C,
+                                         int32_t D, int32_t H, int32_t W, const float *stats, const float *coef, int32_t relu,
+                                         void *dy, vnDtype dy_dtype, const int64_t *list, const int32_t *count, int64_t cap,
+                                         vnStream stream) {
+    VN_CHECK_ARG(rows_ok(C, C) && 256 % (C >> 3) == 0 && D > 0 && H > 0 && W > 0 && cap >= 0);
+    if (cap == 0) return VN_OK;
+    VN_CHECK_ARG(da_rows && y && stats && coef && dy && list);
+    const int rpb = 256 / (C >> 3);
+    k_bn_bwd_apply_list<<<gs_blocks(cap, rpb * 2, 4096), 256, 0, vn_stream(stream)>>>(da_rows, (int)da_dtype, y, (int)y_dtype, C, D,
+                                                                                       H, W, stats, coef, relu, dy, (int)dy_dtype,
+                                                                                       list, count, cap, 1);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+// total[ci] = sum over ALL sites of the data gradient of a 3x3x(kD) convolution (stride 1 and padding 1 in H/W, no padding in
+// D) with the torch weight w (Co,Ci,kD,3,3) fp32, from box sums of its dense output gradient dy (B,D,H,W,Co); two launches
+extern "C" size_t vn_dgrad_total_workspace_bytes(int32_t Co) { return (size_t)(1024 + 8 * 16) * (size_t)(Co > 0 ? Co : 0) * sizeof(float); }
+extern "C" int vn_dgrad_total(const void *dy, vnDtype dy_dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co, int32_t Ci,
+                              int32_t kD, const float *w, int32_t dy_sums_to_zero, void *workspace, size_t workspace_bytes,
+                              float *total, vnStream stream) {
+    VN_CHECK_ARG(dy && w && workspace && total && B > 0 && D > 0 && H > 1 && W > 1 && kD >= 1 && kD <= 3);
+    VN_CHECK_ARG(rows_ok(Co, Co) && 256 % (Co >> 3) == 0 && Co <= 256 && Ci > 0);
+    if (workspace_bytes < vn_dgrad_total_workspace_bytes(Co)) return VN_EWORKSPACE;
+    // dy_sums_to_zero: dy is the output of a train-mode BatchNorm backward — its sum over all sites is zero per channel in
+    // exact arithmetic (the output of BatchNorm does not change when a constant is added to its input), so only the eight
+    // edge sums are taken (9k rows instead of a pass over the whole tensor)
+    const int nb = dy_sums_to_zero ? 0 : 1024;
+    float *slab = static_cast<float *>(workspace);
+    k_box_partials<<<nb + 8 * BOX_EB, 256, 0, vn_stream(stream)>>>(dy, (int)dy_dtype, B, D, H, W, Co, nb, slab);
+    k_box_total<<<Ci, 256, 0, vn_stream(stream)>>>(slab, nb, Co, Ci, kD, w, dy_dtype == VN_BF16 ? 1 : 0, total);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

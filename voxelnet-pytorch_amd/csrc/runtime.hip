@@ -90,6 +90,7 @@ struct Plan {
     void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes; void *hcs_ws; size_t hcs_ws_bytes;
     // sparse first layer
     int64_t *alist; int32_t *acount; int64_t acap; void *aws; size_t aws_bytes;
+    float *dtot; void *dtot_ws; size_t dtot_ws_bytes; bool list_bwd;   // first layer's BatchNorm backward from the active sites only
     int32_t *igrid; float *rbP;   // rulebook: voxel index grid over the input cells, P[v][tap][64]
     // zeroed regions
     char *zf_begin, *zf_end, *zb_begin, *zb_end;
@@ -137,6 +138,7 @@ vnConv wgrad_geom(const Plan &P, int l, const Rows &x) {
     return geom(x, P.odims[l], sp.cin, sp.cout, sp.k, sp.s, ONE, sp.p, ONE, rs);
 }
 
+int m0_bn_knob();
 bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     if (!c || c->B <= 0 || c->D != 10 || c->H <= 0 || c->W <= 0 || (c->H & 7) || (c->W & 7)) return false;
     if (c->mode != 0 && c->mode != 1) return false;
@@ -239,6 +241,16 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         P->rbP = (float *)A.take(sizeof(float) * (size_t)(K > 0 ? K : 1) * 27 * 64);
         P->slab_rows[0] = vn_rulebook_slab_rows(cap);
         P->slab[0] = (float *)A.take((size_t)P->slab_rows[0] * 2 * P->spec[0].cout * sizeof(float));   // (its own size)
+        P->dtot = (float *)A.take(256 * sizeof(float));
+        P->dtot_ws_bytes = vn_dgrad_total_workspace_bytes(P->spec[1].cout);
+        P->dtot_ws = A.take(P->dtot_ws_bytes);
+    }
+    {   // middle_layer.1's data gradient at middle_layer.0's active sites only + box sums for the BatchNorm totals: needs
+        // its 3x3 taps with stride 1 / padding 1 in H/W and every depth tap in range (stride 1, no padding in D)
+        const Spec &s1 = P->spec[1];
+        P->list_bwd = c->sparse_first && (m0_bn_knob() & 8) && !s1.transposed && s1.k[1] == 3 && s1.k[2] == 3 && s1.k[0] <= 3 &&
+                      s1.s[0] == 1 && s1.s[1] == 1 && s1.s[2] == 1 && s1.p[0] == 0 && s1.p[1] == 1 && s1.p[2] == 1 &&
+                      s1.cin == P->spec[0].cout && s1.cin == 64 && s1.cout <= 256;
     }
     // ---- backward buffers
     P->zb_begin = base ? base + A.off : nullptr;
@@ -448,11 +460,20 @@ __global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
 
 // tuning aid: VN_M0_BN bit 0 flagged forward apply (measured SLOWER than the dense pass, 124 vs 86 us: a per-row flag test
 // in a streaming kernel; off), bit 1 flagged backward reduce (90 vs 102 us), bit 2 list-based backward apply (30 vs 87 us)
+// first middle layer (tuning aid VN_M0_BN, bits): 1 flagged forward apply, 2 flagged backward reduce, 4 list-based backward
+// apply, 8 the BatchNorm backward from the activation gradient at the active sites only (middle_layer.1's data gradient as
+// a row-list launch + box sums)
 int m0_bn_knob() {
-    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 6; }();
+    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 14; }();
     return v;
 }
 
+// tuning aid VN_BOX_ZERO=1: take the sum of middle_layer.1's dy over all sites as zero (the BatchNorm identity) instead of
+// summing it (measured: 509.7 vs 508.7 point-clouds/s — not worth a shortcut that drops the rounding noise of dy)
+int box_zero_total() {
+    static const int v = [] { const char *e = getenv("VN_BOX_ZERO"); return e && *e ? atoi(e) : 0; }();
+    return v;
+}
 int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, vnStream st) {
     return vn_bn_apply(y.ptr, (vnDtype)y.dtype, y.sW, y.M(), C, stats, 1, a.ptr, (vnDtype)a.dtype, a.sW, 0, st);
 }
@@ -637,6 +658,14 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // (no memset: the backward sums are per-workgroup slabs / partial rows written with plain stores)
     const int B = cfg->B;
     const int64_t S = (int64_t)P.hf * P.wf;
+    // timing mode only: the number of active first-layer sites (device-resident; the FLOPs of the row-list launches executed
+    // in this call are reported with it).  A blocking read — never in a timed step.
+    double active_rows = 0.0;
+    if (net->timing && P.list_bwd) {
+        int32_t cnt = 0;
+        VN_HIP(hipMemcpy(&cnt, P.acount, sizeof(cnt), hipMemcpyDeviceToHost));
+        active_rows = cnt < 0 ? 0.0 : (cnt > P.acap ? (double)P.acap : (double)cnt);
+    }
     // packed fp32 weight gradients -> torch layouts: collected here, one launch at the end of the segment.
     // (the data-gradient operand packs were made by vn_net_forward, cfg->training)
     vnUnpackJob unpack[NL + 1];
@@ -777,6 +806,21 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 vn_bn_bwd_apply_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], P.coef[l], 1,
                                     dy.ptr, (vnDtype)dy.dtype, ls));
         } else {
+            if (l == 0 && P.list_bwd) {
+                // da = middle_layer.1's data gradient at the active sites only ([acap][C] rows in list order) + its total
+                const Rows &dac = P.dx[1];
+                const int64_t lrows = vn_bn_bwd_list_slab_rows(P.acap, C);
+                RTT(T_BN_BWD_REDUCE, l, 0.0, 0.0, ls,
+                    vn_bn_bwd_reduce_list(dac.ptr, (vnDtype)dac.dtype, y.ptr, (vnDtype)y.dtype, C, P.odims[0][0], P.odims[0][1],
+                                          P.odims[0][2], P.stats[l], 1, P.bslab[l], P.alist, P.acount, P.acap, ls));
+                RTT(T_BN_FINALIZE, l, 0.0, 12.0 * lrows * C, ls,
+                    vn_bn_bwd_finalize_list(P.bslab[l], lrows, M, C, L[l].gamma, P.stats[l], P.dtot, L[l].bias, (vnDtype)y.dtype, 1,
+                                            P.coef[l], G[l].gamma, G[l].beta, ls));
+                RTT(T_BN_BWD_APPLY, l, 0.0, 0.0, ls,
+                    vn_bn_bwd_apply_list_rows(dac.ptr, (vnDtype)dac.dtype, y.ptr, (vnDtype)y.dtype, C, P.odims[0][0], P.odims[0][1],
+                                              P.odims[0][2], P.stats[l], P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, P.alist,
+                                              P.acount, P.acap, ls));
+            } else {
             if (l == 0 && cfg->sparse_first && (m0_bn_knob() & 2))   // y is the bias at the ~90 % inactive sites: read at the flagged rows only
                 RTT(T_BN_BWD_REDUCE, l, 0.0, 1.1 * rows_bytes(y), ls,
                     vn_bn_bwd_reduce_slab_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C,
@@ -802,6 +846,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 RTT(T_BN_BWD_APPLY, l, 0.0, 3.0 * rows_bytes(y), ls,
                     vn_bn_bwd_apply(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
                                     P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, 0, ls));
+            }
         }
         zj.ptr[zj.n] = G[l].bias; zj.len[zj.n] = C; ++zj.n;          // bias before a train-mode BN: gradient exactly 0
         const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
@@ -814,6 +859,20 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
             RTT(T_CONV_DGRAD, l, 2.0 * K * sp.cin * 27.0 * C, 0.0, ls,
                 vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr, ls));
+            return VN_OK;
+        }
+        if (l == 1 && P.list_bwd) {
+            if (!L[l].weight) return VN_EINVAL;
+            // the layer below is constant outside its active sites: its BatchNorm backward needs this data gradient at those
+            // sites only (a row-list launch into [acap][cin] rows) and its sum over all sites (box sums of dy)
+            RTT(T_MISC, l, 0.0, box_zero_total() ? 0.0 : rows_bytes(dy), ls,
+                vn_dgrad_total(dy.ptr, (vnDtype)dy.dtype, B, P.odims[l][0], P.odims[l][1], P.odims[l][2], C, sp.cin, sp.k[0],
+                               L[l].weight, box_zero_total(), P.dtot_ws, P.dtot_ws_bytes, P.dtot, ls));
+            const int64_t rs[4] = {0, 0, 0, sp.cin};
+            vnConv gl = geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
+            RTT(T_CONV_DGRAD, l, 2.0 * active_rows * taps * sp.cin * C, rows_bytes(dy) + 2.0 * active_rows * sp.cin * P.esz, ls,
+                vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, P.dx[l].ptr, (vnDtype)P.dx[l].dtype, &gl, P.alist, P.acap,
+                                         P.acount, 1, nullptr, ls));
             return VN_OK;
         }
         // data gradient

@@ -150,6 +150,13 @@ SIGNATURES = {
                                               c_vp]),
     "vn_bn_bwd_apply_list": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp,
                                      c_vp, c_i64, c_vp]),
+    "vn_bn_bwd_list_slab_rows": (c_i64, [c_i64, c_i32]),
+    "vn_bn_bwd_reduce_list": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "vn_bn_bwd_finalize_list": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "vn_bn_bwd_apply_list_rows": (c_i32, [c_vp, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32,
+                                          c_vp, c_vp, c_i64, c_vp]),
+    "vn_dgrad_total_workspace_bytes": (c_sz, [c_i32]),
+    "vn_dgrad_total": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_sz, c_vp, c_vp]),
     "vn_bn_bwd_apply_flagged": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32,
                                         c_i64, c_vp, c_vp]),
     "vn_nchw_to_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_vp]),
