@@ -595,6 +595,7 @@ __global__ void __launch_bounds__(256) k_box_partials(const void *__restrict__ x
 __global__ void __launch_bounds__(256) k_box_total(const float *__restrict__ slab, int nb, int Co, int Ci, int kD,
                                                    const float *__restrict__ w, int w_bf16, float *__restrict__ total) {
     __shared__ double part[4][256];    // [row quarter][co]
+    __shared__ double edge[8][256];
     __shared__ double box[9][256];     // [3*hc + wc][co]: hc / wc 0 = exclude first, 1 = all, 2 = exclude last
     __shared__ double red[256];
     const int ci = blockIdx.x;
@@ -615,14 +616,25 @@ __global__ void __launch_bounds__(256) k_box_total(const float *__restrict__ sla
             part[q][co] = a;
         }
     }
+    // the eight edge sums: BOX_EB slab rows each, two edges per row quarter, all loads of an edge issued together
+    for (int base = 0; base < Co; base += 64) {
+        const int co = base + (threadIdx.x & 63), q = threadIdx.x >> 6;
+        if (co < Co)
+            for (int k = 2 * q; k < 2 * q + 2; ++k) {
+                float v[BOX_EB];
+#pragma unroll
+                for (int j = 0; j < BOX_EB; ++j) v[j] = slab[(size_t)(nb + k * BOX_EB + j) * Co + co];
+                double a = 0.0;
+#pragma unroll
+                for (int j = 0; j < BOX_EB; ++j) a += (double)v[j];
+                edge[k][co] = a;
+            }
+    }
     __syncthreads();
     for (int co = threadIdx.x; co < Co; co += 256) {
         const double tot = (part[0][co] + part[1][co]) + (part[2][co] + part[3][co]);
         double e[8];
-        for (int k = 0; k < 8; ++k) {
-            e[k] = 0.0;
-            for (int j = 0; j < BOX_EB; ++j) e[k] += (double)slab[(size_t)(nb + k * BOX_EB + j) * Co + co];
-        }
+        for (int k = 0; k < 8; ++k) e[k] = edge[k][co];
         for (int hc = 0; hc < 3; ++hc)
             for (int wc = 0; wc < 3; ++wc) {
                 double v = tot;

@@ -1128,7 +1128,9 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
                 p.taps[ntap++] = GGTap{i, j, k, (sd.tap[i] * g->kH + sh.tap[j]) * g->kW + sw.tap[k]};
     c.ntaps = ntap;
     p.nclasses = 1;
-    const GGConfig cfg = g->Cr > 64 ? GG_CFG[1] : GG_CFG[0];   // capacity launch: rows are not known on the host
+    // capacity launch: rows are not known on the host.  (tuning aid VN_GG_ROWS_CONFIG: one configuration for every list launch)
+    static const int rows_force = [] { const char *e = getenv("VN_GG_ROWS_CONFIG"); return e && *e ? atoi(e) : -1; }();
+    const GGConfig cfg = rows_force >= 0 && rows_force < 5 ? GG_CFG[rows_force] : (g->Cr > 64 ? GG_CFG[1] : GG_CFG[0]);
     const int64_t tiles_m = vn_ceil_div(row_cap, cfg.BM), tiles_n = vn_ceil_div(g->Cr, cfg.BN);
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1);
     hipStream_t st = vn_stream(stream);
