@@ -250,6 +250,11 @@ int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, const float 
 int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_packed, const vnConv *geom,
                        const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes,
                        vnStream stream);
+/* vn_conv_wgrad_partials over a row list whose length is only known on the device: row_cap = the list's capacity (it
+ * sizes the launch and the chunking), *row_count (device) the valid rows; chunks past the count store zero partials. */
+int vn_conv_wgrad_partials_counted(const void *src, const void *rows, const vnConv *geom, const int64_t *row_list,
+                                   int64_t row_cap, const int32_t *row_count, void *workspace, size_t workspace_bytes,
+                                   int32_t *chunks, vnStream stream);
 /* Active output sites of a forward conv over a sparse input: the ordered (b,d,h,w) list of the sites
  * whose receptive field contains at least one of the K occupied voxel coordinates (coord (K,4) int64
  * [b,z,y,x]).  geom = the conv's forward geometry.  list holds up to cap rows; *count = min(n, cap).
@@ -510,6 +515,19 @@ size_t vn_dgrad_total_workspace_bytes(int32_t Co);
 int vn_dgrad_total(const void *dy, vnDtype dy_dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co, int32_t Ci,
                    int32_t kD, const float *w, int32_t dy_sums_to_zero, void *workspace, size_t workspace_bytes,
                    float *total, vnStream stream);
+/* The sparse route for the WEIGHT gradient of the layer above the first middle layer (ConvMD backward, model.py:111-167,
+ * for middle_layer.1): its input a = relu(BN(y)) is the constant cvec outside the first layer's site list, so
+ *   dW = [weight gradient against the rows a(site) - cvec of the listed sites: vn_act_delta_rows +
+ *         vn_conv_wgrad_partials_counted]  +  cvec (x) box sums of dy  [vn_wgrad_const_add, after the unpack].
+ * vn_box_col_sums: the box-sum half of vn_dgrad_total alone (same workspace layout). */
+int vn_box_col_sums(const void *dy, vnDtype dy_dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co,
+                    void *workspace, size_t workspace_bytes, vnStream stream);
+int vn_act_delta_rows(const void *a, vnDtype a_dtype, int32_t C, int32_t D, int32_t H, int32_t W, const float *stats,
+                      const float *inactive, vnDtype y_dtype, int32_t relu, const int64_t *list, const int32_t *count,
+                      int64_t cap, void *delta_rows, vnDtype delta_dtype, vnStream stream);
+int vn_wgrad_const_add(float *dw, const void *workspace, size_t workspace_bytes, int32_t Co, int32_t Ci, int32_t kD,
+                       const float *stats, const float *inactive, vnDtype y_dtype, vnDtype a_dtype, int32_t relu,
+                       vnStream stream);
 /* Row-flag variant for the first middle layer: row_flags = the uint8 site flags vn_active_sites leaves at the head
  * of its workspace ((B,Dr,Hr,Wr) order, 1 = some occupied voxel in the receptive field).  Rows with flag 0 are
  * skipped: that layer's weight- and data-gradient (the row-list kernels) only gather dy at flagged sites. */

@@ -419,3 +419,75 @@ def test_first_layer_batchnorm_backward_from_the_active_sites_only(dt):
               part.data_ptr(), vdt, lst.data_ptr(), cnt.data_ptr(), cap, E.stream())
     f = flags.bool()
     assert torch.equal(part[f], full[f]) and bool((part[~f] == 5.0).all())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_middle_layer_1_weight_gradient_from_the_active_sites(dt):
+    """a0 = cvec outside the first layer's active sites: dW(middle_layer.1) = [row-list weight gradient of the rows a0 - cvec at
+    the active sites: vn_act_delta_rows + vn_conv_wgrad_partials_counted + unpack]  +  cvec (x) box sums of dy
+    [vn_box_col_sums + vn_wgrad_const_add], against torch's conv weight gradient in float64 on the same operands."""
+    import ctypes
+    from voxelnet_amd import _lib, engine as E, net as N
+    DEV = "cuda:0"
+    lib = _lib.load()
+    torch.manual_seed(21)
+    vdt = _lib.VN_BF16 if dt == torch.bfloat16 else _lib.VN_F32
+    B, D0, H, W, C = 2, 5, 20, 24, 64
+    D1 = D0 - 2
+    M0 = B * D0 * H * W
+    sp = dict(N.layer_table(2))["middle_layer.1"]
+    # the first layer's BatchNorm state, its conv bias and an activation tensor that is relu(BN(bias)) outside the active sites
+    stats = torch.cat([torch.randn(C) * 0.2, torch.rand(C) + 0.5, torch.rand(C) + 0.5, torch.randn(C) * 0.2]).to(DEV)
+    bias = torch.randn(C, device=DEV) * 0.3
+    mean, S, be = stats[:C], stats[2 * C:3 * C], stats[3 * C:]
+    cvec = torch.relu(S * (bias.to(dt).float() - mean) + be).to(dt)           # as k_bn_apply<flagged> writes it
+    flags = torch.rand(M0, device=DEV) < 0.12
+    a0 = cvec.repeat(M0, 1)
+    a0[flags] = (torch.rand(int(flags.sum()), C, device=DEV) * 2.0).to(dt)
+    dy1 = (torch.randn(B, D1, H, W, 64, device=DEV) * 0.5).to(dt)
+    # ---- reference: dW of conv3d(a0, w, stride 1, padding (0,1,1)) in float64
+    x64 = a0.double().reshape(B, D0, H, W, C).permute(0, 4, 1, 2, 3).contiguous().requires_grad_(False)
+    w64 = torch.zeros(64, 64, 3, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    y64 = torch.nn.functional.conv3d(x64, w64, stride=1, padding=(0, 1, 1))
+    y64.backward(dy1.double().permute(0, 4, 1, 2, 3).contiguous())
+    ref = w64.grad
+    # ---- the sparse route
+    idx = torch.nonzero(flags).flatten()
+    n = int(idx.numel())
+    lst = torch.stack([idx // (D0 * H * W), (idx // (H * W)) % D0, (idx // W) % H, idx % W], 1).contiguous()
+    cap = n + 100
+    lst = torch.cat([lst, torch.zeros((100, 4), dtype=torch.int64, device=DEV)])
+    cnt = torch.tensor([n], dtype=torch.int32, device=DEV)
+    drows = torch.full((cap, C), 3.0, dtype=dt, device=DEV)                   # rows past the count are never read
+    _lib.call("vn_act_delta_rows", a0.data_ptr(), vdt, C, D0, H, W, stats.data_ptr(), bias.data_ptr(), vdt, 1, lst.data_ptr(),
+              cnt.data_ptr(), cap, drows.data_ptr(), vdt, E.stream())
+    # (the kernel forms cvec with one fma, this test with a multiply and an add: an ulp of fp32)
+    assert torch.allclose(drows[:n].float(), (a0[idx].float() - cvec.float()).to(dt).float(), rtol=0, atol=2e-2 if dt == torch.bfloat16 else 1e-6)
+    x_dy = E.Rows(dy1, 64)
+    b = ((1, 1, 1), (-1, -1, -1), tuple(-p for p in sp.pad), sp.stride)
+    g = E._geom(B, x_dy, (D0, H, W), 64, 0, 64, sp.k, *b, (0, 0, 0, 64))
+    ws, ws_bytes = E.wgrad_workspace(g, 0, cap, DEV)
+    chunks = ctypes.c_int32(0)
+    _lib.call("vn_conv_wgrad_partials_counted", dy1.data_ptr(), drows.data_ptr(), ctypes.byref(g), lst.data_ptr(), cap,
+              cnt.data_ptr(), ws.data_ptr(), ws_bytes, ctypes.byref(chunks), E.stream())
+    dw = torch.zeros(64, 64, 3, 3, 3, device=DEV)
+    job = (_lib.VnUnpackJob * 1)()
+    job[0].dw_packed, job[0].dw = ws.data_ptr(), dw.data_ptr()
+    job[0].c_out, job[0].c_in, job[0].taps, job[0].mode, job[0].cin_fold = 64, 64, 27, 2, 1
+    job[0].chunks, job[0].chunk_stride = chunks.value, 27 * 64 * 64
+    _lib.call("vn_unpack_wgrads_batch", job, 1, E.stream())
+    bs_bytes = lib.vn_dgrad_total_workspace_bytes(64)
+    bws = torch.empty(bs_bytes, dtype=torch.uint8, device=DEV)
+    _lib.call("vn_box_col_sums", dy1.data_ptr(), vdt, B, D1, H, W, 64, bws.data_ptr(), bs_bytes, E.stream())
+    _lib.call("vn_wgrad_const_add", dw.data_ptr(), bws.data_ptr(), bs_bytes, 64, 64, 3, stats.data_ptr(), bias.data_ptr(), vdt, vdt,
+              1, E.stream())
+    # forward-error bound of an fp32-accumulated sum (plus, in bf16, the rounding of the rows a0 - cvec to bf16: 2^-9 of each)
+    xa = a0.double().abs().reshape(B, D0, H, W, C).permute(0, 4, 1, 2, 3).contiguous()
+    wa = torch.zeros(64, 64, 3, 3, 3, dtype=torch.float64, device=DEV, requires_grad=True)
+    torch.nn.functional.conv3d(xa, wa, stride=1, padding=(0, 1, 1)).backward(dy1.double().abs().permute(0, 4, 1, 2, 3).contiguous())
+    terms = wa.grad
+    err = (dw.double() - ref).abs()
+    tol = (2e-5 if dt == torch.float32 else 6e-4) * terms + 1e-9      # bf16: + half a bf16 ulp of the rows a0 - cvec (12 % of the sites)
+    assert bool((err <= tol).all()), float((err / tol).max())
+    l2 = float((dw.double() - ref).norm() / ref.norm())
+    assert l2 < (1e-5 if dt == torch.float32 else 2e-3), l2

@@ -899,6 +899,89 @@ extern "C" int vn_bn_bwd_apply_list(const void *da, vnDtype da_dtype, const void
     return VN_OK;
 }
 
+namespace {
+
+// value the activation a = relu(BN(y)) holds at the sites where y = inactive[c] (stored in y's dtype), as stored in a's dtype
+__device__ __forceinline__ float inactive_act(const float *stats, const float *inactive, int C, int c, int ydt, int adt, int relu) {
+    const float v = as_stored(inactive[c], ydt);
+    float z = fmaf(stats[2 * C + c], v - stats[c], stats[3 * C + c]);
+    if (relu) z = fmaxf(z, 0.f);
+    return as_stored(z, adt);
+}
+
+// delta[e][:] = a(site e)[:] - (the inactive sites' activation) for the listed sites: the sparse part of an activation that
+// is constant outside the list
+__global__ void __launch_bounds__(256) k_act_delta_rows(const void *__restrict__ a, int adt, int C, int D, int H, int W,
+                                                        const float *__restrict__ stats, const float *__restrict__ inactive,
+                                                        int ydt, int relu, const int64_t *__restrict__ list,
+                                                        const int32_t *__restrict__ count, int64_t cap,
+                                                        void *__restrict__ out, int odt) {
+    const int groups = C >> 3, rpb = 256 / groups;
+    const int c = (threadIdx.x % groups) << 3, rr = threadIdx.x / groups;
+    if (rr >= rpb) return;
+    int64_t n = count ? (int64_t)count[0] : cap;
+    if (n > cap) n = cap;
+    float cv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) cv[j] = inactive_act(stats, inactive, C, c + j, ydt, adt, relu);
+    for (int64_t e = (int64_t)blockIdx.x * rpb + rr; e < n; e += (int64_t)gridDim.x * rpb) {
+        const int64_t *rc = list + e * 4;
+        const int64_t m = ((rc[0] * D + rc[1]) * H + rc[2]) * W + rc[3];
+        float v[8];
+        load8(a, adt, m * C + c, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] -= cv[j];
+        store8(out, odt, 0, e * C + c, v);
+    }
+}
+
+// dw[co][ci][kd][kh][kw] += cvec[ci] * Box(kh,kw)[co]: the weight gradient of a 3x3x(kD) convolution (stride 1, padding 1 in
+// H/W, none in D) against the CONSTANT part cvec of its input, from the box sums of its output gradient (the slab of
+// k_box_partials: see k_box_total).  One workgroup per output channel.
+__global__ void __launch_bounds__(256) k_wgrad_const_add(float *__restrict__ dw, const float *__restrict__ slab, int nb, int Co,
+                                                         int Ci, int kD, const float *__restrict__ stats,
+                                                         const float *__restrict__ inactive, int ydt, int adt, int relu) {
+    __shared__ double red[256];
+    __shared__ double sums[9];         // Tot, then the eight edges
+    __shared__ float box[9];
+    const int co = blockIdx.x;
+    for (int k = 0; k < 9; ++k) {
+        const int r0 = k == 0 ? 0 : nb + (k - 1) * BOX_EB, rn = k == 0 ? nb : BOX_EB;
+        double a = 0.0;
+        for (int r = threadIdx.x; r < rn; r += 256) a += (double)slab[(size_t)(r0 + r) * Co + co];
+        red[threadIdx.x] = a;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) sums[k] = red[0];
+        __syncthreads();
+    }
+    if (threadIdx.x < 9) {
+        const int hc = threadIdx.x / 3, wc = threadIdx.x % 3;
+        double v = sums[0];
+        if (hc == 0) v -= sums[1];
+        if (hc == 2) v -= sums[2];
+        if (wc == 0) v -= sums[3];
+        if (wc == 2) v -= sums[4];
+        if (hc == 0 && wc == 0) v += sums[5];
+        if (hc == 0 && wc == 2) v += sums[6];
+        if (hc == 2 && wc == 0) v += sums[7];
+        if (hc == 2 && wc == 2) v += sums[8];
+        box[threadIdx.x] = (float)v;
+    }
+    __syncthreads();
+    const int per = kD * 9;
+    for (int i = threadIdx.x; i < Ci * per; i += 256) {
+        const int ci = i / per, t = i - ci * per;
+        const float cv = inactive_act(stats, inactive, Ci, ci, ydt, adt, relu);
+        dw[((size_t)co * Ci + ci) * per + t] += cv * box[t % 9];
+    }
+}
+
+}  // namespace
+
 // ---- BatchNorm backward of a layer whose output is constant outside a site list, from the activation gradient at the
 //      listed sites only (see the comment above k_bn_bwd_reduce_list)
 extern "C" int64_t vn_bn_bwd_list_slab_rows(int64_t cap, int32_t C) {
@@ -954,6 +1037,44 @@ extern "C" int vn_dgrad_total(const void *dy, vnDtype dy_dtype, int32_t B, int32
     float *slab = static_cast<float *>(workspace);
     k_box_partials<<<nb + 8 * BOX_EB, 256, 0, vn_stream(stream)>>>(dy, (int)dy_dtype, B, D, H, W, Co, nb, slab);
     k_box_total<<<Ci, 256, 0, vn_stream(stream)>>>(slab, nb, Co, Ci, kD, w, dy_dtype == VN_BF16 ? 1 : 0, total);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+// The box-sum half of vn_dgrad_total on its own (workspace = its slab, reused by vn_wgrad_const_add)
+extern "C" int vn_box_col_sums(const void *dy, vnDtype dy_dtype, int32_t B, int32_t D, int32_t H, int32_t W, int32_t Co,
+                               void *workspace, size_t workspace_bytes, vnStream stream) {
+    VN_CHECK_ARG(dy && workspace && B > 0 && D > 0 && H > 1 && W > 1 && rows_ok(Co, Co) && 256 % (Co >> 3) == 0 && Co <= 256);
+    if (workspace_bytes < vn_dgrad_total_workspace_bytes(Co)) return VN_EWORKSPACE;
+    k_box_partials<<<1024 + 8 * BOX_EB, 256, 0, vn_stream(stream)>>>(dy, (int)dy_dtype, B, D, H, W, Co, 1024,
+                                                                     static_cast<float *>(workspace));
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+// delta_rows[e][:] = a(listed site e)[:] - cvec, cvec[c] = the value a = relu(BN(y)) holds where y = inactive[c]: the sparse
+// part of the first middle layer's activation (model.py:207 + 142 over the sparse grid of model.py:102-106)
+extern "C" int vn_act_delta_rows(const void *a, vnDtype a_dtype, int32_t C, int32_t D, int32_t H, int32_t W, const float *stats,
+                                 const float *inactive, vnDtype y_dtype, int32_t relu, const int64_t *list,
+                                 const int32_t *count, int64_t cap, void *delta_rows, vnDtype delta_dtype, vnStream stream) {
+    VN_CHECK_ARG(rows_ok(C, C) && 256 % (C >> 3) == 0 && D > 0 && H > 0 && W > 0 && cap >= 0);
+    if (cap == 0) return VN_OK;
+    VN_CHECK_ARG(a && stats && inactive && list && delta_rows);
+    const int rpb = 256 / (C >> 3);
+    k_act_delta_rows<<<gs_blocks(cap, rpb * 2, 4096), 256, 0, vn_stream(stream)>>>(a, (int)a_dtype, C, D, H, W, stats, inactive,
+                                                                                    (int)y_dtype, relu, list, count, cap, delta_rows,
+                                                                                    (int)delta_dtype);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+// dw (torch (Co,Ci,kD,3,3) fp32) += the weight gradient against the constant part cvec of the input (see vn_act_delta_rows),
+// from the box sums of the layer's output gradient left in `workspace` by vn_dgrad_total (dy_sums_to_zero = 0) / vn_box_col_sums
+extern "C" int vn_wgrad_const_add(float *dw, const void *workspace, size_t workspace_bytes, int32_t Co, int32_t Ci, int32_t kD,
+                                  const float *stats, const float *inactive, vnDtype y_dtype, vnDtype a_dtype, int32_t relu,
+                                  vnStream stream) {
+    VN_CHECK_ARG(dw && workspace && stats && inactive && Co > 0 && Co <= 256 && Ci > 0 && kD >= 1 && kD <= 3);
+    if (workspace_bytes < vn_dgrad_total_workspace_bytes(Co)) return VN_EWORKSPACE;
+    k_wgrad_const_add<<<Co, 256, 0, vn_stream(stream)>>>(dw, static_cast<const float *>(workspace), 1024, Co, Ci, kD, stats, inactive,
+                                                         (int)y_dtype, (int)a_dtype, relu);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

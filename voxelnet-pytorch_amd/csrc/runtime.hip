@@ -91,6 +91,7 @@ struct Plan {
     // sparse first layer
     int64_t *alist; int32_t *acount; int64_t acap; void *aws; size_t aws_bytes;
     float *dtot; void *dtot_ws; size_t dtot_ws_bytes; bool list_bwd;   // first layer's BatchNorm backward from the active sites only
+    void *drows; bool sparse_w1;   // middle_layer.1's weight gradient: [acap][64] rows a0 - const at the active sites + a rank-1 term
     int32_t *igrid; float *rbP;   // rulebook: voxel index grid over the input cells, P[v][tap][64]
     // zeroed regions
     char *zf_begin, *zf_end, *zb_begin, *zb_end;
@@ -139,6 +140,7 @@ vnConv wgrad_geom(const Plan &P, int l, const Rows &x) {
 }
 
 int m0_bn_knob();
+int box_zero_total();
 bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     if (!c || c->B <= 0 || c->D != 10 || c->H <= 0 || c->W <= 0 || (c->H & 7) || (c->W & 7)) return false;
     if (c->mode != 0 && c->mode != 1) return false;
@@ -250,7 +252,13 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         const Spec &s1 = P->spec[1];
         P->list_bwd = c->sparse_first && (m0_bn_knob() & 8) && !s1.transposed && s1.k[1] == 3 && s1.k[2] == 3 && s1.k[0] <= 3 &&
                       s1.s[0] == 1 && s1.s[1] == 1 && s1.s[2] == 1 && s1.p[0] == 0 && s1.p[1] == 1 && s1.p[2] == 1 &&
-                      s1.cin == P->spec[0].cout && s1.cin == 64 && s1.cout <= 256;
+                      s1.cin == P->spec[0].cout && s1.cin == 64 && s1.cout <= 256 &&
+                      // worth it while the active sites are a minority (their number is only known on the device: the list's
+                      // capacity K * 18 is the bound): the row-list launch re-gathers every tap, the dense kernel stages
+                      // halo patches — at 160k voxels (BASELINE configs[4]) the dense route is 3 % faster
+                      P->acap * 10 <= P->y[0].M() * 3;
+        P->sparse_w1 = P->list_bwd && (m0_bn_knob() & 16) && !box_zero_total();
+        P->drows = P->sparse_w1 ? A.take((size_t)P->acap * 64 * P->esz) : nullptr;
     }
     // ---- backward buffers
     P->zb_begin = base ? base + A.off : nullptr;
@@ -290,6 +298,8 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
             size_t b;
             if (l == 0 && c->sparse_first) {
                 b = ask(P->in_dims[0], sp.cout, sp.cin, sp.k, K > 0 ? K : 1);
+            } else if (l == 1 && P->sparse_w1) {
+                b = ask(P->in_dims[1], sp.cout, sp.cin, sp.k, P->acap);
             } else {   // the real launch geometry: the kernel variant (and its chunking) is chosen from it
                 const Rows xin = dense_rows(nullptr, P->adt, B, P->in_dims[l][0], P->in_dims[l][1], P->in_dims[l][2], sp.cin);
                 const vnConv gw = wgrad_geom(*P, l, xin);
@@ -462,9 +472,9 @@ __global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
 // in a streaming kernel; off), bit 1 flagged backward reduce (90 vs 102 us), bit 2 list-based backward apply (30 vs 87 us)
 // first middle layer (tuning aid VN_M0_BN, bits): 1 flagged forward apply, 2 flagged backward reduce, 4 list-based backward
 // apply, 8 the BatchNorm backward from the activation gradient at the active sites only (middle_layer.1's data gradient as
-// a row-list launch + box sums)
+// a row-list launch + box sums), 16 middle_layer.1's weight gradient from the active sites' rows a0 - const + a rank-1 term
 int m0_bn_knob() {
-    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 14; }();
+    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 30; }();
     return v;
 }
 
@@ -670,6 +680,16 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // (the data-gradient operand packs were made by vn_net_forward, cfg->training)
     vnUnpackJob unpack[NL + 1];
     int nu = 0;
+    int rank1_job = -1;     // index of middle_layer.1's unpack job when its weight gradient took the sparse route
+    // (after the unpack that holds that job: + const (x) box sums of dy, on the same stream)
+    auto after_unpack = [&](int first, int end, vnStream st) -> int {
+        if (rank1_job < first || rank1_job >= end) return VN_OK;
+        const Spec &s1 = P.spec[1];
+        RTT(T_UNPACK, 1, 0.0, 0.0, st,
+            vn_wgrad_const_add(G[1].weight, P.dtot_ws, P.dtot_ws_bytes, s1.cout, s1.cin, s1.k[0], P.stats[0], L[0].bias,
+                               (vnDtype)P.y[0].dtype, (vnDtype)P.a[0].dtype, 1, st));
+        return VN_OK;
+    };
     ZeroJobs zj{};
     // The weight gradient of a layer and its data gradient are independent; on the small late layers either one is
     // 60-140 workgroups on 256 CUs.  With a side stream the weight-gradient launches run beside the main stream's
@@ -740,6 +760,23 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
             RTT(T_WGRAD, l, 2.0 * K * sp.cin * 27.0 * C, 0.0, wstream,
                 vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
+            return VN_OK;
+        }
+        if (l == 1 && P.sparse_w1) {
+            // a0 = const + (rows at the first layer's active sites): the rows' part as a row-list weight gradient (10 % of the
+            // sites), the constant's part = const (x) box sums of dy, added after the unpack (rank1_job)
+            const Rows &a0 = P.a[0];
+            RTT(T_MISC, l, 0.0, 0.0, wstream,
+                vn_act_delta_rows(a0.ptr, (vnDtype)a0.dtype, sp.cin, P.odims[0][0], P.odims[0][1], P.odims[0][2], P.stats[0],
+                                  L[0].bias, (vnDtype)P.y[0].dtype, 1, P.alist, P.acount, P.acap, P.drows, (vnDtype)a0.dtype, wstream));
+            const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
+            const int64_t rs[4] = {0, 0, 0, sp.cin};
+            vnConv gl = geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
+            RTT(T_WGRAD, l, 2.0 * active_rows * taps * sp.cin * C, rows_bytes(dy) + 2.0 * active_rows * sp.cin * P.esz, wstream,
+                vn_conv_wgrad_partials_counted(dy.ptr, P.drows, &gl, P.alist, P.acap, P.acount, P.dwp[l], P.dwp_bytes[l], &wch,
+                                               wstream));
+            rank1_job = nu;
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
             return VN_OK;
         }
@@ -915,6 +952,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         RT(flush());
         if (b == 3 && m0_on_main) RT(fork());     // the first layer's partials come from the main stream
         RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack + u_done, nu - u_done), wstream, vn_unpack_wgrads_batch(unpack + u_done, nu - u_done, wstream));
+        RT(after_unpack(u_done, nu, wstream));
         u_done = nu;
         if (zj.n > z_done) {   // (bias gradients in front of a train-mode BatchNorm: zero; off the main chain)
             ZeroJobs part{};
@@ -944,6 +982,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             if ((l >= L_B1 && l < L_D1) || l == L_B2 || l == L_B3 || l <= L_M2) RT(flush());
             if (l == L_B1 && tail_balance && early_unpack_on) {
                 RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack, nu), wstream, vn_unpack_wgrads_batch(unpack, nu, wstream));
+                RT(after_unpack(0, nu, wstream));
                 u_early = nu;
             }
         }
@@ -960,6 +999,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream
         if (m0_on_main) RT(fork());     // the first layer's partials come from the main stream
         RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack + u_early, nu - u_early), wstream, vn_unpack_wgrads_batch(unpack + u_early, nu - u_early, wstream));
+        RT(after_unpack(u_early, nu, wstream));
         if (zj.n > 0) {
             k_zero_many<<<zj.n, 256, 0, ws>>>(zj);
             VN_LAUNCH_STATUS();
@@ -973,6 +1013,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         VN_HIP(hipStreamWaitEvent(hs, e, 0));
     }
     RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack, nu), stream, vn_unpack_wgrads_batch(unpack, nu, stream));
+    RT(after_unpack(0, nu, stream));
     if (zj.n > 0) {
         k_zero_many<<<zj.n, 256, 0, hs>>>(zj);
         VN_LAUNCH_STATUS();

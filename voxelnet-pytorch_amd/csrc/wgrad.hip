@@ -42,6 +42,7 @@ struct WGParams {
     // a plain [n_rows][...] matrix (row index * rW) and the gathered site may be a strided TRANSPOSED one
     const int64_t *row_list;
     int64_t n_rows;
+    const int32_t *row_count;   // device: number of valid list rows (<= n_rows = the list's capacity), or NULL
     int32_t divD, divH, divW;
     // partial sums: chunk c (blockIdx.x) stores its tiles at part + c * part_stride; NULL = a single chunk, which
     // adds into dw itself (one writer per element: no atomics either way)
@@ -90,12 +91,28 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     const int tap0 = blockIdx.y * TPB;          // TPB == 3: the three kW taps of one (kd, kh)
     const int td = tap0 / (p.kH * p.kW), th = (tap0 / p.kW) % p.kH, tw0 = tap0 % p.kW;
     const bool list = p.row_list != nullptr;
-    const int64_t M = list ? p.n_rows : (int64_t)p.B * p.Dr * p.Hr * p.Wr;
-    const int64_t rbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
-    if (rbeg >= M) return;   // (the host sizes the grid so that every chunk has rows)
+    int64_t M = list ? p.n_rows : (int64_t)p.B * p.Dr * p.Hr * p.Wr;
+    if (list && p.row_count) {   // capacity launch: the chunks past the device-side count store all-zero partials
+        const int64_t cnt = (int64_t)p.row_count[0];
+        M = cnt < 0 ? 0 : (cnt < M ? cnt : M);
+    }
+    // counted list: the slabs of ROWS rows are dealt round-robin to the chunks (the launch is sized for the list's capacity;
+    // contiguous ranges would leave the chunks past the count without work)
+    const bool dealt = list && p.row_count;
+    int64_t rbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
+    if (rbeg >= M && !dealt) return;   // (the host sizes the grid so that every chunk has rows)
     int64_t rend = rbeg + p.rows_per_chunk;
     if (rend > M) rend = M;
-    const int nsteps = (int)((rend - rbeg + ROWS - 1) / ROWS);
+    if (rend < rbeg) rend = rbeg;
+    int nsteps = (int)((rend - rbeg + ROWS - 1) / ROWS);
+    int64_t slab_stride = ROWS;        // rows between two consecutive slabs of this chunk
+    if (dealt) {
+        const int64_t nslabs = (M + ROWS - 1) / ROWS;
+        nsteps = (int)(nslabs > blockIdx.x ? (nslabs - blockIdx.x + gridDim.x - 1) / gridDim.x : 0);
+        rbeg = (int64_t)blockIdx.x * ROWS;
+        rend = M;
+        slab_stride = (int64_t)gridDim.x * ROWS;
+    }
     const int nv = p.split ? 3 : 1;
     const int nstages = nsteps * nv;
 
@@ -123,7 +140,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
 #pragma unroll
         for (int j = 0; j < TPB; ++j) so[j] = WG_OOB;
         if (list) {
-            const int64_t m = rbeg + (int64_t)step * ROWS + lane;
+            const int64_t m = rbeg + (int64_t)step * slab_stride + lane;
             if (m < rend && lane < ROWS) {
                 const int64_t *rc = p.row_list + m * 4;
                 const int b = (int)rc[0];
@@ -218,9 +235,9 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
     // transposed-read lane geometry: lane = 16g + 4q + pp -> row (8g + q [+4]), 8-B piece pp of a 16-column tile
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
 
-    if (wave == 0) table_write(0);
+    if (wave == 0 && nstages > 0) table_write(0);
     __syncthreads();
-    stage(0, 0);
+    if (nstages > 0) stage(0, 0);
     if (wave == 0 && nstages > 1) table_write(1);
     for (int s = 0; s < nstages; ++s) {
         const int buf = s & 1;
@@ -546,7 +563,7 @@ int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
 
 static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
                       const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes, vnStream stream,
-                      int32_t *chunks_out = nullptr);
+                      int32_t *chunks_out = nullptr, const int32_t *row_count = nullptr);
 
 // tiling of one weight-gradient problem (shared by the launcher and the workspace query)
 struct WGPlan {
@@ -664,6 +681,16 @@ extern "C" int vn_conv_wgrad_partials(const void *src, const void *rows, const v
                       workspace_bytes, stream, chunks);
 }
 
+// vn_conv_wgrad_partials over a row list whose length is only known on the device: row_cap = the list's capacity (sizes
+// the launch and the chunking), *row_count (device) the valid rows; chunks past the count store all-zero partials.
+extern "C" int vn_conv_wgrad_partials_counted(const void *src, const void *rows, const vnConv *g, const int64_t *row_list,
+                                              int64_t row_cap, const int32_t *row_count, void *workspace,
+                                              size_t workspace_bytes, int32_t *chunks, vnStream stream) {
+    VN_CHECK_ARG(chunks && workspace && row_list && row_count && row_cap > 0);
+    return wgrad_impl(src, rows, static_cast<float *>(workspace), g, 0, row_list, row_cap, workspace, workspace_bytes, stream,
+                      chunks, row_count);
+}
+
 extern "C" int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_packed, const vnConv *g,
                                   const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes,
                                   vnStream stream) {
@@ -674,7 +701,7 @@ extern "C" int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_p
 
 static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
                       const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes, vnStream stream,
-                      int32_t *chunks_out) {
+                      int32_t *chunks_out, const int32_t *row_count) {
     const bool partial_only = chunks_out != nullptr;   // leave the chunk partials in the workspace, no reduction
     if (partial_only) dw_packed = static_cast<float *>(workspace);
     VN_CHECK_ARG(src && rows && dw_packed && g);
@@ -719,6 +746,7 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     p.tiles_k = tiles_k;
     p.row_list = row_list;
     p.n_rows = n_rows;
+    p.row_count = row_list ? row_count : nullptr;
     p.divD = g->divD; p.divH = g->divH; p.divW = g->divW;
     const WPPlan wp = wgrad_patch_plan(g, split, row_list != nullptr);
     if (wp.ok && workspace && !(reinterpret_cast<uintptr_t>(workspace) & 15) && !(w.dw_elems & 3) &&

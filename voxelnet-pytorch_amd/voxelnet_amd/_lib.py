@@ -157,6 +157,11 @@ SIGNATURES = {
                                           c_vp, c_vp, c_i64, c_vp]),
     "vn_dgrad_total_workspace_bytes": (c_sz, [c_i32]),
     "vn_dgrad_total": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_sz, c_vp, c_vp]),
+    "vn_box_col_sums": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_sz, c_vp]),
+    "vn_act_delta_rows": (c_i32, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i32,
+                                  c_vp]),
+    "vn_wgrad_const_add": (c_i32, [c_vp, c_vp, c_sz, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "vn_conv_wgrad_partials_counted": (c_i32, [c_vp, c_vp, _P(VnConv), c_vp, c_i64, c_vp, c_vp, c_sz, c_vp, c_vp]),
     "vn_bn_bwd_apply_flagged": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32,
                                         c_i64, c_vp, c_vp]),
     "vn_nchw_to_rows": (c_i32, [c_vp, c_i32, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_vp]),
