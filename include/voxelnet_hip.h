@@ -236,6 +236,14 @@ int vn_conv_wgrad_partials(const void *src, const void *rows, const vnConv *geom
                            const int64_t *row_list, int64_t n_rows, void *workspace,
                            size_t workspace_bytes, int32_t *chunks, vnStream stream);
 
+/* A data-gradient launch (ConvMD backward, model.py:111-167) that also leaves the BatchNorm-backward sums of the layer
+ * BELOW in its epilogue: out = the gradient w.r.t. that layer's activation a = relu(BN(y)); bn_y = that layer's conv
+ * output (same site strides as out), bn_stats its forward statistics [4][Cr] (vn_bn_finalize_slab);
+ * slab[vn_conv_stats_slab_rows(geom)][2][Cr] receives per workgroup sum dz and sum dz*xhat, the rows
+ * vn_bn_bwd_finalize_slab reads — the vn_bn_bwd_reduce_slab launch is saved.  Only the geometries with
+ * vn_conv_plan_id == 123 (small-image 3x3 kernel); VN_EUNSUPPORTED otherwise. */
+int vn_conv_dgrad_bn_bwd(const void *src, const void *w_packed, void *out, vnDtype out_dtype, const vnConv *geom,
+                         const void *bn_y, vnDtype bn_y_dtype, const float *bn_stats, float *slab, vnStream stream);
 /* Row-list ("sparse rows") variants for the first middle layer, whose input grid is ~99 % empty:
  * the produced rows are an explicit list of (b,d,h,w) int64 coordinates instead of the dense
  * (B,Dr,Hr,Wr) grid.  row_count (device int32, may be NULL = row_cap) lets the launch be sized by a

@@ -491,3 +491,54 @@ def test_middle_layer_1_weight_gradient_from_the_active_sites(dt):
     assert bool((err <= tol).all()), float((err / tol).max())
     l2 = float((dw.double() - ref).norm() / ref.norm())
     assert l2 < (1e-5 if dt == torch.float32 else 2e-3), l2
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+@pytest.mark.parametrize("shape", [(100, 88, 128), (50, 44, 256)], ids=["block2", "block3"])
+def test_data_gradient_with_fused_batchnorm_backward_sums(dt, shape):
+    """vn_conv_dgrad_bn_bwd (the small-image 3x3 data gradient with the BatchNorm-backward sums of the layer below in its
+    epilogue) == vn_conv_gather_gemm followed by vn_bn_bwd_reduce_slab: same dx bit for bit, same sums after the finalize"""
+    import ctypes
+    from voxelnet_amd import _lib, engine as E, net as N
+    DEV = "cuda:0"
+    lib = _lib.load()
+    torch.manual_seed(31)
+    mode = "bf16" if dt == torch.bfloat16 else "fp32"
+    vdt = _lib.VN_BF16 if dt == torch.bfloat16 else _lib.VN_F32
+    H, W, C = shape
+    B = 2
+    M = B * H * W
+    sp = dict(N.layer_table(2))["block2.1" if C == 128 else "block3.1"]
+    assert sp.cin == C and sp.cout == C and sp.k == (1, 3, 3)
+    w = torch.randn(C, C, 3, 3, device=DEV) * 0.03
+    wpd = E.pack_weight(w, sp, 1, mode)
+    dy = E.Rows((torch.randn(B, 1, H, W, C, device=DEV) * 0.5).to(dt), C)
+    b = ((1, 1, 1), (-1, -1, -1), tuple(-p for p in sp.pad), sp.stride)
+    dx0 = E.Rows(torch.empty(B, 1, H, W, C, dtype=dt, device=DEV), C)
+    dx1 = E.Rows(torch.empty(B, 1, H, W, C, dtype=dt, device=DEV), C)
+    g = E.gather_geometry(dy, dx0, sp.k, C, C, *b, (1, H, W))
+    assert lib.vn_conv_plan_id(ctypes.byref(g)) == 123
+    y = (torch.randn(M, C, device=DEV) * 1.2).to(dt)                       # the conv output of the layer below
+    stats = torch.cat([torch.randn(C) * 0.2, torch.rand(C) + 0.5, torch.rand(C) + 0.5, torch.randn(C) * 0.2]).to(DEV)
+    gamma = torch.rand(C, device=DEV) + 0.5
+    # ---- two launches
+    _lib.call("vn_conv_gather_gemm", dy.ptr(), wpd.data_ptr(), None, dx0.ptr(), vdt, ctypes.byref(g), 0, None, E.stream())
+    rows0 = lib.vn_bn_bwd_slab_rows(M, C)
+    s0 = torch.empty((rows0, 2, C), device=DEV)
+    _lib.call("vn_bn_bwd_reduce_slab", dx0.ptr(), vdt, C, y.data_ptr(), vdt, C, M, C, stats.data_ptr(), 1, s0.data_ptr(), E.stream())
+    out0 = [torch.empty(3 * C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)]
+    _lib.call("vn_bn_bwd_finalize_slab", s0.data_ptr(), rows0, M, C, gamma.data_ptr(), stats.data_ptr(), out0[0].data_ptr(),
+              out0[1].data_ptr(), out0[2].data_ptr(), E.stream())
+    # ---- one launch
+    rows1 = lib.vn_conv_stats_slab_rows(ctypes.byref(g))
+    s1 = torch.full((rows1, 2, C), float("nan"), device=DEV)
+    _lib.call("vn_conv_dgrad_bn_bwd", dy.ptr(), wpd.data_ptr(), dx1.ptr(), vdt, ctypes.byref(g), y.data_ptr(), vdt, stats.data_ptr(),
+              s1.data_ptr(), E.stream())
+    assert torch.equal(dx0.t, dx1.t)
+    out1 = [torch.empty(3 * C, device=DEV), torch.empty(C, device=DEV), torch.empty(C, device=DEV)]
+    _lib.call("vn_bn_bwd_finalize_slab", s1.data_ptr(), rows1, M, C, gamma.data_ptr(), stats.data_ptr(), out1[0].data_ptr(),
+              out1[1].data_ptr(), out1[2].data_ptr(), E.stream())
+    sc = float(dx0.t.float().abs().sum(dim=(0, 1, 2, 3)).max())
+    for a, bb in zip(out0[1:], out1[1:]):                                  # d_gamma, d_beta: fp32 partials in another grouping
+        assert float((a - bb).abs().max()) < 1e-5 * sc * 3
+    assert torch.allclose(out0[0], out1[0], rtol=1e-4, atol=1e-5 * sc / M)

@@ -50,6 +50,12 @@ struct GGParams {
     const float *bias;
     char *out;
     float *stats;               // [tiles_m][2][N] per-workgroup partial sums, or NULL
+    // data-gradient launches (k_conv_patch2d): stats = the BatchNorm-BACKWARD sums of the layer below instead — its conv
+    // output bn_y (same site layout as out), its forward statistics bn_stats [4][N]: sum dz, sum dz*xhat with
+    // dz = relu-masked out value as stored (what vn_bn_bwd_reduce_slab would read back)
+    const void *bn_y;
+    const float *bn_stats;
+    int32_t bn_y_f32;
     int64_t sB, sD, sH, sW;   // elements
     int64_t oB, oD, oH, oW;
     int32_t B, Ds, Hs, Ws, Do, Ho, Wo;
@@ -86,7 +92,7 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds
 
 // Store one workgroup's accumulators (+bias, optional accumulate) through the per-row offset table otab (LDS, -1 =
 // row not stored) and, if asked, its per-channel sum / sum of squares into stats slab row `tile`.
-template <int WM, int WN, int SM>
+template <int WM, int WN, int SM, bool BNBWD = false>
 __device__ __forceinline__ void gg_store(const GGParams &p, f32x4_t (&acc)[SM][4], char *smem, const int32_t *otab, int64_t tile,
                                          int n0, int wm, int wn, int lane) {
     constexpr int BN = 64 * WN;
@@ -100,6 +106,16 @@ __device__ __forceinline__ void gg_store(const GGParams &p, f32x4_t (&acc)[SM][4
         bias4[0] = bv.x; bias4[1] = bv.y; bias4[2] = bv.z; bias4[3] = bv.w;
     }
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    float bmean[4] = {0.f, 0.f, 0.f, 0.f}, binv[4] = {0.f, 0.f, 0.f, 0.f}, bS[4] = {0.f, 0.f, 0.f, 0.f}, bbe[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (BNBWD) {
+        if (col_ok) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                bmean[j] = p.bn_stats[ncol + j]; binv[j] = p.bn_stats[p.N + ncol + j];
+                bS[j] = p.bn_stats[2 * p.N + ncol + j]; bbe[j] = p.bn_stats[3 * p.N + ncol + j];
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < SM; ++i) {
         const int4 offs = *reinterpret_cast<const int4 *>(otab + wm * (16 * SM) + i * 16 + fq * 4);
@@ -108,12 +124,36 @@ __device__ __forceinline__ void gg_store(const GGParams &p, f32x4_t (&acc)[SM][4
         for (int e = 0; e < 4; ++e) {
             if (o4[e] < 0 || !col_ok) continue;
             float v[4];
+            if constexpr (BNBWD) {
+                // (no bias, no accumulate on this path: checked on the host)  dz of the rounded value, as the separate pass reads it
+                float yv[4];
+                if (p.bn_y_f32) {
+                    const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p.bn_y) + (int64_t)o4[e] + ncol);
+                    yv[0] = t.x; yv[1] = t.y; yv[2] = t.z; yv[3] = t.w;
+                } else {
+                    const bf16x4_t t = *reinterpret_cast<const bf16x4_t *>(reinterpret_cast<const bf16_t *>(p.bn_y) + (int64_t)o4[e] + ncol);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) yv[j] = (float)t[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float a = acc[i][j][e];
+                    v[j] = a;
+                    const float st = p.out_f32 ? a : (float)(bf16_t)a;
+                    const float d0 = yv[j] - bmean[j];
+                    const float z = fmaf(bS[j], d0, bbe[j]);
+                    const float dz = z > 0.f ? st : 0.f;
+                    s1[j] += dz;
+                    s2[j] += dz * (d0 * binv[j]);
+                }
+            } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float a = acc[i][j][e];
                 s1[j] += a;
                 s2[j] += a * a;
                 v[j] = a + bias4[j];
+            }
             }
             if (p.out_f32) {
                 float4 *dst = reinterpret_cast<float4 *>(reinterpret_cast<float *>(p.out) + (int64_t)o4[e] + ncol);
@@ -861,7 +901,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch2d(const GGParams p) {
         otab[r] = off;
     }
     __syncthreads();
-    gg_store<WM, WN, SM>(p, acc, smem, otab, tile, n0, wm, wn, lane);
+    if (p.bn_y) gg_store<WM, WN, SM, true>(p, acc, smem, otab, tile, n0, wm, wn, lane);
+    else gg_store<WM, WN, SM>(p, acc, smem, otab, tile, n0, wm, wn, lane);
 }
 
 inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
@@ -1171,9 +1212,32 @@ extern "C" int32_t vn_conv_plan_id(const vnConv *g) {
     return gg_config((int64_t)g->B * qd * qh * qw, g->Cr, nd * nh * nw).id;   // largest class x number of classes
 }
 
+static int gather_gemm_impl(const void *src, const void *w_packed, const float *bias, void *out, vnDtype out_dtype,
+                            const vnConv *g, int32_t accumulate, float *stats_slab, vnStream stream, const void *bn_y,
+                            vnDtype bn_y_dtype, const float *bn_stats);
+
 extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const float *bias, void *out,
                                    vnDtype out_dtype, const vnConv *g, int32_t accumulate, float *stats_slab,
                                    vnStream stream) {
+    return gather_gemm_impl(src, w_packed, bias, out, out_dtype, g, accumulate, stats_slab, stream, nullptr, VN_BF16, nullptr);
+}
+
+// A data-gradient launch that also leaves the BatchNorm-BACKWARD sums of the layer BELOW in its epilogue: out = the
+// gradient w.r.t. that layer's activation a = relu(BN(y)); slab[vn_conv_stats_slab_rows(g)][2][Cr] receives, per workgroup,
+// sum dz and sum dz*xhat (dz = the relu-masked out value as stored) — the rows vn_bn_bwd_finalize_slab reads, i.e. the
+// vn_bn_bwd_reduce_slab launch (ConvMD backward, model.py:142-166) is saved.  Only for the geometries of the small-image
+// 3x3 kernel (vn_conv_plan_id 123); VN_EUNSUPPORTED otherwise (use the two calls).
+extern "C" int vn_conv_dgrad_bn_bwd(const void *src, const void *w_packed, void *out, vnDtype out_dtype, const vnConv *g,
+                                    const void *bn_y, vnDtype bn_y_dtype, const float *bn_stats, float *slab,
+                                    vnStream stream) {
+    VN_CHECK_ARG(bn_y && bn_stats && slab && g);
+    if (vn_conv_plan_id(g) != 123) return VN_EUNSUPPORTED;
+    return gather_gemm_impl(src, w_packed, nullptr, out, out_dtype, g, 0, slab, stream, bn_y, bn_y_dtype, bn_stats);
+}
+
+static int gather_gemm_impl(const void *src, const void *w_packed, const float *bias, void *out, vnDtype out_dtype,
+                            const vnConv *g, int32_t accumulate, float *stats_slab, vnStream stream, const void *bn_y,
+                            vnDtype bn_y_dtype, const float *bn_stats) {
     VN_CHECK_ARG(src && w_packed && out && g);
     VN_CHECK_ARG(g->B > 0 && g->Ds > 0 && g->Hs > 0 && g->Ws > 0 && g->Dr > 0 && g->Hr > 0 && g->Wr > 0);
     VN_CHECK_ARG(g->kD >= 1 && g->kD <= 4 && g->kH >= 1 && g->kH <= 4 && g->kW >= 1 && g->kW <= 4);
@@ -1203,6 +1267,9 @@ extern "C" int vn_conv_gather_gemm(const void *src, const void *w_packed, const 
     p.bias = bias;
     p.out = static_cast<char *>(out);
     p.stats = stats_slab;
+    p.bn_y = bn_y;
+    p.bn_stats = bn_stats;
+    p.bn_y_f32 = bn_y_dtype == VN_F32;
     p.sB = g->src_sB; p.sD = g->src_sD; p.sH = g->src_sH; p.sW = g->src_sW;
     p.oB = g->out_sB; p.oD = g->out_sD; p.oH = g->out_sH; p.oW = g->out_sW;
     p.B = g->B; p.Ds = g->Ds; p.Hs = g->Hs; p.Ws = g->Ws;

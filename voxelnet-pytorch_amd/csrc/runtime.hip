@@ -480,6 +480,10 @@ int m0_bn_knob() {
 
 // tuning aid VN_BOX_ZERO=1: take the sum of middle_layer.1's dy over all sites as zero (the BatchNorm identity) instead of
 // summing it (measured: 509.7 vs 508.7 point-clouds/s — not worth a shortcut that drops the rounding noise of dy)
+int fuse_bwd_reduce_on() {   // tuning aid VN_FUSE_BWD_REDUCE=0: every BatchNorm backward reduction as its own launch
+    static const int v = [] { const char *e = getenv("VN_FUSE_BWD_REDUCE"); return e && *e ? atoi(e) : 1; }();
+    return v;
+}
 int box_zero_total() {
     static const int v = [] { const char *e = getenv("VN_BOX_ZERO"); return e && *e ? atoi(e) : 0; }();
     return v;
@@ -814,6 +818,8 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     const bool bucket_mode = ws != hs && cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
     const bool m0_on_main = (tail_balance || bucket_mode) && m0_main_on;
     int u_early = 0;
+    int64_t fused_rows[NL] = {0};      // > 0: layer's BatchNorm-backward slab was written by the data gradient above it (rows)
+    const bool single_call = seg_begin == 0 && seg_end == NL + 1;
     // one layer of the backward: BatchNorm backward and data gradient on `ls`, weight gradient on the side stream
     auto do_layer = [&](int l, vnStream ls, bool on_side, bool accumulate) -> int {
         const Spec &sp = P.spec[l];
@@ -862,12 +868,13 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 RTT(T_BN_BWD_REDUCE, l, 0.0, 1.1 * rows_bytes(y), ls,
                     vn_bn_bwd_reduce_slab_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C,
                                                   P.stats[l], 1, P.bslab[l], static_cast<const uint8_t *>(P.aws), L[l].bias, ls));
-            else
+            else if (fused_rows[l] == 0)      // (else: the sums came out of the data-gradient launch of layer l + 1)
             RTT(T_BN_BWD_REDUCE, l, 0.0, 2.0 * rows_bytes(y), ls,
                 vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
                                       P.bslab[l], ls));
-            RTT(T_BN_FINALIZE, l, 0.0, 8.0 * P.bslab_rows[l] * C, ls,
-                vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
+            const int64_t brows = fused_rows[l] > 0 ? fused_rows[l] : P.bslab_rows[l];
+            RTT(T_BN_FINALIZE, l, 0.0, 8.0 * brows * C, ls,
+                vn_bn_bwd_finalize_slab(P.bslab[l], brows, M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
                                         G[l].beta, ls));
             if (l == 0 && cfg->sparse_first && !(m0_bn_knob() & 4))
                 RTT(T_BN_BWD_APPLY, l, 0.0, 0.0, ls,
@@ -921,6 +928,19 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         const int64_t os[4] = {dx.sB, dx.sD, dx.sH, dx.sW};
         vnConv gd = sp.transposed ? geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, os)
                                   : geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, os);
+        // small-image 3x3 layers: the BatchNorm-backward sums of the layer below come out of this launch's epilogue (its
+        // own reduce launch — 4-8 us plus the gap between two dependent launches — is skipped in do_layer(l - 1))
+        const bool below_plain = l >= 2 && l - 1 != L_M2 && l - 1 != L_D1 && l - 1 != L_D2 && l - 1 != L_D3 && l != L_D1 &&
+                                 l != L_D2 && l != L_D3 && !P.spec[l - 1].transposed;
+        if (fuse_bwd_reduce_on() && single_call && !accumulate && !on_side && below_plain && vn_conv_plan_id(&gd) == 123 &&
+            P.y[l - 1].sB == dx.sB && P.y[l - 1].sD == dx.sD && P.y[l - 1].sH == dx.sH && P.y[l - 1].sW == dx.sW &&
+            vn_conv_stats_slab_rows(&gd) <= P.bslab_rows[l - 1]) {
+            RTT(T_CONV_DGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(dy) + 2.0 * rows_bytes(dx), ls,
+                vn_conv_dgrad_bn_bwd(dy.ptr, P.wp_d[l], dx.ptr, (vnDtype)dx.dtype, &gd, P.y[l - 1].ptr, (vnDtype)P.y[l - 1].dtype,
+                                     P.stats[l - 1], P.bslab[l - 1], ls));
+            fused_rows[l - 1] = vn_conv_stats_slab_rows(&gd);
+            return VN_OK;
+        }
         RTT(T_CONV_DGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(dy) + rows_bytes(dx), ls,
             vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr, ls));
         return VN_OK;

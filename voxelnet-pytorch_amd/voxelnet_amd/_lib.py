@@ -123,6 +123,7 @@ SIGNATURES = {
     "vn_bn_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
     "vn_conv_wgrad_workspace_bytes": (c_sz, [_P(VnConv), c_i32, c_i64]),
     "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_sz, c_vp]),
+    "vn_conv_dgrad_bn_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_vp, c_i32, c_vp, c_vp, c_vp]),
     "vn_conv_gather_gemm_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
     "vn_conv_wgrad_partials": (c_i32, [c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp]),
     "vn_conv_wgrad_rows": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_vp, c_i64, c_vp, c_sz, c_vp]),
