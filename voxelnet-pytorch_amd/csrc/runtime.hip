@@ -818,6 +818,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     const bool bucket_mode = ws != hs && cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
     const bool m0_on_main = (tail_balance || bucket_mode) && m0_main_on;
     int u_early = 0;
+    hipEvent_t box_ev = nullptr;       // recorded on the side stream behind the box sums of middle_layer.1's dy
     int64_t fused_rows[NL] = {0};      // > 0: layer's BatchNorm-backward slab was written by the data gradient above it (rows)
     const bool single_call = seg_begin == 0 && seg_end == NL + 1;
     // one layer of the backward: BatchNorm backward and data gradient on `ls`, weight gradient on the side stream
@@ -856,6 +857,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 RTT(T_BN_BWD_REDUCE, l, 0.0, 0.0, ls,
                     vn_bn_bwd_reduce_list(dac.ptr, (vnDtype)dac.dtype, y.ptr, (vnDtype)y.dtype, C, P.odims[0][0], P.odims[0][1],
                                           P.odims[0][2], P.stats[l], 1, P.bslab[l], P.alist, P.acount, P.acap, ls));
+                if (box_ev) VN_HIP(hipStreamWaitEvent(vn_stream(ls), box_ev, 0));    // the totals from the side stream
                 RTT(T_BN_FINALIZE, l, 0.0, 12.0 * lrows * C, ls,
                     vn_bn_bwd_finalize_list(P.bslab[l], lrows, M, C, L[l].gamma, P.stats[l], P.dtot, L[l].bias, (vnDtype)y.dtype, 1,
                                             P.coef[l], G[l].gamma, G[l].beta, ls));
@@ -909,9 +911,20 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             if (!L[l].weight) return VN_EINVAL;
             // the layer below is constant outside its active sites: its BatchNorm backward needs this data gradient at those
             // sites only (a row-list launch into [acap][cin] rows) and its sum over all sites (box sums of dy)
-            RTT(T_MISC, l, 0.0, box_zero_total() ? 0.0 : rows_bytes(dy), ls,
+            // (the box sums are only read by the first layer's finalize, ~120 us down this stream, and by the weight
+            //  gradient's constant part on the side stream: with a side stream they run there, beside the row-list launch)
+            static const int box_side = [] { const char *e = getenv("VN_BOX_SIDE"); return e && *e ? atoi(e) : 1; }();
+            const bool box_on_side = box_side && ws != hs && !on_side && single_call;
+            if (box_on_side) RT(fork());
+            const vnStream bs = box_on_side ? wstream : ls;
+            RTT(T_MISC, l, 0.0, box_zero_total() ? 0.0 : rows_bytes(dy), bs,
                 vn_dgrad_total(dy.ptr, (vnDtype)dy.dtype, B, P.odims[l][0], P.odims[l][1], P.odims[l][2], C, sp.cin, sp.k[0],
-                               L[l].weight, box_zero_total(), P.dtot_ws, P.dtot_ws_bytes, P.dtot, ls));
+                               L[l].weight, box_zero_total(), P.dtot_ws, P.dtot_ws_bytes, P.dtot, bs));
+            if (box_on_side) {
+                box_ev = net->next_event();
+                if (!box_ev) return VN_EINVAL;
+                VN_HIP(hipEventRecord(box_ev, ws));
+            }
             const int64_t rs[4] = {0, 0, 0, sp.cin};
             vnConv gl = geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
             RTT(T_CONV_DGRAD, l, 2.0 * active_rows * taps * sp.cin * C, rows_bytes(dy) + 2.0 * active_rows * sp.cin * P.esz, ls,
