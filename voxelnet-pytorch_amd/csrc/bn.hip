@@ -194,9 +194,46 @@ template <bool FLAGGED>
 __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, int ydt, int64_t ystride, int64_t M, int C,
                                                   const float *__restrict__ stats, int relu, void *__restrict__ a,
                                                   int adt, int64_t astride, int64_t lo_off, int64_t fold,
-                                                  const uint8_t *__restrict__ flags, const float *__restrict__ inactive) {
+                                                  const uint8_t *__restrict__ flags, const float *__restrict__ inactive,
+                                                  int hoist) {
     const int groups = C >> 3;
     const int64_t total = M * groups;
+    {
+        if (256 % groups == 0 && !fold && (FLAGGED || hoist)) {
+            // a thread keeps one group of 8 channels: the activation of an inactive row is computed ONCE (the rows without a
+            // flag — 90 % of the first layer's — are then 16-B stores of it: the pass is a write stream)
+            const int rpb = 256 / groups;
+            const int c = (threadIdx.x % groups) << 3, rr = threadIdx.x / groups;
+            float mean[8], S[8], be[8], cv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                mean[j] = stats[c + j]; S[j] = stats[2 * C + c + j]; be[j] = stats[3 * C + c + j];
+                cv[j] = 0.f;
+                if constexpr (FLAGGED) {
+                    const float z = fmaf(S[j], as_stored(inactive[c + j], ydt) - mean[j], be[j]);
+                    cv[j] = relu ? fmaxf(z, 0.f) : z;
+                }
+            }
+            for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
+                float v[8];
+                bool inact = false;
+                if constexpr (FLAGGED) inact = !flags[m];
+                if (inact) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = cv[j];
+                } else {
+                    load8(y, ydt, m * ystride + c, v);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float z = fmaf(S[j], v[j] - mean[j], be[j]);
+                        v[j] = relu ? fmaxf(z, 0.f) : z;
+                    }
+                }
+                store8(a, adt, lo_off, m * astride + c, v);
+            }
+            return;
+        }
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t m = i / groups;
         const int c = (int)(i - m * groups) << 3;
@@ -687,6 +724,10 @@ inline int apply_epl(int64_t total) {
     const int64_t r = total / (256 * 2048);
     return r < 1 ? 1 : (r > 4 ? 4 : (int)r);
 }
+inline int apply_hoist() {   // tuning aid VN_BN_HOIST: the plain forward apply keeps its per-channel constants in registers
+    static const int v = [] { const char *e = getenv("VN_BN_HOIST"); return e && *e ? atoi(e) : 1; }();
+    return v;
+}
 inline bool rows_ok(int C, int64_t stride) { return C >= 8 && (C & 7) == 0 && C <= 2048 && (stride & 7) == 0; }
 
 }  // namespace
@@ -730,7 +771,7 @@ extern "C" int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t y_stride, int
     VN_CHECK_ARG(y && a && stats);
     k_bn_apply<false><<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
                                                                                           relu, a, (int)a_dtype, a_stride, lo_off, 0,
-                                                                                          nullptr, nullptr);
+                                                                                          nullptr, nullptr, apply_hoist());
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -746,7 +787,7 @@ extern "C" int vn_bn_apply_flagged(const void *y, vnDtype y_dtype, int64_t y_str
     VN_CHECK_ARG(y && a && stats && row_flags && inactive);
     k_bn_apply<true><<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
                                                                                          relu, a, (int)a_dtype, a_stride, 0, 0,
-                                                                                         row_flags, inactive);
+                                                                                         row_flags, inactive, 1);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -854,7 +895,7 @@ extern "C" int vn_bn_apply_bev(const void *y, vnDtype y_dtype, int64_t M, int32_
     VN_CHECK_ARG(M > 0 && rows_ok(C, C) && hw > 0 && M % (2 * hw) == 0 && wide_stride >= 2 * C && (wide_stride & 7) == 0);
     VN_CHECK_ARG(y && a && stats);
     k_bn_apply<false><<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, C, M, C, stats, relu, a,
-                                                                                          (int)a_dtype, wide_stride, 0, hw, nullptr, nullptr);
+                                                                                          (int)a_dtype, wide_stride, 0, hw, nullptr, nullptr, 0);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

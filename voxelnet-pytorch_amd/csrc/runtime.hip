@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
 // apply, 8 the BatchNorm backward from the activation gradient at the active sites only (middle_layer.1's data gradient as
 // a row-list launch + box sums), 16 middle_layer.1's weight gradient from the active sites' rows a0 - const + a rank-1 term
 int m0_bn_knob() {
-    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 30; }();
+    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 31; }();
     return v;
 }
 
