@@ -568,6 +568,14 @@ int vn_col_sums(const void *rows, vnDtype dtype, int64_t stride, int64_t M, int3
  * d_rows = [d_prob * p * (1-p) | d_reg] as f32, bf16 or split bf16 rows */
 /* forward side in one launch: rows16 (B*S,16) fp32 (stride 16) -> prob = sigmoid(rows[:, :2]) (B,2,S), reg (B,14,S) */
 int vn_heads_to_nchw(const float *rows16, int32_t B, int64_t S, float *prob, float *reg, vnStream stream);
+/* The two heads (model.py:276-281) as streaming kernels over the (B*S, 768) bf16 concat rows: forward = product with the
+ * packed [16][768] weight (vn_pack_weight mode 0) + bias + sigmoid on channels 0-1, written straight to prob (B,2,S) /
+ * reg (B,14,S); data gradient = d_rows (M,16) bf16 times the packed [768][16] weight (mode 1) -> d_cat (M,768) bf16.
+ * bf16 only (the fp32 mode keeps vn_conv_gather_gemm + vn_heads_to_nchw). */
+int vn_heads_fwd(const void *cat_rows, int64_t cat_stride, const void *w_packed, const float *bias, int32_t B, int64_t S,
+                 float *prob, float *reg, vnStream stream);
+int vn_heads_dgrad(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, void *d_cat, int64_t d_cat_stride,
+                   int64_t M, vnStream stream);
 int vn_heads_bwd(const float *d_prob /*(B,2,S)*/, const float *d_reg /*(B,14,S)*/,
                  const float *prob /*(B,2,S)*/, int32_t B, int64_t S, void *d_rows, vnDtype d_dtype,
                  int64_t d_stride, int32_t split, vnStream stream);

@@ -492,3 +492,36 @@ def test_bf16_step_vs_fp32_step():
     for k, l2, cos, nrm in table:
         assert cos > (0.9 if ("prob_conv" in k or "reg_conv" in k) else GRAD_COS), (k, l2, cos)
 
+
+
+def test_heads_streaming_kernels():
+    """vn_heads_fwd / vn_heads_dgrad (the two 1x1 heads of model.py:276-281 as streaming kernels over the 768-channel concat)
+    against float64 on the bf16 operands the kernels read: fp32 outputs within the forward-error bound of an fp32 sum, the
+    bf16 data gradient correctly rounded (half a bf16 ulp + accumulation noise), at the full 2 x 200 x 176 map and on a
+    site count that is not a multiple of 16"""
+    from voxelnet_amd import _lib, engine as E
+    for B, S in ((2, 200 * 176), (1, 1003)):
+        M = B * S
+        cat = bf16r(seeded((M, 768), 9100 + S, 0.7))
+        w = bf16r(seeded((16, 768), 9200 + S, 0.05))
+        bias = seeded((16,), 9300 + S, 0.1)
+        cat_d = cat.to(torch.bfloat16).to(DEV)
+        wf = w.to(torch.bfloat16).to(DEV).contiguous()                      # [16][768]: vn_pack_weight mode 0 of the (16,768,1,1) weight
+        wd = w.t().contiguous().to(torch.bfloat16).to(DEV)                  # [768][16]: mode 1
+        prob = torch.full((B, 2, S), float("nan"), device=DEV)
+        reg = torch.full((B, 14, S), float("nan"), device=DEV)
+        _lib.call("vn_heads_fwd", cat_d.data_ptr(), 768, wf.data_ptr(), bias.to(DEV).data_ptr(), B, S, prob.data_ptr(), reg.data_ptr(),
+                  E.stream())
+        lin = cat.double() @ w.double().t() + bias.double()                  # (M,16)
+        terms = cat.double().abs() @ w.double().abs().t() + bias.double().abs()
+        lin_b = lin.reshape(B, S, 16).permute(0, 2, 1)
+        terms_b = terms.reshape(B, S, 16).permute(0, 2, 1)
+        assert_fp32_sum(reg, lin_b[:, 2:], terms_b[:, 2:], "heads reg")
+        p_ref = torch.sigmoid(lin_b[:, :2])
+        assert float((prob.double().cpu() - p_ref).abs().max()) < 1e-6 + 2e-5 * float(terms_b[:, :2].max()) * 0.25
+        # ---- data gradient
+        g = bf16r(seeded((M, 16), 9400 + S, 0.3))
+        g_d = g.to(torch.bfloat16).to(DEV)
+        dcat = torch.full((M, 768), float("nan"), dtype=torch.bfloat16, device=DEV)
+        _lib.call("vn_heads_dgrad", g_d.data_ptr(), 16, wd.data_ptr(), dcat.data_ptr(), 768, M, E.stream())
+        assert_rounded(dcat.float(), (g.double() @ w.double()).numpy(), "heads data gradient")

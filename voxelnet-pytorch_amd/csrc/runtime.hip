@@ -480,6 +480,10 @@ int m0_bn_knob() {
 
 // tuning aid VN_BOX_ZERO=1: take the sum of middle_layer.1's dy over all sites as zero (the BatchNorm identity) instead of
 // summing it (measured: 509.7 vs 508.7 point-clouds/s — not worth a shortcut that drops the rounding noise of dy)
+int heads_stream_on() {   // tuning aid VN_HEADS_STREAM=0: the heads through k_gather_gemm as before
+    static const int v = [] { const char *e = getenv("VN_HEADS_STREAM"); return e && *e ? atoi(e) : 1; }();
+    return v;
+}
 int fuse_bwd_reduce_on() {   // tuning aid VN_FUSE_BWD_REDUCE=0: every BatchNorm backward reduction as its own launch
     static const int v = [] { const char *e = getenv("VN_FUSE_BWD_REDUCE"); return e && *e ? atoi(e) : 1; }();
     return v;
@@ -647,10 +651,15 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
         const int od[3] = {1, P.hf, P.wf};
         vnConv g = fwd_geom(hs16, P.cat, od, P.hy);
         const int64_t S = (int64_t)P.hf * P.wf;
+        if (P.adt == VN_BF16 && heads_stream_on()) {
+            RTT(T_CONV_FWD, NL, 2.0 * cfg->B * S * 768 * 16, rows_bytes(P.cat) + rows_bytes(P.hy), stream,
+                vn_heads_fwd(P.cat.ptr, P.cat.sW, P.hwp_f, heads_b, cfg->B, S, prob, reg, stream));
+        } else {
         RTT(T_CONV_FWD, NL, 2.0 * cfg->B * S * 768 * 16, rows_bytes(P.cat) + rows_bytes(P.hy), stream,
             vn_conv_gather_gemm(P.cat.ptr, P.hwp_f, heads_b, P.hy.ptr, VN_F32, &g, 0, nullptr, stream));
         RTT(T_MISC, NL, 0.0, 2.0 * rows_bytes(P.hy), stream,
             vn_heads_to_nchw(reinterpret_cast<const float *>(P.hy.ptr), cfg->B, S, prob, reg, stream));
+        }
     }
     return VN_OK;
 }
@@ -723,6 +732,10 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
         // the heads' weight gradient goes to the side stream behind ONE fork that also serves the early deconv
         // branches (which need the data gradient): one event record less on the main stream (483 vs 480 pc/s)
+        if (P.adt == VN_BF16 && P.pdt == VN_BF16 && heads_stream_on())
+            RTT(T_CONV_DGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.d_cat), stream,
+                vn_heads_dgrad(P.d_rows.ptr, P.d_rows.sW, P.hwp_d, P.d_cat.ptr, P.d_cat.sW, (int64_t)B * S, stream));
+        else
         RTT(T_CONV_DGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.d_cat), stream,
             vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.pdt, &gd, 0, nullptr, stream));
         RT(fork());

@@ -171,6 +171,8 @@ SIGNATURES = {
     "vn_col_sums_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "vn_col_sums": (c_i32, [c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_sz, c_vp]),
     "vn_heads_to_nchw": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "vn_heads_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "vn_heads_dgrad": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
     "vn_heads_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vn_pack_weights_batch": (c_i32, [c_vp, c_i32, c_vp]),
     "vn_unpack_wgrads_batch": (c_i32, [c_vp, c_i32, c_vp]),
