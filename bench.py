@@ -321,16 +321,15 @@ def main():
 
     # ---- host cost of one step, un-throttled: the enqueue of ONE step into an EMPTY queue (the timed loop's enqueue time is
     #      paced by the GPU: the host runs into the queue's back-pressure), median of 7
-    host_free = None
-    if rank == 0:
-        samples = []
-        for _ in range(7):
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            step_eager()
-            samples.append(time.perf_counter() - th)
+    #      (every rank runs them: a step holds the gradient collectives)
+    samples = []
+    for _ in range(7):
         torch.cuda.synchronize()
-        host_free = 1e3 * sorted(samples)[len(samples) // 2]
+        th = time.perf_counter()
+        step_eager()
+        samples.append(time.perf_counter() - th)
+    torch.cuda.synchronize()
+    host_free = 1e3 * sorted(samples)[len(samples) // 2]
     sync_all()
 
     # ---- per-kernel durations: the native executor's own HIP events around every launch (same path as the timed region),

@@ -13,6 +13,9 @@ python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 cat gpurun_out/final_bench.json
 python bench.py --config ped --no-cpu-baseline > gpurun_out/final_bench_ped.json 2> gpurun_out/final_bench_ped.err
 python bench.py --config dense --no-cpu-baseline > gpurun_out/final_bench_dense.json 2> gpurun_out/final_bench_dense.err
+# the N > 1 code path, rehearsed with two ranks on the one GPU of this box (gloo carries the collective)
+VN_BENCH_SHARE_GPU=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final_bench_n2_rehearsal.json 2> gpurun_out/final_bench_n2_rehearsal.err
+tail -c 600 gpurun_out/final_bench_n2_rehearsal.json
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
 rocprofv3 --kernel-trace --stats -d $O/fstats -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $O/fstats.log 2>&1
