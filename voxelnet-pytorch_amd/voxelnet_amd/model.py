@@ -587,19 +587,27 @@ class _DetectorFn(torch.autograd.Function):
                 D, H, W = fn._grid.dims
                 K = feature.shape[0]
                 cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, 1 if mode == "fp32" else 0, int(training), int(sparse), 0, 0)
-                heads = _heads_params([f.detach() for f in flat[-4:]])
+                side = rpn._side_stream(dev_) if rpn.overlap_wgrad else None
+                if side is not None:
+                    # the (16,768) / (16,) concatenations of the two heads' parameters: two small launches, read first by the
+                    # weight packing on the side stream — issued there, not in front of the VFE forward on the main stream
+                    side_t = rpn.__dict__["_side"]
+                    side_t.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side_t):
+                        heads = _heads_params([f.detach() for f in flat[-4:]])
+                    for t_ in heads.values():
+                        t_.record_stream(torch.cuda.current_stream())
+                else:
+                    heads = _heads_params([f.detach() for f in flat[-4:]])
                 arr, _ = _native_layer_arrays(mid)
                 lib = _lib.load()
                 ws_bytes = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
                 if ws_bytes == 0:
                     raise _lib.VoxelnetHipError("vn_net_workspace_bytes: unsupported network configuration")
                 ws = rpn._ws_acquire(ws_bytes, dev_)
-                side = rpn._side_stream(dev_) if rpn.overlap_wgrad else None
                 if side is not None:
                     # what does not depend on the voxel features (weight packing, the first layer's site list / index
                     # grid / bias fill) runs on the side stream beside the VFE forward
-                    side_t = rpn.__dict__["_side"]
-                    side_t.wait_stream(torch.cuda.current_stream())
                     _lib.call("vn_net_prepare", rpn._net_handle(dev_), ctypes.byref(cfg), arr, heads["weight"].data_ptr(), coord.data_ptr(), K,
                               ws.data_ptr(), ws_bytes, side)
                     cfg.prepared = 1
