@@ -452,7 +452,8 @@ def main():
                     "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": traffic, "avg_launch_us": 1e3 * t / n, "launches_per_step": n / ns,
                     "gflop_per_step": f / ns / 1e9, "ms_per_step": t / ns,
-                    "note": "algorithmic FLOPs (SURVEY.md 8d; the rulebook first layer with its executed FLOPs) / summed "
+                    "note": "algorithmic FLOPs (SURVEY.md 8d; the launches that skip constant data — the rulebook first layer, "
+                            "the row-list data gradients at its active sites — with the FLOPs they execute) / summed "
                             "HIP-event time of every launch of the family, events on the launch's own stream inside the "
                             "native executor, %d steps on the same inputs right after the timed region" % args.timer_steps}
                 # FLOPs the MFMA pipes actually execute in a step (first layer: rulebook, not dense-equivalent)
