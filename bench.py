@@ -456,6 +456,15 @@ def main():
                             "the row-list data gradients at its active sites — with the FLOPs they execute) / summed "
                             "HIP-event time of every launch of the family, events on the launch's own stream inside the "
                             "native executor, %d steps on the same inputs right after the timed region" % args.timer_steps}
+                # the family's largest single symbol: the 6x32-pixel Conv3d tiles (car / dense: middle_layer.1 and .2 forward,
+                # middle_layer.2 data gradient)
+                big = [(ms, fl) for kind, layer, ms, fl, by in recs if (kind == 0 and layer in (1, 2)) or (kind == 1 and layer == 2)]
+                if big:
+                    tb, fb = sum(m for m, _ in big), sum(f_ for _, f_ in big)
+                    res["roofline"]["largest_symbol"] = {
+                        "kernel": "k_conv_patch<4,1,3,32> (64-channel Conv3d layers, 6x32-pixel tiles)",
+                        "launches_per_step": len(big) / ns, "ms_per_step": tb / ns, "achieved": fb / (tb * 1e-3) / 1e12,
+                        "frac": fb / (tb * 1e-3) / 1e12 / peak}
                 # FLOPs the MFMA pipes actually execute in a step (first layer: rulebook, not dense-equivalent)
                 fx = sum(fam.get(k, (0, 0, 0, 0))[2] for k in (0, 1, 2)) / ns
                 res["executed_mfma_flops_fraction_of_peak"] = fx / (1e-3 * res["ms_per_step"]) / (peak * 1e12)
