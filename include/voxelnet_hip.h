@@ -350,6 +350,15 @@ typedef struct {
     int32_t defer_join;      /* backward with a side stream: the last segment does NOT wait for the side stream; the
                               * weight-gradient unpack runs there and the CALLER joins it (stream wait) before anything
                               * reads the weight gradients — lets e.g. the VFE backward run beside the last weight gradients */
+    int32_t grad_storage;    /* bf16 mode only: which tensors of the step are kept in fp32 instead of bf16 (bit set), DESIGN.md §4:
+                              * 1 = the heads' data gradient (the 768-channel concat gradient the three deconvs' BatchNorm
+                              *     backward reads), 2 = every layer's data gradient (the input of the BatchNorm backward below),
+                              * 4 = every conv output y (forward), 8 = the heads' data gradient is computed from the fp32
+                              * (B*S,16) logit gradient and the fp32 head weights (vn_heads_dgrad_f32) instead of their bf16
+                              * roundings.  0 = everything bf16 (the shipped configuration: tools/grad_attribution.py measures
+                              * that none of the four moves a gradient).  fp32 mode: 16 = diagnostic, every activation is rounded
+                              * to the nearest bf16 VALUE (stored fp32; the sparse first-layer backward shortcuts are off) — the
+                              * bf16 forward function with an exact fp32 backward. */
 } vnNetConfig;
 typedef struct {
     const float *weight, *bias, *gamma, *beta;
@@ -576,6 +585,10 @@ int vn_heads_fwd(const void *cat_rows, int64_t cat_stride, const void *w_packed,
                  float *prob, float *reg, vnStream stream);
 int vn_heads_dgrad(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, void *d_cat, int64_t d_cat_stride,
                    int64_t M, vnStream stream);
+/* d_cat (M, 768) rows (fp32 or bf16) = d_rows (M,16) fp32 . w (16,768) fp32 (the torch layout of the two heads' weights,
+ * score rows first), all products and sums in fp32: no operand rounding in front of the three deconvs' BatchNorm backward */
+int vn_heads_dgrad_f32(const float *d_rows, int64_t d_rows_stride, const float *w /*[16][768]*/, void *d_cat,
+                       vnDtype d_cat_dtype, int64_t d_cat_stride, int64_t M, vnStream stream);
 int vn_heads_bwd(const float *d_prob /*(B,2,S)*/, const float *d_reg /*(B,14,S)*/,
                  const float *prob /*(B,2,S)*/, int32_t B, int64_t S, void *d_rows, vnDtype d_dtype,
                  int64_t d_stride, int32_t split, vnStream stream);

@@ -264,3 +264,26 @@ def clip_sgd_step(params, grads, lr=0.01, max_norm=5.0):
     coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
     clipped = [g * coef for g in grads]
     return [p - lr * g for p, g in zip(params, clipped)], clipped, total
+
+
+def train_step(features, coordinates, sd, dims, cls_name, targets, lr=0.01, max_norm=5.0, alpha=1.5, beta=1.0, sigma=3.0):
+    """One iteration of the reference's train loop (train.py:148-155: forward with the loss of model.py:310-352,
+    loss.backward(), clip_grad_norm_(params, max_norm), SGD(lr).step(), zero_grad()) on the state dict `sd`, IN PLACE:
+    parameters updated, BatchNorm running statistics updated by the forward, num_batches_tracked += 1.
+    targets = (pos_equal_one (B,h,w,2), neg_equal_one (B,h,w,2), targets (B,h,w,14)) float tensors, what
+    utils.generate_targets returns at model.py:309.  -> ([loss, cls, reg, cls_pos, cls_neg] floats, total gradient norm)."""
+    keys = param_keys(sd)
+    leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
+    work = dict(sd)
+    work.update(leaves)
+    dense = feature_net(features, coordinates, work, dims, True)
+    prob, reg = middle_rpn(dense, work, cls_name, True)
+    out = rpn_loss(prob, reg, *targets, alpha, beta, sigma)
+    out[0].backward()
+    new, _, total = clip_sgd_step([leaves[k].detach() for k in keys], [leaves[k].grad for k in keys], lr, max_norm)
+    for k, v in zip(keys, new):
+        sd[k] = v
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            sd[k] = sd[k] + 1
+    return [float(v) for v in out], float(total)

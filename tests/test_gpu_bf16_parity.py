@@ -28,7 +28,10 @@ from oracle import torch_ref as tr
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 EPS = 1e-5
-MAP_MAX, MAP_L2, GRAD_L2, GRAD_COS = 0.15, 0.1, 1.5, 0.3    # test_bf16_step_vs_fp32_step (measured: 0.087 / 0.012 / see DESIGN.md §4)
+MAP_MAX, MAP_L2 = 0.15, 0.1             # test_bf16_step_vs_fp32_step, maps (measured: 0.087 / 0.058)
+GRAD_L2, GRAD_COS = 0.8, 0.7            # ... conv / BatchNorm gradients (measured: <= 0.71, >= 0.77)
+VFE_GRAD_L2, VFE_GRAD_COS = 1.3, 0.4    # ... VFE gradients (measured: <= 1.16, >= 0.48)
+FROZEN_L2, FROZEN_COS = 0.05, 0.999    # test_bf16_backward_chain_on_frozen_forward (measured: <= 0.036 / >= 0.9994; convs <= 0.019)
 
 
 def bf16r(t):
@@ -423,10 +426,18 @@ def test_bf16_rulebook_first_layer():
 def test_bf16_step_vs_fp32_step():
     """One full-size car step at B=2 (BASELINE configs[1]) in bf16 — the benchmarked configuration, through the native
     executor — against the same step in the fp32 parity mode (which test_gpu_model.py pins to the oracle at <= 1e-3).
-    Stated bounds (MAP_MAX / MAP_L2 / GRAD_L2 below), relative to the tensor maximum and as relative L2: the 23
-    Conv+BN+ReLU layers each add ~2 bf16 roundings of relative size 2^-9 (rel-L2 1.7e-3 per rounding, measured per layer
-    above) and the stack amplifies per-layer rounding ~20x (measured for the reference's own fp32-vs-fp64 pair, DESIGN.md
-    §4); ReLU-mask flips move the chained gradients of the reference itself by 0.08-0.22 between fp32 and fp64."""
+
+    What the distances below are (round 3, tools/grad_attribution.py + tools/forward_error_profile.py): NOT
+    backward arithmetic.  (i) Promoting any or all of the bf16 mode's gradient tensors (concat gradient, every data
+    gradient, the logit gradient) to fp32 storage changes no gradient distance in the third digit; (ii) the exact fp32
+    kernels produce the same distances once only the conv weights (0.31-0.43 below the deconvs), only the activations
+    (0.33-0.45) or both (0.40-0.52) are rounded to bf16 VALUES; (iii) with the forward frozen the bf16 backward chain is
+    within 0.004-0.036 of an exact backward (test_bf16_backward_chain_on_frozen_forward).  The cause is the FORWARD: this
+    random-weight BatchNorm/ReLU stack amplifies any perturbation ~1.2x per layer (the fp32 mode's own summation-order
+    difference grows 8.6e-8 -> 1.2e-5 over the 23 layers), the bf16 activations are 0.4 % (first layer) ... 10 % (block3)
+    away from the fp32 ones, 0.007 % ... 4.2 % of the ReLU masks differ, and a flipped mask element changes its gradient
+    by 100 %.  The reference's own fp32 and fp64 gradients differ by 0.08-0.22 on this frame for the same reason.
+    Bars: what was measured plus margin; that training in this mode FOLLOWS the reference is tests/test_gpu_trajectory.py."""
     from voxelnet_amd import model as M
     from voxelnet_amd import synth
     from voxelnet_amd.config import grid_config
@@ -457,7 +468,7 @@ def test_bf16_step_vs_fp32_step():
                      {k: p.grad.detach().double().cpu().clone() for k, p in m.named_parameters()}, float(res[2]))
         del m
     print(f"bf16 vs fp32 step, loss: {out['bf16'][3]:.6f} vs {out['fp32'][3]:.6f}")
-    assert abs(out["bf16"][3] - out["fp32"][3]) < 2e-2 * abs(out["fp32"][3])
+    assert abs(out["bf16"][3] - out["fp32"][3]) < 2.5e-2 * abs(out["fp32"][3])      # (measured 1.9e-2: -log(1 - p + 1e-6) at p ~ 1)
     M.set_precision("bf16")
     report = {}
     for i, nm in enumerate(("prob", "reg")):
@@ -482,16 +493,136 @@ def test_bf16_step_vs_fp32_step():
     print("bf16 vs fp32 step, worst parameter gradient rel-L2:", worst)
     for nm, (emax, l2) in report.items():
         assert emax < MAP_MAX and l2 < MAP_L2, (nm, emax, l2)
-    # Gradients.  The RPN loss gradient is almost the same number at every negative anchor (98 % of them), and every
-    # train-mode BatchNorm backward subtracts exactly that common mode: what is left is a few per cent of what was
-    # stored, so the 2^-9 rounding of a bf16-stored gradient tensor is a 10-30 % perturbation of the signal one BatchNorm
-    # further down (heads 0.04-0.08, the three deconvs 0.14-0.30, saturating at 0.5-0.7 in the 20 layers below them;
-    # DESIGN.md §4).  That is a property of bf16 gradient storage, not of a kernel: every kernel of this chain is held to
-    # half a bf16 ulp on its own operands above.  What this test pins is that the directions agree and nothing blows up.
-    assert worst[1] < GRAD_L2, worst
+    # Gradients: see the docstring — the distance is forward-induced (ReLU-mask flips), the bars are measured + margin.
     for k, l2, cos, nrm in table:
-        assert cos > (0.9 if ("prob_conv" in k or "reg_conv" in k) else GRAD_COS), (k, l2, cos)
+        heads, vfe = ("prob_conv" in k or "reg_conv" in k), k.startswith("feature_net")
+        assert l2 < (0.1 if heads else VFE_GRAD_L2 if vfe else GRAD_L2), (k, l2, cos)
+        assert cos > (0.99 if heads else VFE_GRAD_COS if vfe else GRAD_COS), (k, l2, cos)
 
+
+def _car_step_inputs():
+    """two full-size car frames voxelized on the device + the seeded RPN targets of bench.py"""
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import grid_config
+    from voxelnet_amd.voxelize import voxelize_device
+    grid = grid_config("Car")
+    feats, coords = [], []
+    for b, f in enumerate(synth.workload_frames(2, batch=2)):
+        fb, cb, _ = voxelize_device(torch.from_numpy(f).to(DEV), grid, b, coord_cols=4)
+        feats.append(fb)
+        coords.append(cb)
+    rng = np.random.default_rng(99)
+    pos = (rng.random((2, 200, 176, 2)) < 0.002).astype(np.float32)
+    neg = ((rng.random((2, 200, 176, 2)) < 0.98) & (pos == 0)).astype(np.float32)
+    tgt = (rng.standard_normal((2, 200, 176, 14)) * 0.1).astype(np.float32)
+    return feats, coords, tuple(torch.from_numpy(a).to(DEV) for a in (pos, neg, tgt))
+
+
+def _bf16_valued(sd):
+    """conv / deconv / head weights rounded to bf16 VALUES: what the bf16 mode's weight packing reads"""
+    return {k: (v.bfloat16().float() if k.endswith("conv.weight") or k.endswith("deconv.weight") else v) for k, v in sd.items()}
+
+
+def _dead_bias(k):
+    return (k.endswith("conv.bias") and "prob_conv" not in k and "reg_conv" not in k) or k.endswith("deconv.bias")
+
+
+def test_bf16_backward_chain_on_frozen_forward():
+    """The bf16 backward as a CHAIN (heads -> 23 layers -> VFE, full-size car step, B=2): the gradients of the bf16 mode
+    against an exact-fp32 backward (fp32 MFMA kernels, fp32 gradient storage) through THE SAME saved forward — the bf16
+    forward's y / a / statistics cast to fp32, so both backwards see identical ReLU masks and normalised values and
+    differ only in what the bf16 backward rounds: dy (the MFMA operand), the stored data gradients, the logit gradient.
+
+    Why this and not "bf16 step vs fp32 step" for the chain: tools/grad_attribution.py shows that the step-vs-step
+    gradient distance (0.4-0.6 relative L2 below the deconvs) is a property of this network FUNCTION, not of any
+    backward arithmetic: the exact fp32 kernels give the same distance as soon as only the conv weights (0.31-0.43), only
+    the activations (0.33-0.45) or both (0.40-0.52) are rounded to bf16 values, and promoting every gradient tensor of
+    the bf16 mode to fp32 storage changes nothing.  With the forward frozen the chain is measurable."""
+    from voxelnet_amd import engine as E
+    from voxelnet_amd import model as M
+    from voxelnet_amd import net as N
+    from voxelnet_amd.engine import Rows
+    feats, coords, targets = _car_step_inputs()
+    sd = _bf16_valued(tr.make_state_dict("Car"))
+    M.set_precision("bf16")
+    m = M.RPN3D("Car")
+    m.load_state_dict(sd)
+    m = m.to(DEV).train()
+    fn, mid = m.feature_net, m.middle_rpn
+    feature = torch.cat(feats, 0).contiguous()
+    coord = torch.cat(coords, 0).contiguous()
+    B, K = 2, feature.shape[0]
+    vparams = [p.detach() for p in M._vfe_weights(fn)]
+    names, P, Bf, flat = M._collect_middle(mid)
+    P = M._detached(P)
+    P["heads"] = M._heads_params([f.detach() for f in flat[-4:]])
+    vw, stats, wst = M.featnet_forward(feature, vparams, fn._bufs(), True)
+    dense = M.scatter_rows(vw, coord, B, fn._grid.dims, "bf16")
+    vw_rows = vw.bfloat16()
+    prob, reg, st = N.middle_forward(dense, P, Bf, mid._block1_stride, True, "bf16", sparse=(coord, vw_rows))
+    pl, rl = prob.detach().requires_grad_(), reg.detach().requires_grad_()
+    m.loss(pl, rl, *targets)[0].backward()
+    d_prob, d_reg = pl.grad, rl.grad
+    # ---- the bf16 chain
+    Gb, dvw_b = N.middle_backward(st, d_prob, d_reg, P)
+    vg_b = M.featnet_backward(feature, wst, stats, dvw_b, vparams)
+    # ---- the exact chain through the same saved forward
+    st32 = N.MiddleState()
+    st32.layers, st32.block1_stride, st32.mode, st32.prob, st32.fmap = {}, st.block1_stride, "fp32", st.prob, st.fmap
+    st32.sparse = (coord, vw_rows.float())
+    for name, s in st.layers.items():
+        t = E.LayerState()
+        t.spec, t.in_dims, t.out_dims, t.stats = s.spec, s.in_dims, s.out_dims, s.stats
+        t.x = s.x if name == "middle_layer.0" else Rows(s.x.t.float(), s.x.C)     # (the dense grid is not read by the sparse backward)
+        t.y = Rows(s.y.t.float(), s.y.C)
+        t.a = Rows(s.a.t.float(), s.a.C) if s.a is not None else None
+        st32.layers[name] = t
+    Gf, dvw_f = N.middle_backward(st32, d_prob, d_reg, P)
+    vg_f = M.featnet_backward(feature, wst, stats, dvw_f, vparams)
+    torch.cuda.synchronize()
+
+    def dist(a, b):
+        a, b = a.double(), b.double()
+        return float((a - b).norm() / (b.norm() + 1e-30)), float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+    rows = [("d_vw (K,128)",) + dist(dvw_b, dvw_f)]
+    for n in names + ["heads"]:
+        for k in ("weight", "gamma", "beta") if n != "heads" else ("weight", "bias"):
+            rows.append((f"{n}.{k}",) + dist(Gb[n][k], Gf[n][k]))
+    for key, a, b in zip(M.VFE_KEYS, vg_b, vg_f):
+        rows.append((key,) + dist(a, b))
+    for nm, l2, cos in rows:
+        print(f"   frozen forward, bf16 vs exact backward: {nm:44s} rel-L2 {l2:.4f}  cos {cos:.5f}")
+    worst = max(rows, key=lambda r: r[1])
+    print("frozen forward: worst", worst)
+    # ---- the native executor's bf16 step (fused epilogues, first-layer shortcuts, two streams) against the same chain
+    res = m((None, None, feats, None, coords, None, None), DEV, targets=targets)
+    res[2].backward()
+    torch.cuda.synchronize()
+    nat = {k: p.grad.detach() for k, p in m.named_parameters()}
+    chain = {}
+    for n in names:
+        cv = "deconv" if n.startswith("deconv") else "conv"
+        chain[f"middle_rpn.{n}.{cv}.weight"] = Gb[n]["weight"]
+        chain[f"middle_rpn.{n}.batch_norm.weight"] = Gb[n]["gamma"]
+        chain[f"middle_rpn.{n}.batch_norm.bias"] = Gb[n]["beta"]
+    chain["middle_rpn.prob_conv.conv.weight"], chain["middle_rpn.reg_conv.conv.weight"] = Gb["heads"]["weight"][:2], Gb["heads"]["weight"][2:]
+    chain["middle_rpn.prob_conv.conv.bias"], chain["middle_rpn.reg_conv.conv.bias"] = Gb["heads"]["bias"][:2], Gb["heads"]["bias"][2:]
+    for key, g in zip(M.VFE_KEYS, vg_b):
+        chain[key] = g
+    # (printed, not asserted beyond the maps: the two bf16 forwards differ only in the summation order of the first layer —
+    #  rulebook P rows vs row-list gather — and this random-weight BatchNorm/ReLU stack amplifies every perturbation ~1.2x
+    #  per layer (tools/forward_error_profile.py; the fp32 mode's own order-only difference grows 8.6e-8 -> 1.2e-5): the
+    #  maps come out 0.6 % / 3 % apart and the gradients 0.1-0.4, exactly like bf16 vs fp32 — a property of the function)
+    mp, mr = dist(res[0].detach(), prob), dist(res[1].detach(), reg)
+    print("native maps vs per-layer maps (rel-L2, cos):", mp, mr)
+    nworst = ("", 0.0, 1.0)
+    for k, g in chain.items():
+        l2, cos = dist(nat[k], g)
+        if l2 > nworst[1]:
+            nworst = (k, l2, cos)
+    print("native executor vs per-layer orchestration (both bf16): worst gradient", nworst)
+    assert worst[1] < FROZEN_L2 and min(r[2] for r in rows) > FROZEN_COS, worst
+    assert mp[0] < MAP_L2 and mr[0] < MAP_L2, (mp, mr)
 
 
 def test_heads_streaming_kernels():

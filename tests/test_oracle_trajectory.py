@@ -1,0 +1,49 @@
+"""CPU: the oracle's restatement of the reference's train loop (oracle/torch_ref.train_step: train.py:148-155 with the
+loss of model.py:310-352, clip_grad_norm_ and SGD) and of its target generation on another anchor grid
+(oracle/targets.py) against tests/golden/trajectory_tiny.npz — 20 iterations of the IMPORTED reference's loop on a
+10 x 48 x 48 grid (tools/gen_golden.py trajectory): per-step loss scalars, gradient norms, final parameters / running
+statistics / num_batches_tracked.
+
+Tolerances.  The loop is a chaotic map at rounding level: the reference's own fp32 and fp64 runs (both in the fixture)
+agree to 1.6e-7 at iteration 0, 6e-5 at iteration 1 and 1e-3 ... 3e-2 from iteration 2 on (every update feeds the
+next forward through 23 BatchNorm/ReLU layers that amplify a perturbation ~1.2x each).  The oracle runs the same ATen
+kernels through a different autograd graph (functional ops, float64 norm in the clip), so: iteration 0 within 1e-5,
+every iteration within max(1e-3, 3 x the running maximum of that fp32-vs-fp64 band)."""
+import numpy as np
+import torch
+
+from oracle import targets as ot
+from oracle import torch_ref as tr
+from oracle import voxelize as ov
+from trajectory_common import batch_clouds, check_final_state, check_targets, check_trajectory, fixture_labels, traj_grid
+
+
+def test_oracle_train_trajectory(golden):
+    g = golden("trajectory_tiny")
+    steps = int(g["steps"])
+    grid = traj_grid(g)
+    anchors = g["anchors"]
+    shape = anchors.shape[:2]
+    sd = tr.make_state_dict("Car")
+    batches = []
+    for j in range(4):
+        feats, coords = [], []
+        for i, cloud in enumerate(batch_clouds(g, j)):
+            v = ov.voxelize(cloud, "Car", H=grid.H, W=grid.W, oy=grid.oy)
+            feats.append(torch.from_numpy(v["feature_buffer"]))
+            coords.append(torch.from_numpy(np.pad(v["coordinate_buffer"], ((0, 0), (1, 0)), constant_values=i)))
+        assert [f.shape[0] for f in feats] == list(g[f"K{j}"])
+        pos, neg, tgt = ot.generate_targets(fixture_labels(g, j), shape, anchors)
+        check_targets(g, j, pos, neg, tgt)
+        batches.append((feats, coords, tuple(torch.from_numpy(np.asarray(a)).float() for a in (pos, neg, tgt))))
+    assert len(g["pos_idx1"]) > 0 and all(len(g[f"pos_idx{j}"]) == 0 for j in (0, 2, 3))
+    losses = []
+    for it in range(steps):
+        feats, coords, targets = batches[int(g["order"][it])]
+        scal, total = tr.train_step(feats, coords, sd, grid.dims, "Car", targets, float(g["lr"]), float(g["clip"]))
+        if it == 0:
+            np.testing.assert_allclose(scal, g["scalars"][0], rtol=1e-5, atol=1e-7)
+            assert abs(total - g["grad_norm"][0]) <= 1e-4 * g["grad_norm"][0]
+        losses.append(scal[0])
+    check_trajectory(g, losses, 1e-3, 3.0, "oracle")
+    check_final_state(g, {k: v.detach().numpy() for k, v in sd.items()}, steps, "oracle")

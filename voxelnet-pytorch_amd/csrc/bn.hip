@@ -211,7 +211,8 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
                 cv[j] = 0.f;
                 if constexpr (FLAGGED) {
                     const float z = fmaf(S[j], as_stored(inactive[c + j], ydt) - mean[j], be[j]);
-                    cv[j] = relu ? fmaxf(z, 0.f) : z;
+                    cv[j] = (relu & 1) ? fmaxf(z, 0.f) : z;
+                    if (relu & 2) cv[j] = (float)(bf16_t)cv[j];
                 }
             }
             for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
@@ -226,7 +227,8 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float z = fmaf(S[j], v[j] - mean[j], be[j]);
-                        v[j] = relu ? fmaxf(z, 0.f) : z;
+                        v[j] = (relu & 1) ? fmaxf(z, 0.f) : z;
+                        if (relu & 2) v[j] = (float)(bf16_t)v[j];
                     }
                 }
                 store8(a, adt, lo_off, m * astride + c, v);
@@ -249,7 +251,8 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float z = fmaf(stats[2 * C + c + j], v[j] - stats[c + j], stats[3 * C + c + j]);
-            v[j] = relu ? fmaxf(z, 0.f) : z;
+            v[j] = (relu & 1) ? fmaxf(z, 0.f) : z;
+            if (relu & 2) v[j] = (float)(bf16_t)v[j];
         }
         store8(a, adt, lo_off, (fold ? fold_off(m, fold, astride, C) : m * astride) + c, v);
     }

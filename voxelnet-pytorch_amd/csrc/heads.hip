@@ -95,7 +95,64 @@ __global__ void __launch_bounds__(256) k_heads_dgrad(const bf16_t *__restrict__ 
     }
 }
 
+// The same data gradient WITHOUT operand rounding: d_rows (M,16) and the weights (16,768) in fp32, fp32 FMAs (the 1.7 GFLOP
+// of this product hide behind the 108-216 MB it writes).  The logit gradient is almost the same number at every negative
+// anchor and each deconv's train-mode BatchNorm backward removes most of what the concat gradient has in common over the
+// sites: the bf16 roundings of d_rows and of the weights are a 2^-9 perturbation of that common part, i.e. a 10-30 %
+// perturbation of what is left.  A thread owns 8 consecutive channels (its 16 x 8 weights in
+// registers) and walks rows; the 96 threads of a row read the same 64 B of d_rows (L1 broadcast).
+template <bool OUT_F32>
+__global__ void __launch_bounds__(192) k_heads_dgrad_f32(const float *__restrict__ drows, int64_t drows_stride,
+                                                         const float *__restrict__ w /* [16][768] */, void *__restrict__ dcat,
+                                                         int64_t dcat_stride, int64_t M) {
+    const int cg = threadIdx.x % 96, rr = threadIdx.x / 96;      // channel group (8 channels), row slot 0/1
+    float W[16][8];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float4 a = *reinterpret_cast<const float4 *>(w + j * 768 + cg * 8);
+        const float4 b = *reinterpret_cast<const float4 *>(w + j * 768 + cg * 8 + 4);
+        W[j][0] = a.x; W[j][1] = a.y; W[j][2] = a.z; W[j][3] = a.w; W[j][4] = b.x; W[j][5] = b.y; W[j][6] = b.z; W[j][7] = b.w;
+    }
+    for (int64_t m = (int64_t)blockIdx.x * 2 + rr; m < M; m += (int64_t)gridDim.x * 2) {
+        float g[16];
+        const float4 *gp = reinterpret_cast<const float4 *>(drows + m * drows_stride);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float4 t = gp[q]; g[4 * q] = t.x; g[4 * q + 1] = t.y; g[4 * q + 2] = t.z; g[4 * q + 3] = t.w; }
+        float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(g[j], W[j][e], o[e]);
+        if constexpr (OUT_F32) {
+            float *d = static_cast<float *>(dcat) + m * dcat_stride + cg * 8;
+            *reinterpret_cast<float4 *>(d) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4 *>(d + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+            bf16x8_t v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)o[e];
+            *reinterpret_cast<bf16x8_t *>(static_cast<bf16_t *>(dcat) + m * dcat_stride + cg * 8) = v;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int vn_heads_dgrad_f32(const float *d_rows, int64_t d_rows_stride, const float *w, void *d_cat, vnDtype d_cat_dtype,
+                                  int64_t d_cat_stride, int64_t M, vnStream stream) {
+    VN_CHECK_ARG(d_rows && w && d_cat && M > 0 && d_rows_stride >= 16 && (d_rows_stride & 3) == 0 && d_cat_stride >= 768 &&
+                 (d_cat_stride & 7) == 0 && (d_cat_dtype == VN_F32 || d_cat_dtype == VN_BF16));
+    if ((reinterpret_cast<uintptr_t>(d_rows) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) || (reinterpret_cast<uintptr_t>(d_cat) & 15))
+        return VN_EUNSUPPORTED;
+    int64_t blocks = (M + 1) / 2;
+    if (blocks > 4096) blocks = 4096;
+    if (d_cat_dtype == VN_F32)
+        k_heads_dgrad_f32<true><<<(unsigned)blocks, 192, 0, vn_stream(stream)>>>(d_rows, d_rows_stride, w, d_cat, d_cat_stride, M);
+    else
+        k_heads_dgrad_f32<false><<<(unsigned)blocks, 192, 0, vn_stream(stream)>>>(d_rows, d_rows_stride, w, d_cat, d_cat_stride, M);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
 
 // prob (B,2,S), reg (B,14,S) fp32 = the two heads over the (B*S, 768) bf16 concat rows; w = the packed [16][768] bf16 weight
 // (rows 0-1: the score head, 2-15: the regression head; vn_pack_weight mode 0), bias [16] fp32 or NULL; sigmoid on the scores

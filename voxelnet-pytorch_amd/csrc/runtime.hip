@@ -74,7 +74,9 @@ struct Arena {
 struct Plan {
     Spec spec[NL];
     int in_dims[NL][3], odims[NL][3];
-    int esz, adt, pdt;           // operand element size / activation dtype / plain (y, gradient) dtype
+    int esz, adt;                // operand element size / activation (MFMA operand) dtype
+    int ydt, gdt, cdt;           // storage dtype of the conv outputs y / of the data gradients dx / of the concat gradient
+                                 // (bf16 mode: bf16 unless cfg->grad_storage promotes them to fp32)
     // per layer
     void *wp_f[NL], *wp_d[NL];   // packed weights (forward / data-gradient orientation)
     Rows y[NL], a[NL];           // conv output (pre-BN), activation
@@ -87,6 +89,8 @@ struct Plan {
     Rows dy[NL], dx[NL];
     float *dwp[NL]; size_t dwp_bytes[NL];   // row-chunk partials of the weight gradient (vn_conv_wgrad_partials)
     // heads
+    bool round_act;   // fp32 mode diagnostic (grad_storage & 16): activations rounded to bf16 VALUES, everything else exact fp32
+    bool exact_heads; Rows d_rows32;   // grad_storage & 8: the fp32 logit gradient beside the bf16 one
     void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes; void *hcs_ws; size_t hcs_ws_bytes;
     // sparse first layer
     int64_t *alist; int32_t *acount; int64_t acap; void *aws; size_t aws_bytes;
@@ -150,7 +154,13 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     const bool f32 = c->mode == 1;
     P->esz = f32 ? 4 : 2;
     P->adt = f32 ? VN_F32 : VN_BF16;
-    P->pdt = P->adt;
+    if (c->grad_storage & ~31) return false;
+    const int gs = f32 ? 0 : (c->grad_storage & 15);
+    P->round_act = f32 && (c->grad_storage & 16);
+    P->ydt = (gs & 4) ? VN_F32 : P->adt;
+    P->gdt = (gs & 2) ? VN_F32 : P->adt;
+    P->cdt = (gs & 1) ? VN_F32 : P->adt;
+    P->exact_heads = f32 ? false : (gs & 8) != 0;
     const int B = c->B;
     Arena A{base, 0, 0};
     auto rows_new = [&](int dtype, const int d[3], int C, int64_t width = 0) {
@@ -195,7 +205,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     P->cat = rows_new(P->adt, fm, 768);
     for (int l = 0; l < NL; ++l) {
         const Spec &sp = P->spec[l];
-        P->y[l] = rows_new(P->pdt, P->odims[l], sp.cout);
+        P->y[l] = rows_new(P->ydt, P->odims[l], sp.cout);
         P->stats[l] = (float *)A.take(4 * 256 * sizeof(float));
         const int64_t M = P->y[l].M();
         P->slab_rows[l] = 0;
@@ -250,7 +260,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     {   // middle_layer.1's data gradient at middle_layer.0's active sites only + box sums for the BatchNorm totals: needs
         // its 3x3 taps with stride 1 / padding 1 in H/W and every depth tap in range (stride 1, no padding in D)
         const Spec &s1 = P->spec[1];
-        P->list_bwd = c->sparse_first && (m0_bn_knob() & 8) && !s1.transposed && s1.k[1] == 3 && s1.k[2] == 3 && s1.k[0] <= 3 &&
+        P->list_bwd = c->sparse_first && !P->round_act && (m0_bn_knob() & 8) && !s1.transposed && s1.k[1] == 3 && s1.k[2] == 3 && s1.k[0] <= 3 &&
                       s1.s[0] == 1 && s1.s[1] == 1 && s1.s[2] == 1 && s1.p[0] == 0 && s1.p[1] == 1 && s1.p[2] == 1 &&
                       s1.cin == P->spec[0].cout && s1.cin == 64 && s1.cout <= 256 &&
                       // worth it while the active sites are a minority (their number is only known on the device: the list's
@@ -279,13 +289,14 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     for (int l = 1; l < NL; ++l) {
         if (l == L_D1 || l == L_D2) continue;             // written into the block output's dx (accumulate)
         const Spec &sp = P->spec[l];
-        P->dx[l] = rows_new(P->pdt, P->in_dims[l], sp.cin);
+        P->dx[l] = rows_new(P->gdt, P->in_dims[l], sp.cin);
     }
     P->dx[L_D1] = P->dx[L_B2];
     P->dx[L_D2] = P->dx[L_B3];
-    if (!c->sparse_first) P->dx[0] = rows_new(P->pdt, P->in_dims[0], 128);
+    if (!c->sparse_first) P->dx[0] = rows_new(P->adt, P->in_dims[0], 128);
     P->d_rows = rows_new(P->adt, fm, 16);
-    P->d_cat = rows_new(P->pdt, fm, 768);
+    P->d_cat = rows_new(P->cdt, fm, 768);
+    P->d_rows32 = P->exact_heads ? rows_new(VN_F32, fm, 16) : Rows{};
     {   // weight-gradient partials: one slab per layer, summed by the batched unpack at the end of a segment
         auto ask = [&](const int rd[3], int Cs, int Cr, const int k[3], int64_t n_rows) {
             vnConv q{};
@@ -492,8 +503,8 @@ int box_zero_total() {
     static const int v = [] { const char *e = getenv("VN_BOX_ZERO"); return e && *e ? atoi(e) : 0; }();
     return v;
 }
-int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, vnStream st) {
-    return vn_bn_apply(y.ptr, (vnDtype)y.dtype, y.sW, y.M(), C, stats, 1, a.ptr, (vnDtype)a.dtype, a.sW, 0, st);
+int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, int relu, vnStream st) {
+    return vn_bn_apply(y.ptr, (vnDtype)y.dtype, y.sW, y.M(), C, stats, relu, a.ptr, (vnDtype)a.dtype, a.sW, 0, st);
 }
 
 }  // namespace
@@ -564,6 +575,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
     hipStream_t hs = vn_stream(stream);
     const int training = cfg->training;
     const float mom = 0.1f, eps = 1e-5f;
+    const int relu_fl = P.round_act ? 3 : 1;    // (bit 1: the activation is rounded to the nearest bf16 value — diagnostic)
     // (no memset: every statistics buffer of the forward is a per-workgroup slab written with plain stores)
     if (!cfg->prepared) RT(net_prepare(net, cfg, P, L, heads_w, coord, K, stream));
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
@@ -625,15 +637,15 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
         const Rows &a = P.a[l];
         if (l == L_M2) {   // BEV fold: channel d*64 + c of the (B,1,H,W,128) activation
             RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream,
-                vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], 1, a.ptr,
+                vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], relu_fl, a.ptr,
                                 (vnDtype)a.dtype, 128, stream));
         } else if (l == 0 && cfg->sparse_first && (m0_bn_knob() & 1)) {
             // ~90 % of the first layer's sites hold the bias (no occupied voxel in reach): their y is not read
             RTT(T_BN_APPLY, l, 0.0, 1.1 * rows_bytes(y), stream,
-                vn_bn_apply_flagged(y.ptr, (vnDtype)y.dtype, y.sW, M, sp.cout, P.stats[l], 1, a.ptr, (vnDtype)a.dtype, a.sW,
+                vn_bn_apply_flagged(y.ptr, (vnDtype)y.dtype, y.sW, M, sp.cout, P.stats[l], relu_fl, a.ptr, (vnDtype)a.dtype, a.sW,
                                     static_cast<const uint8_t *>(P.aws), L[l].bias, stream));
         } else {
-            RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream, bn_apply_rows(y, P.stats[l], a, sp.cout, stream));
+            RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream, bn_apply_rows(y, P.stats[l], a, sp.cout, relu_fl, stream));
         }
         if (!sp.transposed) x = a;
         if (l == L_D1 - 1) x1 = a;
@@ -732,12 +744,17 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
         // the heads' weight gradient goes to the side stream behind ONE fork that also serves the early deconv
         // branches (which need the data gradient): one event record less on the main stream (483 vs 480 pc/s)
-        if (P.adt == VN_BF16 && P.pdt == VN_BF16 && heads_stream_on())
+        if (P.exact_heads) {
+            RTT(T_MISC, NL, 0.0, 0.0, stream, vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows32.ptr, VN_F32, 16, 0, stream));
+            RTT(T_CONV_DGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows32) + rows_bytes(P.d_cat), stream,
+                vn_heads_dgrad_f32(reinterpret_cast<const float *>(P.d_rows32.ptr), P.d_rows32.sW, heads_w, P.d_cat.ptr,
+                                   (vnDtype)P.cdt, P.d_cat.sW, (int64_t)B * S, stream));
+        } else if (P.adt == VN_BF16 && P.cdt == VN_BF16 && heads_stream_on())
             RTT(T_CONV_DGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.d_cat), stream,
                 vn_heads_dgrad(P.d_rows.ptr, P.d_rows.sW, P.hwp_d, P.d_cat.ptr, P.d_cat.sW, (int64_t)B * S, stream));
         else
         RTT(T_CONV_DGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.d_cat), stream,
-            vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.pdt, &gd, 0, nullptr, stream));
+            vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.cdt, &gd, 0, nullptr, stream));
         RT(fork());
         heads_forked = true;
         RTT(T_WGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.cat), wstream,
@@ -746,7 +763,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     }
     auto cat_slice = [&](int off) {
         Rows r = P.d_cat;
-        r.ptr += (size_t)off * (P.pdt == VN_F32 ? 4 : 2);
+        r.ptr += (size_t)off * (P.cdt == VN_F32 ? 4 : 2);
         r.C = 256;
         return r;
     };
@@ -949,7 +966,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         Rows dx = P.dx[l];
         if (l == 0) {
             if (!d_input) return VN_OK;
-            dx = dense_rows(d_input, P.pdt, B, cfg->D, cfg->H, cfg->W, 128);
+            dx = dense_rows(d_input, P.adt, B, cfg->D, cfg->H, cfg->W, 128);
         }
         const int64_t os[4] = {dx.sB, dx.sD, dx.sH, dx.sW};
         vnConv gd = sp.transposed ? geom(dy, P.in_dims[l], C, sp.cin, sp.k, sp.s, ONE, sp.p, ONE, os)

@@ -44,7 +44,7 @@ class VnVfeGrads(ctypes.Structure):
 
 
 class VnNetConfig(ctypes.Structure):
-    _fields_ = [(n, c_i32) for n in ("B", "D", "H", "W", "block1_stride", "mode", "training", "sparse_first", "prepared", "bucket_events", "defer_join")]
+    _fields_ = [(n, c_i32) for n in ("B", "D", "H", "W", "block1_stride", "mode", "training", "sparse_first", "prepared", "bucket_events", "defer_join", "grad_storage")]
 
 
 class VnTimingRecord(ctypes.Structure):
@@ -173,6 +173,7 @@ SIGNATURES = {
     "vn_heads_to_nchw": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "vn_heads_fwd": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp]),
     "vn_heads_dgrad": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_vp]),
+    "vn_heads_dgrad_f32": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i64, c_i64, c_vp]),
     "vn_heads_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vn_pack_weights_batch": (c_i32, [c_vp, c_i32, c_vp]),
     "vn_unpack_wgrads_batch": (c_i32, [c_vp, c_i32, c_vp]),
@@ -197,7 +198,7 @@ class VoxelnetHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 2     # include/voxelnet_hip.h: vn_abi_version()
+ABI_VERSION = 3     # include/voxelnet_hip.h: vn_abi_version()
 
 
 def load():

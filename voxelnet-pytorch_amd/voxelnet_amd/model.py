@@ -587,6 +587,7 @@ class _DetectorFn(torch.autograd.Function):
                 D, H, W = fn._grid.dims
                 K = feature.shape[0]
                 cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, 1 if mode == "fp32" else 0, int(training), int(sparse), 0, 0)
+                cfg.grad_storage = int(rpn.grad_storage) & (16 if mode == "fp32" else 15)
                 side = rpn._side_stream(dev_) if rpn.overlap_wgrad else None
                 if side is not None:
                     # the (16,768) / (16,) concatenations of the two heads' parameters: two small launches, read first by the
@@ -616,7 +617,7 @@ class _DetectorFn(torch.autograd.Function):
                 # active site) the dense (B,10,400,352,128) grid of model.py:102-106 is never built.
                 dense = None if sparse else scatter_rows(vw, coord, B, fn._grid.dims, mode)
                 if mode == "fp32":
-                    vw_rows = vw
+                    vw_rows = vw.bfloat16().float() if cfg.grad_storage & 16 else vw      # (diagnostic: see vnNetConfig)
                 else:
                     vw_rows = torch.empty((vw.shape[0], 128), dtype=torch.bfloat16, device=vw.device)
                     _lib.call("vn_cast_rows", vw.data_ptr(), _lib.VN_F32, 128, vw.shape[0], 128, vw_rows.data_ptr(),
@@ -902,6 +903,7 @@ class RPN3D(nn.Module):
         self.native_executor = True      # C++ step executor (csrc/runtime.hip) instead of per-launch Python calls
         self.grad_reducer = None  # parallel.GradAllReducer: bucketed all-reduce overlapped with backward
         self.overlap_wgrad = True # native path: weight-gradient launches on a side stream beside the data-gradient ones
+        self.grad_storage = 0     # bf16 mode, native path: vnNetConfig.grad_storage (which step tensors are kept in fp32)
 
     # Runtime caches kept in the instance __dict__ (ctypes arrays, HIP streams, the ~1.5 GB executor arenas, the flat
     # gradient buffer, device-side target / decode helpers).  They are rebuilt on demand and must not travel with
