@@ -423,6 +423,9 @@ int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *lay
  * vn_allreduce_bucket: bucket[i] = sum over ranks of scale * bucket[i], in place, asynchronous on `stream`
  * (scale = 1/world: the mean stock DDP takes; scaled before the sum, so all ranks end bit-identical).
  * ---------------------------------------------------------------------- */
+int vn_comm_rccl_version(void); /* ncclGetVersion() code of the librccl bound at run time (e.g. 22703), 0 if none;
+                                  * every vn_comm_* / vn_allreduce_bucket call returns VN_EUNSUPPORTED unless it is 2.x:
+                                  * the RCCL entry points are declared by hand (ncclUniqueId by value, ncclFloat32 = 7) */
 int vn_comm_unique_id(void *id128 /* out: 128 bytes (ncclUniqueId) */);
 int vn_comm_create(void **nccl_comm, const void *id128, int32_t world, int32_t rank);
 int vn_comm_destroy(void *nccl_comm);

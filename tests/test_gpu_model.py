@@ -285,3 +285,41 @@ def test_reducer_path_gives_the_same_gradients(golden):
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-7), (k, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_train_step_on_a_grid_the_native_executor_does_not_take(mode):
+    """D = 9 (the three Conv3d layers still fold to depth 2: model.py:207-209, 262) is outside the native executor
+    (csrc/runtime.hip plans D = 10 only): detect() must then route the whole step — forward AND backward — through the
+    per-layer orchestration with the parameters as autograd inputs (round 2 picked the one-tensor 'anchor' call from a
+    different predicate than the forward's path choice and the backward raised).  fp32: maps against the oracle at 1e-3;
+    both modes: every parameter receives a finite gradient through autograd (torch.autograd.grad works on this path)."""
+    from oracle import voxelize as ov
+    from voxelnet_amd import model as M
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import grid_config
+    g9 = grid_config("Car", D=9, H=16, W=24, oy=1.6)
+    feats, coords = [], []
+    for i in range(2):
+        cloud = synth.synth_cloud("Car", k0=120 + 30 * i, seed=700 + i, grid=g9, overflow_frac=0.03)
+        v = ov.voxelize(cloud, "Car", D=9, H=16, W=24, oy=1.6)
+        feats.append(torch.from_numpy(v["feature_buffer"]))
+        coords.append(torch.from_numpy(np.pad(v["coordinate_buffer"], ((0, 0), (1, 0)), constant_values=i)))
+    M.set_precision(mode)
+    m = M.RPN3D("Car")
+    m.load_state_dict(tr.make_state_dict("Car"))
+    m.feature_net._grid = g9
+    m = m.to(DEV).train()
+    assert not m._native_ok(mode)
+    prob, reg = m.detect([f.to(DEV) for f in feats], [c.to(DEV) for c in coords])
+    assert prob.shape == (2, 2, 8, 12)
+    if mode == "fp32":
+        with torch.no_grad():
+            sd = tr.make_state_dict("Car")
+            rp, rr = tr.middle_rpn(tr.feature_net(feats, coords, sd, (9, 16, 24), True), sd, "Car", True)
+        assert rel_err(prob, rp.numpy()) < 1e-3 and rel_err(reg, rr.numpy()) < 1e-3
+    params = list(m.parameters())
+    grads = torch.autograd.grad(prob.square().mean() + reg.square().mean(), params)
+    assert len(grads) == 104 and all(g is not None and torch.isfinite(g).all() for g in grads)
+    assert sum(float(g.abs().sum()) for g in grads) > 0
+    M.set_precision("bf16")

@@ -17,13 +17,19 @@ typedef int (*fn_get_id)(NcclId *);
 typedef int (*fn_init_rank)(NcclComm *, int, NcclId, int);
 typedef int (*fn_destroy)(NcclComm);
 typedef int (*fn_allreduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t);
-constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;   // ncclDataType_t / ncclRedOp_t values of rccl.h
+typedef int (*fn_version)(int *);
+constexpr int NCCL_FLOAT32 = 7, NCCL_SUM = 0;   // ncclDataType_t / ncclRedOp_t values of rccl.h (NCCL 2.x)
+// The four entry points are declared by hand (no link-time dependency), so the hand-written ABI above — the 128-byte id
+// passed BY VALUE, ncclFloat32 = 7, ncclSum = 0 — is only trusted for the major version it was written against:
+// ncclGetVersion() must report 2.x (version code = major * 10000 + minor * 100 + patch for >= 2.9, major * 1000 + ... before)
+constexpr int NCCL_MAJOR_EXPECTED = 2;
 
 struct Rccl {
     fn_get_id get_id;
     fn_init_rank init_rank;
     fn_destroy destroy;
     fn_allreduce allreduce;
+    int version;     // ncclGetVersion code, 0 if unavailable
     bool ok;
 };
 
@@ -43,7 +49,11 @@ const Rccl &rccl() {
         t.init_rank = reinterpret_cast<fn_init_rank>(dlsym(h, "ncclCommInitRank"));
         t.destroy = reinterpret_cast<fn_destroy>(dlsym(h, "ncclCommDestroy"));
         t.allreduce = reinterpret_cast<fn_allreduce>(dlsym(h, "ncclAllReduce"));
-        t.ok = t.get_id && t.init_rank && t.destroy && t.allreduce;
+        fn_version ver = reinterpret_cast<fn_version>(dlsym(h, "ncclGetVersion"));
+        int code = 0;
+        if (ver && ver(&code) == 0) t.version = code;
+        const int major = t.version >= 20000 ? t.version / 10000 : t.version / 1000;
+        t.ok = t.get_id && t.init_rank && t.destroy && t.allreduce && major == NCCL_MAJOR_EXPECTED;
         return t;
     }();
     return r;
@@ -62,7 +72,16 @@ __global__ void __launch_bounds__(256) k_scale(float *__restrict__ x, int64_t n4
 
 }  // namespace
 
-// status: VN_OK, VN_EINVAL, VN_EUNSUPPORTED (no librccl in the process / on the box), or 1000 + ncclResult_t
+// status: VN_OK, VN_EINVAL, VN_EUNSUPPORTED (no librccl in the process / on the box, or one whose ncclGetVersion is not
+// 2.x), or 1000 + ncclResult_t.
+// EXPERIMENTAL until it has run on 2+ GPUs (this pool hands out one GPU per call; the default data-parallel path is
+// torch.distributed's process group, voxelnet_amd/parallel.py).  A communicator made here lives NEXT TO torch's NCCL
+// process group: collectives of the two must never be in flight together in different orders on different ranks —
+// GradAllReducer issues its buckets in one fixed order on every rank and the caller must not run a torch.distributed
+// collective between launch_bucket(0) and finish().
+
+// RCCL version code the library bound (ncclGetVersion), 0 when no usable librccl was found
+extern "C" int vn_comm_rccl_version(void) { return rccl().version; }
 
 extern "C" int vn_comm_unique_id(void *id128) {
     VN_CHECK_ARG(id128);

@@ -10,6 +10,12 @@
 #define VN_LAUNCH_STATUS() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) return (int)e_; } while (0)
 #define VN_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return (int)e_; } while (0)
 
+// Tuning aids: the ONLY way this library reads the environment.  vn_knob(name, default) returns the integer value of the
+// environment variable `name` if it is set (and listed in abi.hip's table: an unlisted name always returns the default),
+// else `default`; callers keep the result in a function-local static (read once per process).  vn_build_info() reports
+// every listed variable that is set, so a stray VN_* in the environment shows up in bench.py's JSON line.
+int vn_knob(const char *name, int dflt);
+
 static inline hipStream_t vn_stream(vnStream s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t vn_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t vn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }

@@ -196,7 +196,7 @@ __device__ __forceinline__ void gg_store(const GGParams &p, f32x4_t (&acc)[SM][4
             }
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < 2 * BN; i += 256) {
+        for (int i = threadIdx.x; i < 2 * BN; i += 64 * WM * WN) {
             const int which = i / BN, c = i - which * BN;
             float v = 0.f;
 #pragma unroll
@@ -707,17 +707,23 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
     gg_store<WM, WN, SM>(p, acc, smem, otab, tile, n0, wm, wn, lane);
 }
 
-// 2-D layers on small images (100 x 88, 50 x 44): the same kernel with an NSB-deep weight pipeline
+// 2-D layers on small images (100 x 88, 50 x 44): the same kernel with an NSB-deep weight pipeline.
+// NW = WM x WN waves, 4 or 8.  These launches are 140-280 workgroups on 256 CUs: ONE workgroup per CU, and with four
+// waves one wave per SIMD that serialises, per tap step, the issue of its LDS-DMA pieces (~113 clk per 1-KiB piece:
+// four weight pieces = 450 clk), its fragment reads, 16 MFMAs (256 clk) and the barrier — ~1000 clk for 256 clk of
+// MFMA, 36 times.  Eight waves (4 x 2 waves of 16 x 64) halve every wave's share of all three and put two waves on
+// each SIMD, so that one wave's DMA issue runs beside the other's MFMAs (round 3).
 template <int WM, int WN, int SM, int TW, int NSB, bool F32>
-__global__ void __launch_bounds__(256, 2) k_conv_patch2d(const GGParams p) {
+__global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_patch2d(const GGParams p) {
     constexpr int ESZ = F32 ? 4 : 2;
+    constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = 16 * SM * WM, BN = 64 * WN, TH = BM / TW;
-    static_assert(WM * WN == 4 && BM % TW == 0, "4 waves; whole patch lines");
+    static_assert((NW == 4 || NW == 8) && BM % TW == 0 && (BN / 8) % NW == 0, "4 or 8 waves; whole patch lines");
     constexpr int PW = TW + 2, PH = TH + 2, PROWS = PH * PW;
     constexpr int PPIECES = (PROWS + 7) / 8;                 // 1-KiB pieces of the patch
-    constexpr int PA = (PPIECES + 3) / 4;                    // per wave
-    constexpr int PATCH_BYTES = PA * 4 * 1024;
-    constexpr int RB = BN / 32;                              // weight pieces per wave and tap
+    constexpr int PA = (PPIECES + NW - 1) / NW;              // per wave
+    constexpr int PATCH_BYTES = PA * NW * 1024;
+    constexpr int RB = BN / (8 * NW);                        // weight pieces per wave and tap
     constexpr int B_BYTES = BN * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char *bst = smem + 2 * PATCH_BYTES;                      // two patch buffers, then NSB weight stages
@@ -749,7 +755,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch2d(const GGParams p) {
     uint32_t a_row[PA];
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
-        const int q = (i * 4 + wave) * 8 + (lane >> 3);       // patch row
+        const int q = (i * NW + wave) * 8 + (lane >> 3);      // patch row
         const int qy = q / PW, qx = q - qy * PW;
         const int sy = y0 - 1 + qy, sx = x0 - 1 + qx;          // H/W: stride 1, offsets -1..1 (checked on the host)
         a_row[i] = (q < PROWS && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
@@ -759,7 +765,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch2d(const GGParams p) {
     uint32_t b_row[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int rho = (i * 4 + wave) * 8 + (lane >> 3);
+        const int rho = (i * NW + wave) * 8 + (lane >> 3);
         const int rl = rho & 63;
         const int n = n0 + (rho & ~63) + (rl & 15) * 4 + (rl >> 4);
         b_row[i] = n < p.N ? (uint32_t)((int64_t)n * p.Cs * ESZ) : GG_OOB;
@@ -803,7 +809,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch2d(const GGParams p) {
         char *lb = bst + buf * B_BYTES + wave * 1024;
 #pragma unroll
         for (int i = 0; i < RB; ++i)
-            lds_dma16(rs_b, lb + i * 4096, (k_ok && b_row[i] != GG_OOB) ? b_row[i] + b_koff : GG_OOB, b_soff);
+            lds_dma16(rs_b, lb + i * (NW * 1024), (k_ok && b_row[i] != GG_OOB) ? b_row[i] + b_koff : GG_OOB, b_soff);
     };
     auto stage_patch = [&](int sd, int kc, char *patch) {
         const int k_lane = kc * BKE + k_lane0;
@@ -812,7 +818,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch2d(const GGParams p) {
         const uint32_t off = (uint32_t)(((int64_t)sd * p.sD + k_src) * ESZ);
 #pragma unroll
         for (int i = 0; i < PA; ++i)
-            lds_dma16(rs_a, patch + (i * 4 + wave) * 1024, (k_ok && a_row[i] != GG_OOB) ? a_row[i] + off : GG_OOB, 0);
+            lds_dma16(rs_a, patch + (i * NW + wave) * 1024, (k_ok && a_row[i] != GG_OOB) ? a_row[i] + off : GG_OOB, 0);
     };
 
     // one source plane (2-D layer): steps s = kc*9 + tap.  The weight tile of step s + NSB - 1 is staged while step s is on
@@ -889,7 +895,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch2d(const GGParams p) {
     // ---- epilogue: row -> output offset table, then the shared store / statistics code
     __syncthreads();
     int32_t *otab = reinterpret_cast<int32_t *>(smem);
-    for (int r = threadIdx.x; r < BM; r += 256) {
+    for (int r = threadIdx.x; r < BM; r += NT) {
         const int py = r / TW, px = r - py * TW;
         const int qh = y0 + py, qw = x0 + px;
         int32_t off = -1;
@@ -961,10 +967,7 @@ struct GGConfig {
 constexpr GGConfig GG_CFG[5] = {{0, 256, 64}, {1, 128, 128}, {2, 64, 128}, {3, 64, 64}, {4, 160, 128}};
 
 int gg_force() {   // tuning aid: VN_GG_CONFIG=0..4 forces one configuration
-    static const int v = [] {
-        const char *e = getenv("VN_GG_CONFIG");
-        return e && *e ? atoi(e) : -1;
-    }();
+    static const int v = vn_knob("VN_GG_CONFIG", -1);
     return v;
 }
 
@@ -986,10 +989,7 @@ struct PatchCfg {
     int id, BM, BN, TW;   // id < 0: not eligible
 };
 int patch_enabled() {     // tuning aid: VN_PATCH=0 keeps every layer on k_gather_gemm, 2 = also small images
-    static const int v = [] {
-        const char *e = getenv("VN_PATCH");
-        return e && *e ? atoi(e) : 1;
-    }();
+    static const int v = vn_knob("VN_PATCH", 1);
     return v;
 }
 PatchCfg patch_config(const vnConv *g) {
@@ -1009,9 +1009,9 @@ PatchCfg patch_config(const vnConv *g) {
     }
     // 64-channel Conv3d layers: 6 x 32 pixels (patch 35 KB + 2 weight stages = 51 KB: THREE workgroups per CU; measured
     // 1340 vs 1183 TFLOP/s on middle_layer.2 against 8 x 32 pixels / two workgroups per CU)
-    static const int p1_rows = [] { const char *e = getenv("VN_PATCH_P1"); return e && *e ? atoi(e) : 192; }();   // tuning aid
+    static const int p1_rows = vn_knob("VN_PATCH_P1", 192);   // tuning aid
     if (g->Cr == 64) return p1_rows == 192 ? PatchCfg{3, 192, 64, 32} : PatchCfg{1, 256, 64, 32};
-    static const int p0_rows = [] { const char *e = getenv("VN_PATCH_P0"); return e && *e ? atoi(e) : 160; }();   // tuning aid
+    static const int p0_rows = vn_knob("VN_PATCH_P0", 160);   // tuning aid
     if (p0_rows == 96) return PatchCfg{4, 96, 128, 16};      // 6 x 16 pixels, three workgroups per CU
     if (p0_rows == 128) return PatchCfg{5, 128, 128, 16};    // 8 x 16 pixels
     return PatchCfg{0, 160, 128, 16};                        // 10 x 16 pixels
@@ -1032,23 +1032,23 @@ int launch_patch(const GGParams &p, dim3 grid, hipStream_t st) {
 }
 template <int WM, int WN, int SM, int TW, int NSB, bool F32>
 int launch_patch2d(const GGParams &p, dim3 grid, hipStream_t st) {
-    constexpr int BM = 16 * SM * WM, TH = BM / TW, PROWS = (TH + 2) * (TW + 2);
-    constexpr size_t lds = 2 * ((size_t)((PROWS + 7) / 8 + 3) / 4 * 4096) + NSB * (size_t)(64 * WN) * 128;
+    constexpr int BM = 16 * SM * WM, TH = BM / TW, PROWS = (TH + 2) * (TW + 2), NW = WM * WN;
+    constexpr size_t lds = 2 * ((size_t)((PROWS + 7) / 8 + NW - 1) / NW * NW * 1024) + NSB * (size_t)(64 * WN) * 128;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_conv_patch2d<WM, WN, SM, TW, NSB, F32>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    k_conv_patch2d<WM, WN, SM, TW, NSB, F32><<<grid, 256, lds, st>>>(p);
+    k_conv_patch2d<WM, WN, SM, TW, NSB, F32><<<grid, 64 * NW, lds, st>>>(p);
     return 0;
 }
 int patch2d_stages() {   // VN_PATCH2D=0: the two-stage kernel for the small images too; 3 / 4: weight stages
-    static const int v = [] {
-        const char *e = getenv("VN_PATCH2D");
-        return e && *e ? atoi(e) : 3;
-    }();
+    static const int v = vn_knob("VN_PATCH2D", 3);
     return v;
 }
 int launch_patch_cfg(const PatchCfg &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
     if (c.id == 2 && p.Ds == 1 && p.nclasses == 1 && p.cls[0].nD == 1 && patch2d_stages() >= 3) {
+        // eight waves (4 x 2 of 16 x 64) for the bf16 kernels; tuning aid VN_PATCH2D_WAVES=4: the four-wave kernel of round 2
+        static const int waves = vn_knob("VN_PATCH2D_WAVES", 8);
+        if (patch2d_stages() == 3 && waves == 8 && !f32) return launch_patch2d<4, 2, 1, 16, 3, false>(p, grid, st);
         if (patch2d_stages() == 3)
             return f32 ? launch_patch2d<2, 2, 2, 16, 3, true>(p, grid, st) : launch_patch2d<2, 2, 2, 16, 3, false>(p, grid, st);
         return f32 ? launch_patch2d<2, 2, 2, 16, 4, true>(p, grid, st) : launch_patch2d<2, 2, 2, 16, 4, false>(p, grid, st);
@@ -1170,7 +1170,7 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
     c.ntaps = ntap;
     p.nclasses = 1;
     // capacity launch: rows are not known on the host.  (tuning aid VN_GG_ROWS_CONFIG: one configuration for every list launch)
-    static const int rows_force = [] { const char *e = getenv("VN_GG_ROWS_CONFIG"); return e && *e ? atoi(e) : -1; }();
+    static const int rows_force = vn_knob("VN_GG_ROWS_CONFIG", -1);
     const GGConfig cfg = rows_force >= 0 && rows_force < 5 ? GG_CFG[rows_force] : (g->Cr > 64 ? GG_CFG[1] : GG_CFG[0]);
     const int64_t tiles_m = vn_ceil_div(row_cap, cfg.BM), tiles_n = vn_ceil_div(g->Cr, cfg.BN);
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1);

@@ -165,7 +165,7 @@ extern "C" int vn_heads_fwd(const void *cat_rows, int64_t cat_stride, const void
     const int64_t groups = ((int64_t)B * S + 15) >> 4;
     int64_t blocks = (groups + 3) / 4;
     // (every wave loads the 24 KB of weights first: few, long-lived waves — VN_HEADS_BLOCKS, default two workgroups per CU)
-    static const int cap = [] { const char *e = getenv("VN_HEADS_BLOCKS"); return e && *e ? atoi(e) : 512; }();
+    static const int cap = vn_knob("VN_HEADS_BLOCKS", 512);
     if (blocks > cap) blocks = cap;
     k_heads_fwd<<<(unsigned)blocks, 256, 0, vn_stream(stream)>>>(static_cast<const bf16_t *>(cat_rows), cat_stride,
                                                                  static_cast<const bf16_t *>(w_packed), bias, B, S, prob, reg);

@@ -280,7 +280,12 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         const Spec &sp = P->spec[l];
         P->coef[l] = (float *)A.take(3 * 256 * sizeof(float));
         P->bslab_rows[l] = vn_bn_bwd_slab_rows(P->y[l].M(), sp.cout);
-        P->bslab[l] = (float *)A.take((size_t)P->bslab_rows[l] * 2 * sp.cout * sizeof(float));
+        size_t bslab_floats = (size_t)P->bslab_rows[l] * 2 * sp.cout;
+        if (l == 0 && P->list_bwd) {   // the list-based reduce writes THREE columns per slab row (vn_bn_bwd_reduce_list)
+            const size_t lf = (size_t)vn_bn_bwd_list_slab_rows(P->acap, sp.cout) * 3 * sp.cout;
+            if (lf > bslab_floats) bslab_floats = lf;
+        }
+        P->bslab[l] = (float *)A.take(bslab_floats * sizeof(float));
         P->dy[l] = rows_new(P->adt, P->odims[l], sp.cout);
         // data gradient buffer of the layer's input (shared where two consumers accumulate)
         P->dx[l] = Rows{};
@@ -328,12 +333,25 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
 }
 
 #define RT(call) do { int rc_ = (call); if (rc_ != VN_OK) return rc_; } while (0)
+// diagnostic VN_DUP (bit = VN_T_* kind): issue every launch of that kind TWICE — the step-time difference is the in-step
+// marginal cost of those launches on their dependency chain (only meaningful for the idempotent BatchNorm passes: kinds 3-6)
+static int dup_mask() {
+    static const int v = vn_knob("VN_DUP", 0);
+    return v;
+}
 // a launch of the executor, bracketed by timing events on ITS stream when the context is in timing mode
 #define RTT(kind, layer, flops, bytes, st, call) do {                                                           \
         vnTimeSlot *ts_ = nullptr;                                                                              \
         if (net->timing && !(ts_ = net->time_begin((kind), (layer), (double)(flops), (double)(bytes), vn_stream(st)))) \
             return VN_EINVAL;                                                                                   \
-        RT(call);                                                                                               \
+        {                                                                                                       \
+            const int rc_ = (call);                                                                             \
+            if (rc_ != VN_OK) {                                                                                 \
+                if (ts_) --net->t_used;   /* e1 was never recorded: drop the slot, vn_net_timing_read would fail on it */ \
+                return rc_;                                                                                     \
+            }                                                                                                   \
+        }                                                                                                       \
+        if (dup_mask() & (1 << (kind))) RT(call);   /* diagnostic VN_DUP: the launch twice (all BatchNorm kinds are idempotent) */ \
         if (ts_) VN_HIP(hipEventRecord(ts_->e1, vn_stream(st)));                                                \
     } while (0)
 
@@ -479,28 +497,27 @@ __global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
     for (int i = threadIdx.x; i < z.len[blockIdx.x]; i += 256) p[i] = 0.f;
 }
 
-// tuning aid: VN_M0_BN bit 0 flagged forward apply (measured SLOWER than the dense pass, 124 vs 86 us: a per-row flag test
-// in a streaming kernel; off), bit 1 flagged backward reduce (90 vs 102 us), bit 2 list-based backward apply (30 vs 87 us)
-// first middle layer (tuning aid VN_M0_BN, bits): 1 flagged forward apply, 2 flagged backward reduce, 4 list-based backward
-// apply, 8 the BatchNorm backward from the activation gradient at the active sites only (middle_layer.1's data gradient as
-// a row-list launch + box sums), 16 middle_layer.1's weight gradient from the active sites' rows a0 - const + a rank-1 term
+// First middle layer (tuning aid VN_M0_BN, bits; default 31 = all on): 1 flagged forward apply (k_bn_apply<true>: the ~90 %
+// of rows without a flag are written without reading y), 2 flagged backward reduce, 4 list-based backward apply, 8 the
+// BatchNorm backward from the activation gradient at the active sites only (middle_layer.1's data gradient as a row-list
+// launch + box sums), 16 middle_layer.1's weight gradient from the active sites' rows a0 - const + a rank-1 term
 int m0_bn_knob() {
-    static const int v = [] { const char *e = getenv("VN_M0_BN"); return e && *e ? atoi(e) : 31; }();
+    static const int v = vn_knob("VN_M0_BN", 31);
     return v;
 }
 
-// tuning aid VN_BOX_ZERO=1: take the sum of middle_layer.1's dy over all sites as zero (the BatchNorm identity) instead of
-// summing it (measured: 509.7 vs 508.7 point-clouds/s — not worth a shortcut that drops the rounding noise of dy)
 int heads_stream_on() {   // tuning aid VN_HEADS_STREAM=0: the heads through k_gather_gemm as before
-    static const int v = [] { const char *e = getenv("VN_HEADS_STREAM"); return e && *e ? atoi(e) : 1; }();
+    static const int v = vn_knob("VN_HEADS_STREAM", 1);
     return v;
 }
 int fuse_bwd_reduce_on() {   // tuning aid VN_FUSE_BWD_REDUCE=0: every BatchNorm backward reduction as its own launch
-    static const int v = [] { const char *e = getenv("VN_FUSE_BWD_REDUCE"); return e && *e ? atoi(e) : 1; }();
+    static const int v = vn_knob("VN_FUSE_BWD_REDUCE", 1);
     return v;
 }
+// tuning aid VN_BOX_ZERO=1: take the sum of middle_layer.1's dy over all sites as zero (the BatchNorm identity) instead of
+// summing it (measured: 509.7 vs 508.7 point-clouds/s — not worth a shortcut that drops the rounding noise of dy)
 int box_zero_total() {
-    static const int v = [] { const char *e = getenv("VN_BOX_ZERO"); return e && *e ? atoi(e) : 0; }();
+    static const int v = vn_knob("VN_BOX_ZERO", 0);
     return v;
 }
 int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, int relu, vnStream st) {
@@ -842,8 +859,8 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // So the FIRST layer's weight gradient runs on the main stream (behind its data gradient), and everything up to
     // block1 is unpacked on the side stream before it waits for middle_layer.2's dy (a ~180 us idle gap there): only
     // the three Conv3d gradients are left for the final unpack.
-    static const int m0_main_on = [] { const char *e = getenv("VN_M0_MAIN"); return e && *e ? atoi(e) : 1; }();
-    static const int early_unpack_on = [] { const char *e = getenv("VN_EARLY_UNPACK"); return e && *e ? atoi(e) : 1; }();
+    static const int m0_main_on = vn_knob("VN_M0_MAIN", 1);
+    static const int early_unpack_on = vn_knob("VN_EARLY_UNPACK", 1);
     const bool tail_balance = ws != hs && cfg->defer_join && !cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
     const bool bucket_mode = ws != hs && cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
     const bool m0_on_main = (tail_balance || bucket_mode) && m0_main_on;
@@ -943,7 +960,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             // sites only (a row-list launch into [acap][cin] rows) and its sum over all sites (box sums of dy)
             // (the box sums are only read by the first layer's finalize, ~120 us down this stream, and by the weight
             //  gradient's constant part on the side stream: with a side stream they run there, beside the row-list launch)
-            static const int box_side = [] { const char *e = getenv("VN_BOX_SIDE"); return e && *e ? atoi(e) : 1; }();
+            static const int box_side = vn_knob("VN_BOX_SIDE", 1);
             const bool box_on_side = box_side && ws != hs && !on_side && single_call;
             if (box_on_side) RT(fork());
             const vnStream bs = box_on_side ? wstream : ls;
@@ -992,7 +1009,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // whole backward is issued first, on the side stream, and overlaps the block3 / block2 chains (50x44 and 100x88
     // images: under-filled launches).  Their data gradient then WRITES the shared buffer and the strided block3.0 /
     // block2.0 data gradient accumulates into it (instead of the other way round).
-    static const int early_on = [] { const char *e = getenv("VN_EARLY_DECONV"); return e && *e ? atoi(e) : 1; }();   // tuning aid
+    static const int early_on = vn_knob("VN_EARLY_DECONV", 1);   // tuning aid
     const bool early = early_on && ws != hs && seg_begin == 0 && seg_end == NL + 1;
     hipEvent_t ev_d2 = nullptr, ev_d1 = nullptr;
     if (early) {

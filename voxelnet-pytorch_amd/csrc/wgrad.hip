@@ -589,7 +589,7 @@ static WGPlan wgrad_plan(const vnConv *g, int32_t split, int64_t M) {
     // slabs of 64 sites per chunk: more chunks only add partial-tile traffic (each chunk stores DN x DK x taps fp32
     // and the batched unpack reads it back), fewer leave CUs idle.  Measured in the full step: 128 / 192 / 256 / 384 /
     // 512 / 768 workgroups -> 357 / 368 / 373 / 370 / 368 / 364 point-clouds/s.
-    static const int target = [] { const char *e = getenv("VN_WG_BLOCKS"); return e && *e ? atoi(e) : 256; }();   // tuning aid
+    static const int target = vn_knob("VN_WG_BLOCKS", 256);   // tuning aid
     int64_t chunks = target / ((int64_t)w.groups * w.tiles_n * w.tiles_k);
     const int64_t slabs = vn_ceil_div(M, 64);
     if (chunks > slabs / 10) chunks = slabs / 10;
@@ -606,10 +606,7 @@ struct WPPlan {
     int64_t ntiles, chunks;
 };
 static int wgrad_patch_enabled() {   // tuning aid: VN_WGRAD_PATCH=0 keeps the row form, 2 = also small images
-    static const int v = [] {
-        const char *e = getenv("VN_WGRAD_PATCH");
-        return e && *e ? atoi(e) : 1;
-    }();
+    static const int v = vn_knob("VN_WGRAD_PATCH", 1);
     return v;
 }
 static WPPlan wgrad_patch_plan(const vnConv *g, int32_t split, bool list) {
@@ -629,7 +626,7 @@ static WPPlan wgrad_patch_plan(const vnConv *g, int32_t split, bool list) {
     w.ntiles = (int64_t)g->B * g->Dr * w.tiles_y * w.tiles_x;
     // (one workgroup per CU: in the step these launches run on the side stream beside the data gradients;
     //  128 ... 512 workgroups measure within 1 %, 768 is 3 % slower)
-    static const int ptarget = [] { const char *e = getenv("VN_WGP_BLOCKS"); return e && *e ? atoi(e) : 256; }();   // tuning aid
+    static const int ptarget = vn_knob("VN_WGP_BLOCKS", 256);   // tuning aid
     int64_t chunks = ptarget / ((int64_t)g->kD * w.tiles_n * w.tiles_k);
     if (chunks > w.ntiles / 8) chunks = w.ntiles / 8;
     if (chunks > 256) chunks = 256;

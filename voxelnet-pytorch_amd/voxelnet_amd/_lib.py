@@ -14,7 +14,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvoxelnet_hip.so")
+# VN_LIB_PATH: another build of the library (tools/ab_bench.sh: interleaved A/B of two builds inside one gpurun call)
+LIB_PATH = os.environ.get("VN_LIB_PATH") or os.path.join(_HERE, "lib", "libvoxelnet_hip.so")
 
 c_i32, c_i64, c_f32, c_vp, c_sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
 
@@ -90,6 +91,7 @@ SIGNATURES = {
                                  c_vp, c_vp, c_sz, c_vp]),
     "vn_vfe_layer_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_sz, c_vp]),
+    "vn_comm_rccl_version": (c_i32, []),
     "vn_comm_unique_id": (c_i32, [c_vp]),
     "vn_comm_create": (c_i32, [_P(c_vp), c_vp, c_i32, c_i32]),
     "vn_comm_destroy": (c_i32, [c_vp]),

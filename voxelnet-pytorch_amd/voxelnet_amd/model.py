@@ -575,7 +575,9 @@ class _DetectorFn(torch.autograd.Function):
             vparams = flat[:nv]
         else:
             vparams = [p.detach() for p in flat[:nv]]
-        native = rpn.native_executor and not E.is_split(mode) and fn._grid.D == 10
+        native = rpn._native_ok(mode)
+        if ctx.anchor and not native:
+            raise _lib.VoxelnetHipError("internal: the one-tensor (anchor) call needs the native executor (RPN3D._native_ok)")
         if not native:          # (the per-launch Python orchestration works on name -> tensor dicts)
             names, P, Bf, _ = _collect_middle(mid)
             P = _detached(P)
@@ -1047,13 +1049,19 @@ class RPN3D(nn.Module):
         feature = (voxel_features[0] if bs == 1 else torch.cat(list(voxel_features), dim=0)).contiguous().float()
         coord = (voxel_coordinates[0] if bs == 1 else torch.cat(list(voxel_coordinates), dim=0)).contiguous().long()
         flat = self._flat_params()
-        if (self.native_executor and self.direct_grads and torch.is_grad_enabled() and feature.is_cuda
-                and not E.is_split(_mode()) and self._all_need_grad(flat)):
+        if (self._native_ok(_mode()) and self.direct_grads and torch.is_grad_enabled() and feature.is_cuda
+                and self._all_need_grad(flat)):
             prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, self._anchor(feature.device))
         else:
             prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, *flat)
         self._tick()
         return prob, reg
+
+    def _native_ok(self, mode):
+        """ONE predicate for "this call runs on the native executor" (csrc/runtime.hip: D = 10 grids, bf16 / fp32 modes), used
+        by detect() to pick the one-tensor call and by _DetectorFn.forward to pick the path: every other configuration
+        (bf16x3, D != 10) trains through the per-layer orchestration with the 104 parameters as autograd inputs."""
+        return bool(self.native_executor) and not E.is_split(mode) and self.feature_net._grid.D == 10
 
     def _all_need_grad(self, flat):
         return all(p.requires_grad for p in flat)

@@ -33,7 +33,7 @@ class ClipSGD(torch.optim.Optimizer):
         self._key = None
         self._table = self._ws = self._norm = None
         self._n_chunks = 0
-        self._plist = self._last_grads = None
+        self._plist = self._last_grads = self._last_pptrs = None
 
     # (kept for callers of the round-1 class)
     @property
@@ -57,7 +57,7 @@ class ClipSGD(torch.optim.Optimizer):
         self._key = None                  # device chunk table / workspace: rebuilt on the first step
         self._table = self._ws = self._norm = None
         self._n_chunks = 0
-        self._plist = self._last_grads = None
+        self._plist = self._last_grads = self._last_pptrs = None
 
     def zero_grad(self, set_to_none=True):
         """torch.optim.Optimizer.zero_grad without its per-parameter foreach bookkeeping (104 small tensors)"""
@@ -68,7 +68,7 @@ class ClipSGD(torch.optim.Optimizer):
 
     def add_param_group(self, group):
         super().add_param_group(group)
-        self._plist = self._last_grads = None
+        self._plist = self._last_grads = self._last_pptrs = None
 
     def _build(self, pairs, dev):
         rows = []
@@ -95,9 +95,11 @@ class ClipSGD(torch.optim.Optimizer):
         if plist is None:
             plist = self._plist = self.params
         last = self.__dict__.get("_last_grads")
-        if last is not None and self._table is not None and all(p.grad is g for p, g in zip(plist, last)):
-            # the same gradient tensors as in the previous step (the model's flat buffer / bucket views): the chunk table
-            # is still valid, nothing to rebuild or re-check
+        if (last is not None and self._table is not None and all(p.grad is g for p, g in zip(plist, last))
+                and self._last_pptrs == [p.data_ptr() for p in plist]):
+            # the same gradient tensors as in the previous step (the model's flat buffer / bucket views) and the same
+            # parameter storage (a `p.data = ...` / `set_()` swap keeps the Parameter object but not its memory): the chunk
+            # table of raw pointers is still valid, nothing to rebuild or re-check
             with torch.cuda.device(self._table.device):
                 stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
                 from . import engine as E
@@ -120,6 +122,7 @@ class ClipSGD(torch.optim.Optimizer):
             self._key = key
         self._n_elems = sum(p.numel() for p, _ in pairs)
         self._last_grads = [p.grad for p in plist] if len(pairs) == len(plist) else None
+        self._last_pptrs = [p.data_ptr() for p in plist]
         with torch.cuda.device(dev):
             stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
             from . import engine as E

@@ -94,11 +94,18 @@ class GradAllReducer:
         self.comm = h
 
     def close(self):
+        """destroy the direct path's communicator (idempotent; also run by __del__ and by bench.py at exit)"""
         if self.comm is not None:
             from . import _lib
             torch.cuda.synchronize()
             _lib.load().vn_comm_destroy(self.comm)
             self.comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:   # noqa: BLE001 - interpreter shutdown
+            pass
 
     def _reduce(self, b):
         """mean over the ranks of bucket b, in place, on the CURRENT stream; returns a work handle or None"""

@@ -193,20 +193,13 @@ def prepare_voxel(voxels):
 
 
 def collate_fn(parts):
-    """dataset.py:70-97: batch 5-tuples (tag, rgb, raw_lidar, label, voxel dict) into the
-    reference's 7-tuple."""
-    tag = [p[0] for p in parts]
-    rgb = [p[1] for p in parts]
-    raw_lidar = [p[2] for p in parts]
-    label = [p[3] for p in parts]
-    voxel = [p[4] for p in parts]
-    voxel_features, voxel_numbers, voxel_coordinates = prepare_voxel(voxel)
-    return (
-        tag,
-        np.array(label, dtype=object),
-        [torch.from_numpy(f) for f in voxel_features],
-        np.array(voxel_numbers, dtype=object),
-        [torch.from_numpy(c) for c in voxel_coordinates],
-        np.array(rgb, dtype=object),
-        np.array(raw_lidar, dtype=object),
-    )
+    """dataset.py:70-97: a list of dataset items (tag, rgb, raw_lidar, label, voxel dict) -> the reference's batch 7-tuple
+    (tags, labels, [feature tensors], numbers, [coordinate tensors (K,4)], rgb, raw_lidar); the per-sample host arrays
+    travel as object arrays, the voxel buffers as torch tensors."""
+    tags, rgbs, clouds, labels, voxels = (list(column) for column in zip(*parts))
+    feats, counts, coords = prepare_voxel(voxels)
+
+    def ragged(seq):
+        return np.array(seq, dtype=object)
+    return (tags, ragged(labels), [torch.from_numpy(f) for f in feats], ragged(counts),
+            [torch.from_numpy(c) for c in coords], ragged(rgbs), ragged(clouds))
