@@ -14,6 +14,12 @@ point clouds are already resident in HBM:
 (ped: the reference's loss cannot run for Pedestrian / Cyclist — its anchor grid does not match the network's output,
 SURVEY.md 8a-a8 — so the backward starts from a fixed seeded upstream gradient)
 
+Targets: by default every timed step generates the RPN targets from the frames' label lines ON THE DEVICE inside the step
+(model.py:309 is part of RPN3D.forward in the reference too); --precomputed-targets takes seeded target maps instead (the
+round-1/2 behaviour; the default run also reports that rate as `value_precomputed_targets`).
+The timed region of `--steps` steps is the headline (`value`); it is repeated `--windows` - 1 more times in the same run and
+`value_min / value_median / value_max` give the spread over all windows (box-to-box variance on this pool is larger).
+
 Rank 0 prints ONE JSON line.
   roofline      the dominant kernel family — the implicit-GEMM convolutions (k_conv_patch + k_gather_gemm: forward and data
                 gradient of every layer) — measured live: HIP events around every launch ON THE STREAM IT IS LAUNCHED ON,
@@ -136,6 +142,11 @@ def main():
                     help="diagnostic: run the DDP bucket path (flat buckets, bucket events) on one GPU")
     ap.add_argument("--static-voxels", action="store_true",
                     help="diagnostic: voxelize once, outside the timed steps (NOT the benchmark configuration)")
+    ap.add_argument("--precomputed-targets", action="store_true",
+                    help="seeded target maps instead of generating the RPN targets from label lines inside every step")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of --steps steps each (the first is the headline)")
+    ap.add_argument("--direct-rccl", action="store_true",
+                    help="N > 1: all-reduce through the library's own RCCL wrapper (vn_allreduce_bucket) instead of torch.distributed")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -188,7 +199,7 @@ def main():
         for p in params:
             dist.broadcast(p.data, 0)
     if world > 1 or args.force_reducer:
-        model.grad_reducer = parallel.GradAllReducer(named)
+        model.grad_reducer = parallel.GradAllReducer(named, direct_rccl=True if args.direct_rccl else None)
 
     frames_np = synth.workload_frames(workload_id, batch=B, frame0=rank * B)   # weak scaling: own frames per rank
     frames = [torch.from_numpy(f).to(dev) for f in frames_np]                  # resident in HBM before timing
@@ -201,6 +212,13 @@ def main():
         return None, (torch.from_numpy((rng.standard_normal((B, 2, hf, wf)) * 1e-3).astype(np.float32)).to(dev),
                       torch.from_numpy((rng.standard_normal((B, 14, hf, wf)) * 1e-3).astype(np.float32)).to(dev))
     targets, upstream = make_targets()
+    # label lines of this rank's frames (six boxes of the class + a DontCare line each): the default step turns them into
+    # targets on the device (voxelnet_amd/targets.py -> vn_rpn_targets), as model.py:309 does inside RPN3D.forward
+    labels = np.empty(B, dtype=object)
+    for b in range(B):
+        labels[b] = synth.synth_labels(cls, 6, seed=7000 + rank * B + b)
+    gen_targets = with_loss and not args.precomputed_targets
+    mode = {"gen": gen_targets}
 
     # Voxelization is software-pipelined one step ahead on its own HIP stream (the input-pipeline stage of the step): the
     # K read-back that sizes its outputs (utils.py:69-71 returns (K,T,7)/(K,3)/(K,) arrays) never stalls the training
@@ -248,7 +266,10 @@ def main():
     def fwd_bwd(feats, coords):
         m = state["model"]
         if with_loss:
-            out = m((None, None, feats, None, coords, None, None), dev, targets=targets)
+            if mode["gen"]:
+                out = m((None, labels, feats, None, coords, None, None), dev)          # targets from the labels, on the device
+            else:
+                out = m((None, None, feats, None, coords, None, None), dev, targets=targets)
             out[2].backward()                                              # train.py:151
             return out[2]
         prob, reg = m.detect(feats, coords)
@@ -266,7 +287,14 @@ def main():
             slot_free[si] = ev
         m = state["model"]
         if m.grad_reducer is not None:
-            m.grad_reducer.finish(state["named"])
+            if state.get("exposed") is not None:       # (N > 1 diagnostic steps only: how long the main stream waits for the reducer)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                m.grad_reducer.finish(state["named"])
+                e1.record()
+                state["exposed"].append((e0, e1))
+            else:
+                m.grad_reducer.finish(state["named"])
         if args.torch_optim:
             torch.nn.utils.clip_grad_norm_(state["params"], GRADIENT_CLIP)  # train.py:153
         state["opt"].step()                                                # train.py:154 (ClipSGD: both lines)
@@ -293,15 +321,38 @@ def main():
     t_enq = time.perf_counter() - t0       # host time to enqueue the K steps (the GPU may still be running)
     sync_all()
     dt = time.perf_counter() - t0
+    # ---- the spread: the same timed region again, --windows - 1 times (every rank: a step holds the collectives)
+    window_dts = [dt]
+    for _ in range(max(0, args.windows - 1)):
+        sync_all()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            step_eager()
+        sync_all()
+        window_dts.append(time.perf_counter() - tw)
+    dt_pre = None
+    if gen_targets:                      # the same window with precomputed target maps (what rounds 1-2 timed)
+        mode["gen"] = False
+        for _ in range(2):
+            step_eager()
+        sync_all()
+        tw = time.perf_counter()
+        for _ in range(args.steps):
+            step_eager()
+        sync_all()
+        dt_pre = time.perf_counter() - tw
+        mode["gen"] = True
     if step_events and rank == 0:
         print("[bench] per-step ms:", " ".join(f"{a.elapsed_time(b):.2f}" for a, b in zip(step_events, step_events[1:])),
               file=sys.stderr)
     assert torch.isfinite(loss).item(), "non-finite loss"
     ranks_in_sync, grad_checksums_equal = None, None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt, dt_pre or 0.0] + window_dts, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        dt_pre = float(t[1].item()) if dt_pre is not None else None
+        window_dts = [float(v) for v in t[2:].tolist()]
         # self-check of the data-parallel path (outside the timed region): every rank started from rank 0's weights
         # and applied the same averaged gradients, so the parameters must still be bit-identical on all ranks ...
         with torch.no_grad():
@@ -332,6 +383,22 @@ def main():
     host_free = 1e3 * sorted(samples)[len(samples) // 2]
     sync_all()
 
+    # ---- N > 1: how long the main stream waits for the gradient exchange at the end of a step (the part of the bucketed
+    #      all-reduce that the backward did not hide), HIP events around GradAllReducer.finish on the training stream
+    exposed_ms = None
+    if model.grad_reducer is not None:
+        state["exposed"] = []
+        for _ in range(10):
+            step_eager()
+        torch.cuda.synchronize()
+        ex = sorted(a.elapsed_time(b) for a, b in state["exposed"])
+        state["exposed"] = None
+        t = torch.tensor([ex[len(ex) // 2]], dtype=torch.float64, device=dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        exposed_ms = float(t.item())
+        sync_all()
+
     # ---- per-kernel durations: the native executor's own HIP events around every launch (same path as the timed region),
     #      torch events around the launch groups the Python side issues (voxelizer, VFE, loss, optimizer)
     recs, sect = None, None
@@ -353,25 +420,46 @@ def main():
         sync_all()
         E.SECTIONS = None
 
-    # ---- the same step in the fp32 parity mode (the mode the <= 1e-3 parity tests run in), a few steps
+    # ---- the same step in the fp32 parity mode (the mode the <= 1e-3 parity tests run in) and in bf16x3, a few steps each,
+    #      and how far the three modes' RPN maps are apart on this batch (same weights: the seed of build_model)
     parity = None
     if rank == 0 and world == 1 and args.precision == "bf16" and not args.no_parity_mode:
-        pm = build_model("fp32")
-        state.update(model=pm, params=list(pm.parameters()), named=list(pm.named_parameters()),
-                     opt=ClipSGD(list(pm.parameters()), LR, GRADIENT_CLIP))
-        for _ in range(2):
-            step_eager()
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for _ in range(5):
-            step_eager()
-        torch.cuda.synchronize()
-        tpe = time.perf_counter() - tp
-        parity = {"dtype": "f32", "value": B * 5 / tpe, "unit": "point-clouds/s", "ms_per_step": 1e3 * tpe / 5,
-                  "note": "fp32 operands on v_mfma_f32_16x16x4_f32: the mode of the <= 1e-3 parity tests"}
-        state.update(model=model, params=params, named=named, opt=opt)
+        feats0, coords0 = voxelize_batch()
+        maps = {}
+
+        def maps_of(m_):
+            with torch.no_grad():
+                pr, rg = m_.detect(feats0, coords0)
+            torch.cuda.synchronize()
+            return pr.double(), rg.double()
+        maps["bf16"] = maps_of(build_model("bf16"))
+        parity = {}
+        for prec, nsteps, note in (("fp32", 5, "fp32 operands on v_mfma_f32_16x16x4_f32: the mode of the <= 1e-3 parity tests"),
+                                   ("bf16x3", 3, "[hi|lo] bf16 operand pairs, three bf16 MFMA products per fp32 product; per-layer "
+                                                 "orchestration from Python (not the native executor: host-bound)")):
+            pm = build_model(prec)
+            maps[prec] = maps_of(pm)
+            state.update(model=pm, params=list(pm.parameters()), named=list(pm.named_parameters()),
+                         opt=ClipSGD(list(pm.parameters()), LR, GRADIENT_CLIP))
+            for _ in range(2):
+                step_eager()
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for _ in range(nsteps):
+                step_eager()
+            torch.cuda.synchronize()
+            tpe = time.perf_counter() - tp
+            parity[prec] = {"dtype": {"fp32": "f32"}.get(prec, prec), "value": B * nsteps / tpe, "unit": "point-clouds/s",
+                            "ms_per_step": 1e3 * tpe / nsteps, "note": note}
+            state.update(model=model, params=params, named=named, opt=opt)
+            del pm
         M.set_precision(args.precision)
-        del pm
+        for prec in ("bf16", "bf16x3"):
+            (pa, ra), (pb, rb) = maps[prec], maps["fp32"]
+            err = {"prob_max_over_max": float((pa - pb).abs().max() / pb.abs().max()), "prob_rel_l2": float((pa - pb).norm() / pb.norm()),
+                   "reg_max_over_max": float((ra - rb).abs().max() / rb.abs().max()), "reg_rel_l2": float((ra - rb).norm() / rb.norm())}
+            (parity[prec] if prec in parity else parity.setdefault("bf16", {}))["map_error_vs_fp32"] = err
+        parity["value"], parity["dtype"], parity["ms_per_step"] = parity["fp32"]["value"], "f32", parity["fp32"]["ms_per_step"]
 
     if rank == 0:
         value = world * B * args.steps / dt
@@ -379,16 +467,21 @@ def main():
         metric = "point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2"
         if args.config != "car":
             metric = "point-clouds/sec fwd+bwd, %s, batch=%d" % (cfg_desc, B)
+        vals = sorted(world * B * args.steps / w for w in window_dts)
         res = {
             "metric": metric,
             "value": value, "unit": "point-clouds/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # the spread over --windows timed regions of --steps steps in this run (the first one is `value`)
+            "value_min": vals[0], "value_median": vals[len(vals) // 2], "value_max": vals[-1], "windows": len(vals),
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
             "config": {"workload": "%s, batch=%d per GPU, fwd+bwd train step (BASELINE configs[%d])" % (cfg_desc, B, cfg_index),
                        "global_batch": world * B, "points_per_frame": int(frames_np[0].shape[0]),
                        "parallelism": "dp%d" % world,
                        "step": "voxelize+VFE+scatter+Conv3d+RPN fwd, %s, bwd, clip_grad_norm, SGD"
-                               % ("loss" if with_loss else "seeded upstream gradient (the reference's loss is undefined for this class)"),
+                               % (("RPN targets from the label lines (device) + loss" if gen_targets else "loss on precomputed target maps")
+                                  if with_loss else "seeded upstream gradient (the reference's loss is undefined for this class)"),
+                       "with_target_generation": bool(gen_targets),
                        "launch_mode": "eager" + ("+native-executor" if model.native_executor else "")},
             # un-throttled: one step enqueued into an empty queue (what the host needs); in_loop: the timed loop's enqueue
             # time, which the GPU paces through queue back-pressure
@@ -396,6 +489,17 @@ def main():
             # dense-equivalent model FLOPs (the first Conv3d's skipped zeros NOT subtracted) over the whole step
             "model_flops_fraction_of_peak": value / world * FLOP_PER_PC[args.config] / (peak * 1e12),
         }
+        res["library"] = _lib.load().vn_build_info().decode()       # build + every VN_* tuning override in effect
+        if dt_pre is not None:
+            res["value_precomputed_targets"] = world * B * args.steps / dt_pre
+        if model.grad_reducer is not None:
+            red = model.grad_reducer
+            res["allreduce"] = {"exposed_ms_per_step": exposed_ms, "bucket_bytes": [int(b["flat"].numel() * 4) for b in red.buckets],
+                                "path": "vn_allreduce_bucket (library RCCL wrapper)" if red.comm is not None else "torch.distributed (%s)" % (dist.get_backend() if world > 1 else "world 1: no collective"),
+                                "rccl_version_bound_by_library": int(_lib.load().vn_comm_rccl_version()),
+                                "torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+                                "note": "exposed = median time the training stream waits in GradAllReducer.finish (HIP events, 10 steps, "
+                                        "MAX over ranks): the part of the 4-bucket all-reduce the backward did not hide"}
         if ranks_in_sync is not None:
             res["ranks_in_sync"] = ranks_in_sync       # parameters bit-identical on all ranks after the timed steps
             res["grad_checksums_equal"] = grad_checksums_equal
@@ -456,15 +560,12 @@ def main():
                             "the row-list data gradients at its active sites — with the FLOPs they execute) / summed "
                             "HIP-event time of every launch of the family, events on the launch's own stream inside the "
                             "native executor, %d steps on the same inputs right after the timed region" % args.timer_steps}
-                # the family's largest single symbol: the 6x32-pixel Conv3d tiles (car / dense: middle_layer.1 and .2 forward,
-                # middle_layer.2 data gradient)
-                big = [(ms, fl) for kind, layer, ms, fl, by in recs if (kind == 0 and layer in (1, 2)) or (kind == 1 and layer == 2)]
-                if big:
-                    tb, fb = sum(m for m, _ in big), sum(f_ for _, f_ in big)
-                    res["roofline"]["largest_symbol"] = {
-                        "kernel": "k_conv_patch<4,1,3,32> (64-channel Conv3d layers, 6x32-pixel tiles)",
-                        "launches_per_step": len(big) / ns, "ms_per_step": tb / ns, "achieved": fb / (tb * 1e-3) / 1e12,
-                        "frac": fb / (tb * 1e-3) / 1e12 / peak}
+                # the other MFMA family: the weight gradients (side stream)
+                if 2 in fam:
+                    nw, tw_, fw_, _ = fam[2]
+                    res["roofline_wgrad"] = {"kernel": "k_wgrad / k_wgrad_patch (weight gradients)", "bound": "mfma",
+                                             "achieved": fw_ / (tw_ * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
+                                             "frac": fw_ / (tw_ * 1e-3) / 1e12 / peak, "launches_per_step": nw / ns, "ms_per_step": tw_ / ns}
                 # FLOPs the MFMA pipes actually execute in a step (first layer: rulebook, not dense-equivalent)
                 fx = sum(fam.get(k, (0, 0, 0, 0))[2] for k in (0, 1, 2)) / ns
                 res["executed_mfma_flops_fraction_of_peak"] = fx / (1e-3 * res["ms_per_step"]) / (peak * 1e12)
@@ -480,6 +581,8 @@ def main():
                 ncpu = os.cpu_count() or 1
             res["cpu_baseline"] = cpu_baseline(frames_np, cls, T, max(1, min(ncpu, 16)))   # a 1-GPU box's CPU share is 16
         print(json.dumps(res))
+    if model.grad_reducer is not None:
+        model.grad_reducer.close()          # (the direct path's RCCL communicator)
     if world > 1:
         dist.destroy_process_group()
 

@@ -322,6 +322,20 @@ int vn_unpack_wgrads_batch(const vnUnpackJob *jobs /* host array */, int32_t n, 
 
 
 /* ------------------------------------------------------------------------
+ * Camera field-of-view crop of a raw Velodyne sweep — voxelnet/preprocess_data.py:42-103 (prepare_velo_points,
+ * project_velo_to_img and the in-image test of align_img_and_velo; main() rewrites the .bin files with the survivors,
+ * :151-154), SURVEY.md 8(f)-3.  points (n,4) fp32 [x,y,z,reflectance] on the device; P_3x4 / Tr_velo_to_cam_4x4 /
+ * R_rect_4x4: HOST pointers to the float32 matrices load_calib returns (row-major).  A point survives when reflectance
+ * > 0, its rectified camera z >= 0 and its rounded pixel satisfies 0 < col < image_cols, 0 < row < image_rows (float32
+ * arithmetic, np.round = round half to even).  out_points (capacity n rows) receives the survivors in input order,
+ * out_index (n int32, may be NULL) their input row numbers, *out_count (device int32) their number.  Asynchronous.
+ * ---------------------------------------------------------------------- */
+size_t vn_fov_crop_workspace_bytes(int64_t n);
+int vn_fov_crop(const float *points, int64_t n, const float *P_3x4, const float *Tr_velo_to_cam_4x4,
+                const float *R_rect_4x4, int32_t image_rows, int32_t image_cols, float *out_points,
+                int32_t *out_index, int32_t *out_count, void *workspace, size_t workspace_bytes, vnStream stream);
+
+/* ------------------------------------------------------------------------
  * Native step executor — MiddleConvNet.forward (model.py:257-281) and its backward as ONE call
  * each (csrc/runtime.hip): layer table, launch geometry and workspace arena live in C++, so the
  * ~450 launches of a step cost microseconds of host time instead of a Python round trip each.

@@ -192,3 +192,50 @@ def test_dense_config_vfe_full_K_and_train_step():
     print(f"dense config: one bf16 train step at batch 4, loss {float(out[2]):.4f}, |g| {float(norm):.3f}, "
           f"peak device memory {peak:.1f} GiB")
     assert peak < 48.0
+
+
+def test_dense_config_fp32_step_vs_oracle():
+    """BASELINE configs[4] at batch 1 (one ~300k-point frame, K ~ 40k voxels, T = 64) as a WHOLE step in the fp32 parity
+    mode against the CPU oracle: at this voxel count the native executor leaves the sparse routes of the first layer's
+    boundary (the active-site list would cover every site: csrc/runtime.hip make_plan, `acap * 10 <= M * 3`) and runs
+    middle_layer.1's data / weight gradient and middle_layer.0's BatchNorm backward DENSE — the route the car / ped
+    fixtures never take.  Maps <= 1e-3 (BASELINE.json); gradients: relative L2 <= 0.1 like test_car_full_backward (the
+    reference's own fp32-vs-fp64 band), the first layers and the VFE — everything downstream of that boundary — printed."""
+    from voxelnet_amd import model as M
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import grid_config
+    torch.cuda.empty_cache()
+    grid = grid_config("Car", T=64)
+    frames = synth.workload_frames(5, batch=1)
+    feats, coords = voxelize_frames(frames, grid)
+    K = feats[0].shape[0]
+    assert 30000 < K <= 40000 and feats[0].shape[1:] == (64, 7)
+    rng = np.random.default_rng(78)
+    dp = torch.from_numpy((rng.standard_normal((1, 2, 200, 176)) * 1e-2).astype(np.float32))
+    dr = torch.from_numpy((rng.standard_normal((1, 14, 200, 176)) * 1e-2).astype(np.float32))
+    rp, rr, ref = tr.forward_backward([f.cpu() for f in feats], [c.cpu() for c in coords], tr.make_state_dict("Car"),
+                                      (10, 400, 352), "Car", dp, dr)
+    M.set_precision("fp32")
+    m = M.RPN3D("Car")
+    m.load_state_dict(tr.make_state_dict("Car"))
+    m.feature_net._grid = grid
+    m = m.to(DEV).train()
+    prob, reg = m.detect(feats, coords)
+    ep, er = rel_err(prob, rp), rel_err(reg, rr)
+    print(f"dense config, batch 1, fp32 mode vs CPU oracle: K = {K}, prob {ep:.2e}, reg {er:.2e}")
+    assert ep < 1e-3 and er < 1e-3, (ep, er)
+    torch.autograd.backward([prob, reg], [dp.to(DEV), dr.to(DEV)])
+    torch.cuda.synchronize()
+    worst = (None, 0.0)
+    for k, p in m.named_parameters():
+        if k.endswith("conv.bias") and "prob_conv" not in k and "reg_conv" not in k or k.endswith("deconv.bias"):
+            continue
+        r = ref[k].double()
+        l2 = float((p.grad.double().cpu() - r).norm() / (r.norm() + 1e-30))
+        if k.startswith("feature_net") or "middle_layer" in k:
+            print(f"   {k:50s} rel L2 {l2:.2e}")
+        if l2 > worst[1]:
+            worst = (k, l2)
+    print("dense config, batch 1: worst gradient", worst)
+    assert worst[1] < 0.1, worst
+    M.set_precision("bf16")

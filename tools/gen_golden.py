@@ -18,6 +18,7 @@ Fixture families:
   car_full        one full-size car frame: K, checksums, map lattice
   targets         utils.generate_anchors / generate_targets on seeded KITTI label lines (stored sparsely)
   predict         utils.deltas_to_boxes_3d + model.filter_boxes (score filter, stand-up boxes, nms) on seeded maps
+  fov_crop        preprocess_data.align_img_and_velo (the camera field-of-view crop) on a bundled KITTI frame
   trajectory      20 iterations of the train loop (train.py:148-155) on the tiny grid: labels -> generate_targets ->
                   loss -> backward -> clip_grad_norm_(5) -> SGD(0.01); per-step loss scalars, final parameter digests
 """
@@ -440,6 +441,46 @@ def gen_predict():
     save("predict_car", **out)
 
 
+# ------------------------------------------------------------------ camera field-of-view crop
+def gen_fov():
+    """preprocess_data.align_img_and_velo (preprocess_data.py:62-103) called on every 6th point of the bundled raw frame
+    0000000000.bin with a KITTI object-format calibration file (the mean calibration of config.py:102-127 as text) and a
+    375 x 1242 image — through temporary files, exactly as main() drives it; plus points placed on the decision boundaries
+    (zero / negative reflectance, behind the camera, projections next to the image border)."""
+    import tempfile
+    from PIL import Image
+    import preprocess_data as ref_pre  # noqa: E402  (reference)
+    rows, cols = 375, 1242
+    raw = np.fromfile("/root/reference/data/2011_09_26/2011_09_26_drive_0001_sync/velodyne_points/data/0000000000.bin",
+                      dtype=np.float32).reshape(-1, 4)[::6].copy()
+    rng = np.random.default_rng(31)
+    extra = np.stack([rng.uniform(2, 60, 400), rng.uniform(-40, 40, 400), rng.uniform(-2.5, 1.0, 400), rng.uniform(0, 1, 400)], 1)
+    extra[:40, 3] = 0.0                       # reflectance exactly 0: dropped (> 0)
+    extra[40:60, 3] = -0.5
+    extra[60:120, 0] = rng.uniform(-30, 0.3, 60)      # behind / next to the camera plane
+    pts = np.concatenate([raw, extra.astype(np.float32)], 0).astype(np.float32)
+    pts = pts[rng.permutation(pts.shape[0])]
+    c = ref_model.cfg.CALIB
+    P2 = np.array(c.MATRIX_P2)[:3]
+    T = np.array(c.T_VELO_2_CAM)[:3]
+    R = np.array(c.R_RECT_0)[:3, :3]
+
+    def fmt(name, a):
+        return name + ": " + " ".join(f"{v:.12e}" for v in np.asarray(a).reshape(-1))
+    with tempfile.TemporaryDirectory() as d:
+        pc, ca, im = os.path.join(d, "000000.bin"), os.path.join(d, "000000.txt"), os.path.join(d, "000000.png")
+        pts.tofile(pc)
+        with open(ca, "w") as fh:          # KITTI object calib: P0..P3, R0_rect, Tr_velo_to_cam, Tr_imu_to_velo (load_calib drops the last line)
+            fh.write("\n".join([fmt("P0", P2), fmt("P1", P2), fmt("P2", P2), fmt("P3", P2), fmt("R0_rect", R), fmt("Tr_velo_to_cam", T),
+                                fmt("Tr_imu_to_velo", T)]) + "\n")
+        Image.fromarray(np.zeros((rows, cols, 3), dtype=np.uint8)).save(im)
+        out = ref_pre.align_img_and_velo(im, pc, ca)
+        P, Tr, Rr = ref_pre.load_calib(ca)
+    kept = out[:, :4].astype("float32")                  # what main() writes back (preprocess_data.py:153)
+    save("fov_crop", points=pts, P=P, Tr=Tr, R=Rr, image_shape=np.array([rows, cols]), kept=kept,
+         pixels=out[:, 7:9].astype(np.float32))
+    print(f"   fov crop: {pts.shape[0]} points -> {kept.shape[0]} kept")
+
 # ------------------------------------------------------------------ train-loop trajectory
 TRAJ_STEPS, TRAJ_H, TRAJ_W = 20, 48, 48
 TRAJ_ORDER = [(0, 2, 3)[it % 3] for it in range(TRAJ_STEPS - 1)] + [1]      # batch of iteration it
@@ -570,6 +611,6 @@ def gen_trajectory():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
-    which = sys.argv[1:] or ["voxelize", "featnet", "layers", "middle", "rpn3d", "car_full", "targets", "predict", "trajectory"]
+    which = sys.argv[1:] or ["voxelize", "featnet", "layers", "middle", "rpn3d", "car_full", "targets", "predict", "trajectory", "fov"]
     for name in which:
         globals()["gen_" + name]()

@@ -91,6 +91,8 @@ SIGNATURES = {
                                  c_vp, c_vp, c_sz, c_vp]),
     "vn_vfe_layer_bwd": (c_i32, [c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,
                                  c_sz, c_vp]),
+    "vn_fov_crop_workspace_bytes": (c_sz, [c_i64]),
+    "vn_fov_crop": (c_i32, [c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "vn_comm_rccl_version": (c_i32, []),
     "vn_comm_unique_id": (c_i32, [c_vp]),
     "vn_comm_create": (c_i32, [_P(c_vp), c_vp, c_i32, c_i32]),

@@ -64,12 +64,18 @@ class DeviceCollate:
     feature (K_i,T,7) f32, number (K_i,) i64, coordinate (K_i,4) i64 [b,z,y,x].  Must run in the process that owns the
     GPU (not in a DataLoader worker)."""
 
-    def __init__(self, device="cuda:0", target="Car", shuffle_points=True):
+    def __init__(self, device="cuda:0", target="Car", shuffle_points=True, fov_calib_dir=None, image_shape=(375, 1242)):
+        """fov_calib_dir: RAW sweeps — crop every cloud to the camera field of view on the device before it is voxelized
+        (the reference does this offline, preprocess_data.py:42-154, and trains on the rewritten .bin files):
+        `<fov_calib_dir>/<tag>.txt` is the sample's KITTI object calibration file, the image size is the sample's image's
+        (or image_shape when images are not loaded).  The crop keeps the input order, so shuffling the raw cloud first
+        still hands the voxelizer a uniformly shuffled cropped cloud."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise _lib.VoxelnetHipError("DeviceCollate needs a HIP device (no CPU path)")
         self.grid = grid_config("Car" if target == "Car" else "Pedestrian")    # utils.py:24-33 ('Car' else ped/cyc)
         self.shuffle_points = shuffle_points
+        self.fov_calib_dir, self.image_shape = fov_calib_dir, tuple(image_shape)
         self.stream = torch.cuda.Stream(device=self.device)
 
     def launch(self, parts):
@@ -82,6 +88,11 @@ class DeviceCollate:
                     np.random.shuffle(pcl)                                     # utils.py:35, in place like the reference
                 host = torch.from_numpy(np.ascontiguousarray(pcl[:, :4], dtype=np.float32)).pin_memory()
                 pts = host.to(self.device, non_blocking=True)
+                if self.fov_calib_dir is not None:
+                    from .fov import fov_crop_device, load_calib
+                    P, Tr, R = load_calib(os.path.join(self.fov_calib_dir, str(p[0]) + ".txt"))
+                    rows, cols = p[1].shape[:2] if p[1] is not None else self.image_shape
+                    pts = fov_crop_device(pts, P, Tr, R, rows, cols)
                 handles.append((voxelize_device_async(pts, self.grid, b, coord_cols=4), pts, host))
         return parts, handles
 
@@ -110,9 +121,9 @@ class DeviceBatcher:
     device-resident 7-tuples, one batch ahead: while the model trains on batch i, batch i+1 is being copied and
     voxelized on the pipeline's own stream."""
 
-    def __init__(self, loader, device="cuda:0", target="Car", shuffle_points=True):
+    def __init__(self, loader, device="cuda:0", target="Car", shuffle_points=True, fov_calib_dir=None, image_shape=(375, 1242)):
         self.loader = loader
-        self.collate = DeviceCollate(device, target, shuffle_points)
+        self.collate = DeviceCollate(device, target, shuffle_points, fov_calib_dir, image_shape)
 
     def __len__(self):
         return len(self.loader)

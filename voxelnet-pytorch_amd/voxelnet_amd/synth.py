@@ -75,3 +75,18 @@ def workload_frames(config_id, batch=None, frame0=0):
     b = w["batch"] if batch is None else batch
     return [synth_cloud(w["target"], w["k0"], frame_seed(config_id, frame0 + f), w["mean_extra"], w["T"])
             for f in range(b)]
+
+
+def synth_labels(target="Car", n_objects=6, seed=0):
+    """KITTI label lines of one synthetic frame: n_objects boxes of the class inside the crop plus one DontCare line —
+    what the dataset hands to RPN3D.forward as x[1][i] (the targets are generated from them on the device, model.py:309)"""
+    from .targets import CLASS_CFG, lidar_box_to_label_line
+    c = CLASS_CFG[target]
+    rng = np.random.default_rng(seed)
+    lines = []
+    for _ in range(int(n_objects)):
+        box = [rng.uniform(c["x"][0] + 4, c["x"][1] - 4), rng.uniform(c["y"][0] + 4, c["y"][1] - 4), c["z"] + rng.uniform(-0.2, 0.2),
+               c["h"] * rng.uniform(0.9, 1.1), c["w"] * rng.uniform(0.9, 1.1), c["l"] * rng.uniform(0.9, 1.1), rng.uniform(-1.5, 1.5)]
+        lines.append(lidar_box_to_label_line(target, box))
+    lines.append("DontCare -1 -1 -10 503.89 169.71 590.61 190.13 -1 -1 -1 -1000 -1000 -1000 -10")
+    return lines

@@ -79,6 +79,16 @@ def label_to_gt_box_3d(labels, cls_name="Car", coordinate="lidar"):
     return out
 
 
+def lidar_box_to_label_line(cls_name, box):
+    """inverse of label_to_gt_box_3d for one box (x, y, z, h, w, l, r) in lidar coordinates: the KITTI label line (camera
+    coordinates by the mean calibration, utils.py lidar_to_camera) the dataset would hand to RPN3D.forward — synthetic
+    labels for bench.py / tests"""
+    x, y, z, h, w, l, rz = (float(v) for v in box)
+    p = np.matmul(_R_RECT_0, np.matmul(_T_VELO_2_CAM, np.array([x, y, z, 1.0])))
+    return (f"{cls_name} 0.00 0 0.00 0.00 0.00 0.00 0.00 {h:.2f} {w:.2f} {l:.2f} {p[0]:.2f} {p[1]:.2f} {p[2]:.2f} "
+            f"{-rz - np.pi / 2:.2f}")
+
+
 def gt_standup_boxes(gt):
     """corner_to_standup_box2d(center_to_corner_box_2d(gt[:, [0,1,4,5,6]])) (utils.py:402-406): axis-aligned hull of
     the rotated footprint; float64 rotation, corners stored as float32 (utils.py:293), result float32 (utils.py:410)."""
@@ -122,7 +132,10 @@ class TargetGenerator:
                 gt[b, :n] = boxes
                 g2[b, :n] = gt_standup_boxes(boxes)
         dev = self.device
-        gt_d, g2_d, cnt_d = (torch.from_numpy(a).to(dev) for a in (gt, g2, cnt))
+        # pinned staging + asynchronous copies on the current stream: a blocking copy from pageable memory would make the
+        # host wait for everything queued before it — every step — and the train loop's enqueue could no longer run ahead
+        # of the GPU (the caching host allocator keeps a pinned block until the copy that reads it has run)
+        gt_d, g2_d, cnt_d = (torch.from_numpy(a).pin_memory().to(dev, non_blocking=True) for a in (gt, g2, cnt))
         N = self.n_anchors
         pos = torch.empty((B, *self.shape, 2), dtype=torch.float32, device=dev)
         neg = torch.empty((B, *self.shape, 2), dtype=torch.float32, device=dev)
