@@ -499,7 +499,7 @@ def main():
                                 "rccl_version_bound_by_library": int(_lib.load().vn_comm_rccl_version()),
                                 "torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                                 "note": "exposed = median time the training stream waits in GradAllReducer.finish (HIP events, 10 steps, "
-                                        "MAX over ranks): the part of the 4-bucket all-reduce the backward did not hide"}
+                                        "MAX over ranks): the part of the bucketed all-reduce the backward did not hide"}
         if ranks_in_sync is not None:
             res["ranks_in_sync"] = ranks_in_sync       # parameters bit-identical on all ranks after the timed steps
             res["grad_checksums_equal"] = grad_checksums_equal

@@ -88,7 +88,7 @@ def main():
             m.grad_reducer.finish(named)
             torch.cuda.synchronize()
             if step == 0:
-                assert calls == [0, 1, 2, 3], calls          # the native-executor bucket path, not grad_ready
+                assert calls == [0, 1, 2, 3, 4], calls          # the native-executor bucket path, not grad_ready
                 for k, p in named:
                     e = expect[k]
                     tol = 1e-5 * float(e.abs().max()) + 1e-12

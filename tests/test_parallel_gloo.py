@@ -36,7 +36,7 @@ def _worker(rank, world, port, q):
         named = [(k, torch.nn.Parameter(v)) for k, v in _named_params()]
         red = parallel.GradAllReducer(named)
         assert sum(b["flat"].numel() for b in red.buckets) == 6809392
-        assert len(red.buckets) == 4
+        assert len(red.buckets) == 5
         # gradients arrive in backward order (reverse of the state_dict / execution order)
         launched = []
         orig = red._launch
@@ -49,7 +49,7 @@ def _worker(rank, world, port, q):
         order += [k for k, _ in reversed(named) if k not in order]
         for k in order:
             red.grad_ready(k, g[k])
-        assert len(launched) == 4
+        assert len(launched) == 5
         red.finish(named)
         # expected mean over ranks, recomputed locally from the seeds
         for i, (k, p) in enumerate(reversed(named)):

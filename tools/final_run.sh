@@ -1,7 +1,7 @@
 # round-end measurement set (run on the GPU box through gpurun): tests, smoke, bench (three configs), rocprofv3 kernel
 # stats of the SAME command, the two HBM-traffic PMC passes and the MFMA-busy PMC pass (each --pmc pass on its own, never
 # combined with tracing).  Summaries are copied to profiles/ by hand afterwards (gpurun_out/ is scratch).
-R=${R:-r02}
+R=${R:-r03}
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 set -e
 cd $GRAFT_REPO_ROOT
@@ -18,11 +18,15 @@ VN_BENCH_SHARE_GPU=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=
 tail -c 600 gpurun_out/final_bench_n2_rehearsal.json
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
-rocprofv3 --kernel-trace --stats -d $O/fstats -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode > $O/fstats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/fpmc_fetch -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer > $O/fpmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/fpmc_write -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer > $O/fpmc_write.log 2>&1
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/fpmc_mfma -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer > $O/fpmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/fstats -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --windows 1 > $O/fstats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $O/fpmc_fetch -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $O/fpmc_write -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_write.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/fpmc_mfma -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_mfma.log 2>&1
+# what bounds the VFE kernels: two counter passes of their own
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/fpmc_vfe_a -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_vfe_a.log 2>&1
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY -d $O/fpmc_vfe_b -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_vfe_b.log 2>&1
 cd $GRAFT_REPO_ROOT
+python tools/pmc_counters.py k_vfe 3 gpurun_out/fpmc_vfe_a gpurun_out/fpmc_vfe_b > gpurun_out/${R}_pmc_vfe.txt 2>&1 || true
 python tools/pmc_traffic.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 > gpurun_out/${R}_pmc_traffic_per_kernel.txt
 python tools/pmc_family.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 gpurun_out/${R}_pmc_traffic.json
 python tools/pmc_mfma.py gpurun_out/fpmc_mfma 3 gpurun_out/${R}_pmc_mfma_per_kernel.txt | head -40

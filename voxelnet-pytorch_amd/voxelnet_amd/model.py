@@ -473,7 +473,7 @@ class MiddleConvNet(nn.Module):
 _BWD_ORDER = [22] + list(range(21, 15, -1)) + [15] + list(range(14, 8, -1)) + [8] + list(range(7, 2, -1)) + [2, 1, 0]
 
 # backward segments of the native executor (vn_net_backward steps) that complete a DDP bucket each
-# (parallel.BUCKET_PLAN): heads+deconv3+block3 | deconv2+block2+deconv1 | block1 | middle_layer (+ VFE after it)
+# (parallel.BUCKET_PLAN): heads+deconv3+block3 | deconv2+block2+deconv1 | block1 | middle_layer (the VFE bucket follows)
 NATIVE_SEGMENTS = [(0, 8), (8, 16), (16, 21), (21, 24)]
 
 
@@ -696,7 +696,6 @@ def _detector_backward_segments(cfg, arr, heads, dp, dr, prob, dense, coord, vw_
                                 side, red, views, table, order, rpn, feature, wst, stats, d_vw, vparams):
     """the executor's backward as one call (no reducer) or one call per DDP bucket (reducer without a comm stream)"""
     mid = rpn.middle_rpn
-    last_names = []
     if True:
         # one segment per DDP bucket when gradients are all-reduced while the backward runs; else a single call
         # (fewer fork/join points for the side stream, one unpack launch)
@@ -721,11 +720,8 @@ def _detector_backward_segments(cfg, arr, heads, dp, dr, prob, dense, coord, vw_
                     cv = "deconv" if spec.transposed else "conv"
                     names += [f"middle_rpn.{name}.{cv}.weight", f"middle_rpn.{name}.{cv}.bias",
                               f"middle_rpn.{name}.batch_norm.weight", f"middle_rpn.{name}.batch_norm.bias"]
-                if se < 24:
-                    for n in names:
-                        red.grad_ready(n, views[n])
-                else:
-                    last_names = names
+                for n in names:       # (with a reducer the call has joined the side stream: the group's gradients are final —
+                    red.grad_ready(n, views[n])      # the middle_layer bucket too, which then runs beside the VFE backward)
         if not cfg.sparse_first:
             d_vw = gather_rows(Rows(d_in, 128), coord, K, 128)
         vg = featnet_backward(feature, wst, stats, d_vw, vparams, out=[views[k] for k in VFE_KEYS])
@@ -733,7 +729,7 @@ def _detector_backward_segments(cfg, arr, heads, dp, dr, prob, dense, coord, vw_
             torch.cuda.current_stream().wait_stream(rpn.__dict__["_side"])
             _split_heads_grads(views, dhw, dhb)      # (dhw is written by the unpack, which ran on the side stream)
         if red is not None:
-            for n in last_names + VFE_KEYS:
+            for n in VFE_KEYS:
                 red.grad_ready(n, views[n])
     return vg
 
@@ -792,12 +788,13 @@ def _detector_backward_native(ctx, d_prob, d_reg):
             red.launch_bucket(0, wait_fn=waiter(0), prelude=lambda: _split_heads_grads(views, dhw, dhb))
             red.launch_bucket(1, wait_fn=waiter(1))
             red.launch_bucket(2, wait_fn=waiter(2))
+            red.launch_bucket(3, wait_fn=waiter(3))          # middle_layer: runs beside the VFE backward
             if not cfg.sparse_first:
                 d_vw = gather_rows(Rows(d_in, 128), coord, K, 128)
             vg = featnet_backward(feature, wst, stats, d_vw, vparams, out=[views[k] for k in VFE_KEYS])
             vfe_done = torch.cuda.Event()
             vfe_done.record()
-            red.launch_bucket(3, wait_fn=waiter(3), after_event=vfe_done)
+            red.launch_bucket(4, after_event=vfe_done)      # the 9.6 KB of VFE gradients: the exposed tail
             torch.cuda.current_stream().wait_stream(rpn.__dict__["_side"])
         else:
             # one segment per DDP bucket when gradients are all-reduced while the backward runs (no side stream); else

@@ -12,7 +12,7 @@ stack and the VFE last): `layer grads ready` -> copied into the flat bucket -> w
 is complete an event is recorded on the compute stream, the comm stream waits for it and
 starts the all-reduce.  xGMI is point-to-point (7 links/GPU), so a handful of multi-MB buckets
 is the right granularity: each all-reduce is large enough to be bandwidth-bound and the last,
-small bucket (the layers that finish last) is what is left exposed.
+tiny bucket (the VFE parameters, whose gradients finish last) is what is left exposed.
 """
 import ctypes
 import os
@@ -25,7 +25,9 @@ BUCKET_PLAN = [
     ["heads", "deconv3", "block3"],                 # ~17.2 MB fp32
     ["deconv2", "block2", "deconv1"],               # ~5.3 MB
     ["block1"],                                     # ~3.0 MB
-    ["middle_layer", "vfe"],                        # ~1.8 MB
+    ["middle_layer"],                               # ~1.8 MB: launched when middle_layer.0's gradients are final — beside the VFE backward
+    ["vfe"],                                        # 9.6 KB: the only bucket that is exposed (round 3: it used to ride with middle_layer,
+    #                                                 which kept that 1.8 MB all-reduce waiting for the VFE backward, ~135 us)
 ]
 
 
