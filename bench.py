@@ -547,7 +547,7 @@ def main():
                 # HBM-side bytes per launch of that family: PMC counters cannot be read in-process; taken from the committed
                 # rocprofv3 --pmc passes of this same command (profiles/, tools/pmc_family.py), car / bf16 / batch 2 only
                 traffic = None
-                pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+                pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
                 if args.config == "car" and args.precision == "bf16" and B == 2 and os.path.exists(pmc):
                     with open(pmc) as fh:
                         traffic = json.load(fh).get("traffic_bytes_per_launch")
