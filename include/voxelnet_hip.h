@@ -115,8 +115,10 @@ int vn_vfe_fwd(const float *feature /*[K,T,7]*/, int64_t K, int32_t T, const vnV
                float *stats /*[320]*/, void *workspace, size_t workspace_bytes, vnStream stream);
 /* gradients of all eight parameter tensors for upstream d_voxelwise (K,128); the input
  * features are leaf data (no d_feature).  `workspace` need not be the forward's; when it IS — the buffer vn_vfe_fwd
- * was given for the same feature / K / T, untouched since — pass workspace_is_forwards = 1 and the effective-row work
- * list found there is reused instead of rebuilt (two launches less). */
+ * was given for the same feature / K / T, untouched since — pass workspace_is_forwards = 1 (bit 0) and the effective-row
+ * work list found there is reused instead of rebuilt (two launches less).  Bit 1 of workspace_is_forwards: the forward
+ * ran with training = 0 (stats = the running statistics): the eval-mode BatchNorm backward, whose batch-statistic terms
+ * vanish (the reference's autograd through `model.eval()`; model.py:76 with self.training False). */
 int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, const float *stats,
                const float *d_voxelwise, const vnVfeGrads *g, void *workspace,
                size_t workspace_bytes, int32_t workspace_is_forwards, vnStream stream);

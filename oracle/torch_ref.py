@@ -242,16 +242,16 @@ def rpn_loss(prob, delta, pos, neg, targets, alpha=1.5, beta=1.0, sigma=3.0):
     return cls + reg, cls, reg, cls_pos.sum(), cls_neg.sum()
 
 
-def forward_backward(features, coordinates, sd, dims, cls_name, d_prob, d_reg):
-    """One train-mode step core (train.py:148-151 minus optimiser) with a supplied
-    upstream gradient: returns (prob, reg, {param: grad}).  Running stats in `sd`
-    are updated in place like nn.BatchNorm does."""
+def forward_backward(features, coordinates, sd, dims, cls_name, d_prob, d_reg, training=True):
+    """One step core (train.py:148-151 minus optimiser) with a supplied upstream gradient: returns (prob, reg,
+    {param: grad}).  training=True: train-mode BatchNorm, running stats in `sd` are updated in place like nn.BatchNorm
+    does; training=False: the reference's autograd through `model.eval()` (running statistics as constants)."""
     keys = param_keys(sd)
     leaves = {k: sd[k].detach().clone().requires_grad_(True) for k in keys}
     work = dict(sd)
     work.update(leaves)
-    dense = feature_net(features, coordinates, work, dims, True)
-    prob, reg = middle_rpn(dense, work, cls_name, True)
+    dense = feature_net(features, coordinates, work, dims, training)
+    prob, reg = middle_rpn(dense, work, cls_name, training)
     torch.autograd.backward([prob, reg], [d_prob, d_reg])
     return prob.detach(), reg.detach(), {k: leaves[k].grad for k in keys}
 

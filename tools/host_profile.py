@@ -18,12 +18,20 @@ opt = ClipSGD(params, 0.01, 5.0)
 grid = grid_config("Car")
 frames = [torch.from_numpy(f).to(dev) for f in synth.workload_frames(2, batch=2)]
 targets = bench.synthetic_targets(2, 200, 176, 99, dev)
+import numpy as np
+labels = np.empty(2, dtype=object)
+for b in range(2):
+    labels[b] = synth.synth_labels("Car", 6, seed=7000 + b)
+USE_LABELS = os.environ.get("HOST_PROFILE_LABELS", "1") == "1"     # targets generated from the label lines inside the step (bench.py's default)
 fc = [voxelize_device(p, grid, b, coord_cols=4) for b, p in enumerate(frames)]
 feats, coords = [x[0] for x in fc], [x[1] for x in fc]
 
 
 def step():
-    out = model((None, None, feats, None, coords, None, None), dev, targets=targets)
+    if USE_LABELS:
+        out = model((None, labels, feats, None, coords, None, None), dev)
+    else:
+        out = model((None, None, feats, None, coords, None, None), dev, targets=targets)
     out[2].backward()
     opt.step()
     opt.zero_grad(set_to_none=True)

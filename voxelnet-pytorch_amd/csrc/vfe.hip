@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(256) k_vfe_bn_bwd_finalize(const float *__rest
                                                              int slab_off, int C, int64_t rows,
                                                              const float *__restrict__ gamma,
                                                              const float *__restrict__ st, float *__restrict__ coef,
-                                                             float *__restrict__ d_gamma, float *__restrict__ d_beta) {
+                                                             float *__restrict__ d_gamma, float *__restrict__ d_beta, int eval) {
     const int c = blockIdx.x;
     double s1, s2;
     slab_pair_sum(slabs, nslabs, slab_stride, slab_off, C, c, s1, s2);
@@ -573,8 +573,9 @@ __global__ void __launch_bounds__(256) k_vfe_bn_bwd_finalize(const float *__rest
         const float invstd = st[C + c];
         const float S = gamma[c] * invstd;
         coef[c] = S;
-        coef[C + c] = -S * invstd * (float)(s2 / n);
-        coef[2 * C + c] = -S * (float)(s1 / n);
+        // eval-mode BatchNorm: mean / invstd are constants (the running statistics), the two batch-statistic terms vanish
+        coef[C + c] = eval ? 0.f : -S * invstd * (float)(s2 / n);
+        coef[2 * C + c] = eval ? 0.f : -S * (float)(s1 / n);
         d_gamma[c] = (float)s2;
         d_beta[c] = (float)s1;
     }
@@ -920,6 +921,10 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
     VN_CHECK_ARG(g->dw1 && g->db1 && g->dg1 && g->dbe1 && g->dw2 && g->db2 && g->dg2 && g->dbe2);
     const Plan pl = make_plan(K, T);
     if (workspace_bytes < pl.bytes) return VN_EWORKSPACE;
+    // workspace_is_forwards: bit 0 = the forward's work list is still in `workspace`; bit 1 = the forward ran in EVAL mode
+    // (stats hold the running statistics: they are constants of the backward, the batch-statistic terms vanish)
+    const int eval = (workspace_is_forwards >> 1) & 1;
+    workspace_is_forwards &= 1;
     hipStream_t st = vn_stream(stream);
     char *ws = static_cast<char *>(workspace);
     float *slabs = reinterpret_cast<float *>(ws + pl.off_slabs);
@@ -938,12 +943,12 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
     }
     k_vfe_b1<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, d_voxelwise, slabs);
     VN_LAUNCH_STATUS();
-    k_vfe_bn_bwd_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, SLAB_B1, 0, C2, rows, w->g2, stats + ST2, coef2, g->dg2, g->dbe2);
+    k_vfe_bn_bwd_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, SLAB_B1, 0, C2, rows, w->g2, stats + ST2, coef2, g->dg2, g->dbe2, eval);
     VN_LAUNCH_STATUS();
     k_vfe_b2<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, d_voxelwise, coef2, dp1, slabs);
     VN_LAUNCH_STATUS();
     k_vfe_bn_bwd_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2 + C2 * 32, C1, rows, w->g1, stats + ST1, coef1,
-                                            g->dg1, g->dbe1);
+                                            g->dg1, g->dbe1, eval);
     VN_LAUNCH_STATUS();
     float *slabs3 = reinterpret_cast<float *>(ws + pl.off_slabs3);
     k_vfe_b3<<<pl.blocks, NT, pl.lds_small, st>>>(feature, T, P, wk, stats, coef1, dp1, slabs3);

@@ -232,7 +232,7 @@ def gather_gemm(src, wp, bias, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dim
 
 class LayerState:
     """What a layer's backward needs (saved by layer_forward)."""
-    __slots__ = ("spec", "x", "y", "stats", "a", "in_dims", "out_dims")
+    __slots__ = ("spec", "x", "y", "stats", "a", "in_dims", "out_dims", "training")
 
 
 def _bev_slices(B, D):
@@ -266,7 +266,7 @@ def layer_forward(spec, x, params, buffers, training, mode, out=None, y_dtype=No
     gather_gemm(x, wp, bias, y, spec.k, spec.cin, spec.cout, mul, tmul, pad, div, odims, stats=slab)
     st = LayerState()
     st.spec, st.x, st.y, st.in_dims, st.out_dims = spec, x, y, x.dims, odims
-    st.stats, st.a = None, None
+    st.stats, st.a, st.training = None, None, bool(training)
     if not spec.bn:
         return y, st
     M = y.M
@@ -336,6 +336,10 @@ def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=Fa
         dbeta = torch.empty(C, dtype=torch.float32, device=dev)
         _lib.call("vn_bn_bwd_finalize", sums.data_ptr(), M, C, 1, params["gamma"].data_ptr(), st.stats.data_ptr(),
                   coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream())
+        if not getattr(st, "training", True):
+            # eval-mode BatchNorm (running statistics): mean / invstd are constants, so dy = S * dz — the two batch-statistic
+            # terms of the train-mode backward vanish (the sums above are still d_gamma / d_beta)
+            coef[C:].zero_()
         dy = new_rows(B, st.out_dims, C, adt, split, dev)
         if bev_da:
             for b, d in _bev_slices(B, D):
@@ -353,6 +357,8 @@ def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=Fa
         # a bias in front of a train-mode BatchNorm has gradient sum_m dy = c0*sum(dz) + c1*sum(y-mean) + M*c2,
         # which is identically 0 (the reference's autograd returns its fp32 rounding noise, ~1e-7 of |dy|)
         grads["bias"] = torch.zeros(C, dtype=torch.float32, device=dev)
+        if not getattr(st, "training", True):       # eval mode: sum_m dy = S * sum_m dz = S * d_beta
+            grads["bias"] = st.stats[2 * C:3 * C] * dbeta
     else:
         width = dy.t.shape[-1]   # column sums of dy (hi + lo parts)
         cs = torch.empty(width, dtype=torch.float32, device=dev)
@@ -440,7 +446,7 @@ def first_layer_forward_sparse(spec, x, coord, params, buffers, training, mode):
                   ctypes.byref(g), lst.data_ptr(), cap, cnt.data_ptr(), 0,
                   slab.data_ptr() if slab is not None else None, stream())
     st = LayerState()
-    st.spec, st.x, st.y, st.in_dims, st.out_dims = spec, x, y, x.dims, odims
+    st.spec, st.x, st.y, st.in_dims, st.out_dims, st.training = spec, x, y, x.dims, odims, bool(training)
     stats = torch.empty(4 * spec.cout, dtype=torch.float32, device=dev)
     if slab is not None:
         _lib.call("vn_bn_finalize_slab", slab.data_ptr(), slab.shape[0], M, spec.cout, bias.data_ptr(),
@@ -473,10 +479,14 @@ def first_layer_backward_sparse(st, da, params, mode, coord, vw_rows):
     dbeta = torch.empty(C, dtype=torch.float32, device=dev)
     _lib.call("vn_bn_bwd_finalize", sums.data_ptr(), M, C, 1, params["gamma"].data_ptr(), st.stats.data_ptr(),
               coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), stream())
+    eval_mode = not getattr(st, "training", True)
+    if eval_mode:
+        coef[C:].zero_()                 # (see layer_backward)
     dy = new_rows(B, st.out_dims, C, adt, False, dev)
     _lib.call("vn_bn_bwd_apply", da.ptr(), _dt(da.t), da.row_stride(), y.ptr(), _dt(y.t), y.row_stride(), M, C,
               st.stats.data_ptr(), coef.data_ptr(), int(spec.relu), dy.ptr(), _dt(dy.t), dy.row_stride(), 0, stream())
-    grads = {"gamma": dgamma, "beta": dbeta, "bias": torch.zeros(C, dtype=torch.float32, device=dev)}
+    grads = {"gamma": dgamma, "beta": dbeta,
+             "bias": st.stats[2 * C:3 * C] * dbeta if eval_mode else torch.zeros(C, dtype=torch.float32, device=dev)}
     K = coord.shape[0]
     taps = spec.taps
     neg_pad = tuple(-q for q in spec.pad)

@@ -52,12 +52,10 @@ def _need_cuda(*ts):
 
 
 def _need_training(training):
-    """The backward kernels implement the TRAIN-mode BatchNorm backward (batch statistics, zero gradient for the conv
-    bias in front of it); the data-gradient weight packs are only made by a train-mode forward.  A backward through an
-    eval-mode forward (frozen-BN fine-tuning, saliency maps) is not built: fail loudly instead of returning numbers."""
-    if not training:
-        raise _lib.VoxelnetHipError("backward through an eval-mode forward is not supported on the HIP path "
-                                    "(train-mode BatchNorm backward only); call model.train() before the forward")
+    """(kept for callers; round 3: a backward through an eval-mode forward is supported — the eval-mode BatchNorm backward of
+    the reference's autograd (running statistics are constants: dy = S * dz, conv-bias gradient S * d_beta) runs through the
+    per-layer orchestration; the native executor handles train-mode steps only and detect() routes accordingly)"""
+    return None
 
 
 def _act_to_nchw(a, dim):
@@ -258,7 +256,7 @@ def featnet_forward(feature, params, bufs, training):
     return vw, stats, (w, ws, ws_bytes)
 
 
-def featnet_backward(feature, wstruct, stats, d_vw, params, out=None):
+def featnet_backward(feature, wstruct, stats, d_vw, params, out=None, training=True):
     w, ws, ws_bytes = wstruct
     K, T = feature.shape[0], feature.shape[1]
     grads = out if out is not None else [torch.empty_like(p) for p in params]
@@ -267,7 +265,7 @@ def featnet_backward(feature, wstruct, stats, d_vw, params, out=None):
     # (ws is the forward's workspace, kept alive and untouched by the saved handle: its work list is reused)
     with E.section("vfe_bwd", 2.0 * (28.0 * K * T + 512.0 * K)):
         _lib.call("vn_vfe_bwd", feature.data_ptr(), K, T, ctypes.byref(w), stats.data_ptr(), d_vw.data_ptr(),
-                  ctypes.byref(g), ws.data_ptr(), ws_bytes, 1, E.stream())
+                  ctypes.byref(g), ws.data_ptr(), ws_bytes, 1 | (0 if training else 2), E.stream())
     return grads
 
 
@@ -316,7 +314,7 @@ class _FeatureNetFn(torch.autograd.Function):
         feature, coord, stats, wst, params = ctx.saved
         with torch.cuda.device(d_dense.device):
             d_vw = gather_rows(Rows(d_dense.contiguous(), 128), coord, feature.shape[0], 128)
-            grads = featnet_backward(feature, wst, stats, d_vw, params)
+            grads = featnet_backward(feature, wst, stats, d_vw, params, training=ctx.training)
         return (None, None, None, None, None, None) + tuple(grads)
 
 
@@ -575,7 +573,9 @@ class _DetectorFn(torch.autograd.Function):
             vparams = flat[:nv]
         else:
             vparams = [p.detach() for p in flat[:nv]]
-        native = rpn._native_ok(mode)
+        # the native executor's backward is the train-mode one: an eval-mode forward that will be differentiated goes through
+        # the per-layer orchestration (eval-mode BatchNorm backward, engine.layer_backward)
+        native = rpn._native_ok(mode) and (bool(training) or not any(ctx.needs_input_grad))   # (needs_input_grad is all False under no_grad)
         if ctx.anchor and not native:
             raise _lib.VoxelnetHipError("internal: the one-tensor (anchor) call needs the native executor (RPN3D._native_ok)")
         if not native:          # (the per-launch Python orchestration works on name -> tensor dicts)
@@ -685,7 +685,7 @@ class _DetectorFn(torch.autograd.Function):
         with torch.cuda.device(d_prob.device):
             G, d_dense = N.middle_backward(st, d_prob.float(), d_reg.float(), P, need_dx=True, on_grads=on_grads)
             d_vw = d_dense if torch.is_tensor(d_dense) else gather_rows(d_dense, coord, feature.shape[0], 128)
-            vg = featnet_backward(feature, wst, stats, d_vw, vparams)
+            vg = featnet_backward(feature, wst, stats, d_vw, vparams, training=ctx.training)
             if red is not None:
                 for key, g in zip(VFE_KEYS, vg):
                     red.grad_ready(key, g)
@@ -1046,7 +1046,7 @@ class RPN3D(nn.Module):
         feature = (voxel_features[0] if bs == 1 else torch.cat(list(voxel_features), dim=0)).contiguous().float()
         coord = (voxel_coordinates[0] if bs == 1 else torch.cat(list(voxel_coordinates), dim=0)).contiguous().long()
         flat = self._flat_params()
-        if (self._native_ok(_mode()) and self.direct_grads and torch.is_grad_enabled() and feature.is_cuda
+        if (self._native_ok(_mode()) and self.training and self.direct_grads and torch.is_grad_enabled() and feature.is_cuda
                 and self._all_need_grad(flat)):
             prob, reg = _DetectorFn.apply(feature, coord, bs, self, self.training, self._anchor(feature.device))
         else:

@@ -33,6 +33,7 @@ _R_RECT_0 = np.array([[0.99992475, 0.00975976, -0.00734152, 0],
                       [-0.0097913, 0.99994262, -0.00430371, 0],
                       [0.00729911, 0.0043753, 0.99996319, 0],
                       [0, 0, 0, 1]])
+_R_RECT_0_INV, _T_VELO_2_CAM_INV = np.linalg.inv(_R_RECT_0), np.linalg.inv(_T_VELO_2_CAM)   # (utils.py:168-169 inverts per call)
 
 
 def generate_anchors(cls_name="Car"):
@@ -61,7 +62,7 @@ def label_to_gt_box_3d(labels, cls_name="Car", coordinate="lidar"):
     """utils.py:178-210 (+ camera_to_lidar_box, :163-174): label lines of every sample -> list of (G_i, 7) float64
     boxes (x, y, z, h, w, l, r), in lidar coordinates by the mean calibration unless coordinate == 'camera'."""
     accept = CLASS_CFG[cls_name]["accept"] if cls_name in CLASS_CFG else ()
-    r_inv, t_inv = np.linalg.inv(_R_RECT_0), np.linalg.inv(_T_VELO_2_CAM)
+    r_inv, t_inv = _R_RECT_0_INV, _T_VELO_2_CAM_INV
     out = []
     for label in labels:
         rows = []
