@@ -402,7 +402,7 @@ typedef struct {
     int32_t kind;    /* VN_T_* */
     int32_t layer;   /* execution-order index 0..22, 23 = heads, -1 = all layers */
     float ms;        /* event-to-event duration of the launch */
-    float reserved;
+    float start_ms;  /* start of the launch's event bracket relative to the first record of this vn_net_timing_read */
     double flops, bytes;
 } vnTimingRecord;
 int vn_net_timing_begin(vnNet *net, int32_t max_records);

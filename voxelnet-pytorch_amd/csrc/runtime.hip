@@ -475,9 +475,12 @@ extern "C" int vn_net_timing_read(vnNet *n, vnTimingRecord *out, int32_t cap, in
     for (int i = 0; i < m; ++i) {
         vnTimeSlot &t = n->slots[i];
         VN_HIP(hipEventSynchronize(t.e1));
-        float ms = 0.f;
+        float ms = 0.f, start = 0.f;
         VN_HIP(hipEventElapsedTime(&ms, t.e0, t.e1));
-        out[i] = vnTimingRecord{t.kind, t.layer, ms, 0.f, t.flops, t.bytes};
+        // start of the launch's bracket relative to the first record's (events of different streams share one clock): a
+        // two-stream timeline of the step (tools/step_timeline.py)
+        if (i > 0 && hipEventElapsedTime(&start, n->slots[0].e0, t.e0) != hipSuccess) start = 0.f;
+        out[i] = vnTimingRecord{t.kind, t.layer, ms, start, t.flops, t.bytes};
     }
     *count = n->t_used;
     n->t_used = 0;

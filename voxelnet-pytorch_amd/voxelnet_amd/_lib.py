@@ -49,7 +49,7 @@ class VnNetConfig(ctypes.Structure):
 
 
 class VnTimingRecord(ctypes.Structure):
-    _fields_ = [("kind", c_i32), ("layer", c_i32), ("ms", c_f32), ("reserved", c_f32), ("flops", ctypes.c_double),
+    _fields_ = [("kind", c_i32), ("layer", c_i32), ("ms", c_f32), ("start_ms", c_f32), ("flops", ctypes.c_double),
                 ("bytes", ctypes.c_double)]
 
 
