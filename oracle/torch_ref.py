@@ -189,13 +189,16 @@ def deconv2d(x, sd, prefix, stride, pad, training=True, relu_mask=None):
     return _relu(_bn(x, sd, prefix + ".batch_norm", training), relu_mask)
 
 
-def middle_rpn(dense, sd, cls_name="Car", training=True, taps=None):
+def middle_rpn(dense, sd, cls_name="Car", training=True, taps=None, masks=None):
     """model.py:257-281.  dense (B,D,H,W,128) -> (sigmoid(probs) (B,2,h,w), reg (B,14,h,w)).
-    `taps`, if a dict, receives intermediate activations for per-layer tests."""
+    `taps`, if a dict, receives intermediate activations for per-layer tests.  `masks`, if a dict name -> 0/1 tensor in
+    the layer's NC(D)HW output shape, replaces every F.relu by a multiplication with the given mask (tests only: see _relu)
+    — a CHAINED backward can then be compared tightly, with the ReLU decisions of the implementation under test."""
     B, _, H, W, _ = dense.shape
+    mk = (lambda n: masks[n]) if masks is not None else (lambda n: None)
     x = dense.permute(0, 4, 1, 2, 3)
     for name, dim, _cin, _cout, _k, s, p in MIDDLE:
-        x = conv_md(x, sd, "middle_rpn." + name, dim, s, p, training=training)
+        x = conv_md(x, sd, "middle_rpn." + name, dim, s, p, training=training, relu_mask=mk(name))
         if taps is not None:
             taps[name] = x
     x = x.reshape(B, -1, H, W)                               # model.py:262: channel = c*2+d
@@ -203,10 +206,10 @@ def middle_rpn(dense, sd, cls_name="Car", training=True, taps=None):
     ups = []
     for block, d in ((blk1, dec[0]), (blk2, dec[1]), (blk3, dec[2])):
         for name, _ci, _co, s in block:
-            x = conv_md(x, sd, "middle_rpn." + name, 2, s, (1, 1), training=training)
+            x = conv_md(x, sd, "middle_rpn." + name, 2, s, (1, 1), training=training, relu_mask=mk(name))
             if taps is not None:
                 taps[name] = x
-        up = deconv2d(x, sd, "middle_rpn." + d[0], d[4], d[5], training)
+        up = deconv2d(x, sd, "middle_rpn." + d[0], d[4], d[5], training, relu_mask=mk(d[0]))
         if taps is not None:
             taps[d[0]] = up
         ups.append(up)
@@ -242,7 +245,7 @@ def rpn_loss(prob, delta, pos, neg, targets, alpha=1.5, beta=1.0, sigma=3.0):
     return cls + reg, cls, reg, cls_pos.sum(), cls_neg.sum()
 
 
-def forward_backward(features, coordinates, sd, dims, cls_name, d_prob, d_reg, training=True):
+def forward_backward(features, coordinates, sd, dims, cls_name, d_prob, d_reg, training=True, masks=None):
     """One step core (train.py:148-151 minus optimiser) with a supplied upstream gradient: returns (prob, reg,
     {param: grad}).  training=True: train-mode BatchNorm, running stats in `sd` are updated in place like nn.BatchNorm
     does; training=False: the reference's autograd through `model.eval()` (running statistics as constants)."""
@@ -251,7 +254,7 @@ def forward_backward(features, coordinates, sd, dims, cls_name, d_prob, d_reg, t
     work = dict(sd)
     work.update(leaves)
     dense = feature_net(features, coordinates, work, dims, training)
-    prob, reg = middle_rpn(dense, work, cls_name, training)
+    prob, reg = middle_rpn(dense, work, cls_name, training, masks=masks)
     torch.autograd.backward([prob, reg], [d_prob, d_reg])
     return prob.detach(), reg.detach(), {k: leaves[k].grad for k in keys}
 
