@@ -12,11 +12,19 @@ if len(sys.argv) > 1 and sys.argv[1] == "random":
     K, T = 12000, 35
     feat = torch.randn(K, T, 7, device=dev)          # every slot differs: the r = T worst case
 else:
-    grid = grid_config("Car")
+    dense = len(sys.argv) > 1 and sys.argv[1] == "dense"      # BASELINE configs[4] (T = 64, batch 4) instead of configs[1]
+    grid = grid_config("Car", T=64) if dense else grid_config("Car")
     feat = torch.cat([voxelize_device(torch.from_numpy(f).to(dev), grid, b, coord_cols=4)[0]
-                      for b, f in enumerate(synth.workload_frames(2))])
+                      for b, f in enumerate(synth.workload_frames(5 if dense else 2))])
     K, T = feat.shape[0], feat.shape[1]
 print("K", K, "T", T)
+# effective rows per voxel (csrc/vfe.hip: 1 + last slot that differs bit-wise from slot T-1) and the wave items they make
+bits = feat.view(torch.int32)
+diff = (bits != bits[:, T - 1:T, :]).any(-1)                   # (K, T)
+r = 1 + torch.where(diff.any(1), (diff.int() * torch.arange(1, T + 1, device=dev)).max(1).values, torch.zeros(K, dtype=torch.int64, device=dev))
+nA, nB, nC = int((r <= 8).sum()), int(((r > 8) & (r <= 16)).sum()), int((r > 16).sum())
+print(f"rows: mean {float(r.float().mean()):.2f}  classes r<=8 {nA}  r<=16 {nB}  r<=64 {nC}  -> wave items {(nA + 7) // 8} + {(nB + 3) // 4} + {nC}"
+      f" = {(nA + 7) // 8 + (nB + 3) // 4 + nC}; effective rows {int(r.sum())} of {K * T}")
 m = M.RPN3D("Car").to(dev).train()
 params = [p.detach() for p in M._vfe_weights(m.feature_net)]
 bufs = m.feature_net._bufs()

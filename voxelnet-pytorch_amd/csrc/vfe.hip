@@ -43,14 +43,47 @@ constexpr int ST1 = 0, ST2 = 4 * C1;            // stats: [mean|invstd|S|beta] p
 constexpr int STATS_FLOATS = 4 * C1 + 4 * C2;   // 320
 constexpr int TS = 65;                          // tile row stride (floats)
 constexpr int NW = 2, NT = NW * 64;             // waves / threads per workgroup (LDS: 2 workgroups per CU)
-constexpr int VFE_BLOCKS_MAX = 512;
-#define VFE_O_UNROLL 4   // the o loops read 16 uniform weights per step from LDS; a full unroll spills
+constexpr int VFE_BLOCKS_MAX = 768;              // three workgroups per CU (LDS: ~44 / 52 KB each)
 // per-voxel-slot vectors in LDS (floats); odd stride: the 8 slots of a wave fall into different banks
-constexpr int V_AGG1 = 0, V_AM1 = 16, V_DAG1 = 32, V_U = 48, V_S = 112, SV = 177;
+// (V_S aliases V_U: u is dead once h2 is in the tile, s is written after that)
+constexpr int V_AGG1 = 0, V_AM1 = 16, V_DAG1 = 32, V_U = 48, V_S = 48, SV = 113;
 // slab (per workgroup) float counts
 constexpr int SLAB_P1 = 64, SLAB_P2 = 2 * C2, SLAB_B1 = 2 * C2;
 constexpr int SLAB_B2 = C2 + C2 * 32 + 64;   // db2 | dW2[64][32] | bn1 sums (32 used, written 64 wide)
 constexpr int SLAB_B3 = 128;                 // dW1 (112) | db1 (16)
+
+// -DVFE_TRACE (tools/trace_vfe_phases.py; never in the product build): lane 0 of every wave stores the shader clock at the
+// phase boundaries of its first 60 items into a buffer installed with vn_debug_vfe_trace.
+#ifdef VFE_TRACE
+__device__ unsigned long long *g_vfe_trace;
+__device__ int g_vfe_trace_kernel;   // which kernel records: 2 p2, 3 p3, 11 b1, 12 b2
+__shared__ int vfe_tr_item_s[8];   // per wave: index of the item being processed
+__shared__ int vfe_tr_on;
+#define VFE_TR_KERNEL(id)                                                                                              \
+    if (threadIdx.x == 0) vfe_tr_on = g_vfe_trace != nullptr && g_vfe_trace_kernel == (id);                            \
+    __syncthreads();
+#define VFE_TR_DECL                                                                                                    \
+    if ((threadIdx.x & 63) == 0) vfe_tr_item_s[threadIdx.x >> 6] = 0;
+#define VFE_TR_SLOT(k) g_vfe_trace[(((size_t)blockIdx.x * 8 + (threadIdx.x >> 6)) * 60 + vfe_tr_item_s[threadIdx.x >> 6]) * 16 + (k)]
+#define VFE_TR(k)                                                                                                      \
+    do {                                                                                                               \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                    \
+        if (vfe_tr_on && (threadIdx.x & 63) == 0 && vfe_tr_item_s[threadIdx.x >> 6] < 60)                            \
+            VFE_TR_SLOT(k) = __builtin_readcyclecounter();                                                             \
+    } while (0)
+#define VFE_TR_CLASS(g)                                                                                                \
+    do {                                                                                                               \
+        if (vfe_tr_on && (threadIdx.x & 63) == 0 && vfe_tr_item_s[threadIdx.x >> 6] < 60) VFE_TR_SLOT(15) = (g);     \
+    } while (0)
+#define VFE_TR_NEXT                                                                                                    \
+    if ((threadIdx.x & 63) == 0) ++vfe_tr_item_s[threadIdx.x >> 6];
+#else
+#define VFE_TR_KERNEL(id)
+#define VFE_TR_DECL
+#define VFE_TR(k)
+#define VFE_TR_CLASS(g)
+#define VFE_TR_NEXT
+#endif
 
 struct VfeParams {
     const float *w1, *b1, *w2, *b2;
@@ -66,11 +99,15 @@ struct WorkList {
 // The skinny-MLP weights (2.2k floats) are wave-uniform.  As kernel-argument loads hipcc hoists ~2000 s_loads out
 // of the per-item loop and spills the SGPRs into VGPR lanes; re-loading them with s_load inside the loop serialises
 // on SMEM latency.  So they live in LDS, one copy per workgroup, read as broadcast ds_read_b128.
-// W2A = W2[o][0..15] as [o][16]; W2B = W2[o][16+i] transposed as [i][65] (lane = o and lane = i reads both clean)
-constexpr int WL_W2A = 0, WL_W2B = 1024, WL_W1 = 2064, WL_B1 = 2176, WL_B2 = 2192, WL_SIZE = 2304;   // floats
+// Only the first layer's 128 floats are here: the products with W2 run on the matrix cores or with per-lane register
+// operands (FwdRegs, B2Acc).
+constexpr int WL_W1 = 0, WL_B1 = 112, WL_SIZE = 128;   // floats
 constexpr int WL_ST = WL_SIZE, WL_CF = WL_ST + STATS_FLOATS, WL_END = WL_SIZE + 512;   // BN stats / BN2 backward coefficients
 
-constexpr int WAVE_FLOATS = 64 * TS + 64 * 16 + 64 + 8 * SV + 16;   // tile | p1t | mk | slot vectors | slot ids
+// per-wave LDS: tile | p1t | mk | slot vectors | slot ids.  Only pass b2 keeps the p1*mask rows; the others use 64 floats
+// of that region (row weights).  20.8 / 24.7 KB per wave: three 2-wave workgroups per CU.
+template <bool P1T>
+constexpr int wave_floats() { return 64 * TS + (P1T ? 64 * 16 : 64) + 64 + 8 * SV + 16; }
 
 struct WaveLds {
     float *tile;   // [64][65]
@@ -80,10 +117,11 @@ struct WaveLds {
     int *sid;      // [8] voxel id, [8] rows
 };
 
+template <bool P1T>
 __device__ __forceinline__ WaveLds carve_lds(float *base, int wave) {
-    float *p = base + (size_t)wave * WAVE_FLOATS;
-    return WaveLds{p, p + 64 * TS, p + 64 * TS + 64 * 16, p + 64 * TS + 64 * 16 + 64,
-                   reinterpret_cast<int *>(p + 64 * TS + 64 * 16 + 64 + 8 * SV)};
+    constexpr int NP = P1T ? 64 * 16 : 64;
+    float *p = base + (size_t)wave * wave_floats<P1T>();
+    return WaveLds{p, p + 64 * TS, p + 64 * TS + NP, p + 64 * TS + NP + 64, reinterpret_cast<int *>(p + 64 * TS + NP + 64 + 8 * SV)};
 }
 
 // ---- items -----------------------------------------------------------------------------
@@ -150,14 +188,43 @@ __device__ __forceinline__ void layer1_lds(const float *__restrict__ wl, const f
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Per-lane operands of the second linear that stay in registers for the whole kernel:
+//   w2b[i]   = W2[lane][16 + i]                       (lane = output channel; the max-pooled half, applied per voxel)
+//   wm[c][s] = W2[16c + (lane & 15)][4s + (lane >> 4)] B operand of v_mfma_f32_16x16x4_f32 for the point-wise half:
+//              h2[row][o] = sum_i p1[row][i] W2[o][i] is a 64 x 64 x 16 product per wave item = 64 MFMAs of exact fp32
+//              (each accumulator is the fmaf chain over i = 0..15 of the scalar form, in the same order).  As fp32 FMAs
+//              with broadcast LDS weights the same product took ~4,500 of an item's ~5,500 instructions.
+//   b2r[c]   = b2[16c + (lane & 15)]
+struct FwdRegs {
+    float w2b[C1];
+    float wm[4][4];
+    float b2r[4];
+};
+
+__device__ __forceinline__ void load_fwd_regs(const VfeParams &P, const float *wl, int lane, FwdRegs &F) {
+#pragma unroll
+    for (int i = 0; i < C1; i += 4) {
+        const float4 q = *reinterpret_cast<const float4 *>(P.w2 + lane * 32 + 16 + i);
+        F.w2b[i] = q.x; F.w2b[i + 1] = q.y; F.w2b[i + 2] = q.z; F.w2b[i + 3] = q.w;
+    }
+    const int fn = lane & 15, fq = lane >> 4;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) F.wm[c][s] = P.w2[(16 * c + fn) * 32 + 4 * s + fq];
+        F.b2r[c] = P.b2[16 * c + fn];
+    }
+}
+
 // forward of one item up to h2 (row lanes), leaving: tile = h2[row][0..63], sv[slot].AGG1 (and AM1), mk, sid,
 // and (WANT_P1T) p1t = p1*m.  Returns per-lane h1 and p1 (unmasked).
 template <int G, bool WANT_AM1, bool WANT_P1T>
 __device__ __forceinline__ void forward_to_h2(const float *__restrict__ wl, const float *__restrict__ stats,
                                               const WaveLds &L, int lane, int v, int r, int s, int j,
-                                              const float x[CIN], float m, const float w2b[C1], float h1[C1],
+                                              const float x[CIN], float m, const FwdRegs &F, float h1[C1],
                                               float p1[C1]) {
     constexpr int R = 64 / G;
+    VFE_TR(1);   // inputs loaded
     layer1_lds(wl, x, h1);
 #pragma unroll
     for (int o = 0; o < C1; ++o) {
@@ -167,6 +234,7 @@ __device__ __forceinline__ void forward_to_h2(const float *__restrict__ wl, cons
     L.mk[lane] = m;
     if (j == 0) { L.sid[s] = v; L.sid[8 + s] = r; }
     __builtin_amdgcn_wave_barrier();
+    VFE_TR(2);   // layer 1 + BN1
     // (slot, channel) tasks: agg1 = max over the slot's rows, first index on ties
     for (int task = lane; task < G * C1; task += 64) {
         const int ts = task >> 4, c = task & 15;
@@ -182,30 +250,56 @@ __device__ __forceinline__ void forward_to_h2(const float *__restrict__ wl, cons
         if (WANT_AM1) L.sv[ts * SV + V_AM1 + c] = __int_as_float(amx);
     }
     __builtin_amdgcn_wave_barrier();
+    VFE_TR(3);   // agg1
     // u[slot][o] = sum_i W2[o][16+i] * agg1[slot][i]   (lane = o)
+    {   // the G chains are independent: i outer, so that a wave alone on its SIMD has G FMAs in flight
+        float u[G];
 #pragma unroll
-    for (int ts = 0; ts < G; ++ts) {
-        float u = 0.f;
+        for (int ts = 0; ts < G; ++ts) u[ts] = 0.f;
 #pragma unroll
-        for (int i = 0; i < C1; ++i) u = fmaf(w2b[i], L.sv[ts * SV + V_AGG1 + i], u);
-        L.sv[ts * SV + V_U + lane] = u;
+        for (int i = 0; i < C1; ++i)
+#pragma unroll
+            for (int ts = 0; ts < G; ++ts) u[ts] = fmaf(F.w2b[i], L.sv[ts * SV + V_AGG1 + i], u[ts]);
+#pragma unroll
+        for (int ts = 0; ts < G; ++ts) L.sv[ts * SV + V_U + lane] = u[ts];
     }
     if (WANT_P1T) {
 #pragma unroll
         for (int i = 0; i < C1; ++i) L.p1t[lane * 16 + i] = p1[i] * m;
     }
     __builtin_amdgcn_wave_barrier();
-    // h2[o] = relu(b2[o] + m * (sum_{i<16} W2[o][i]*p1[i] + u[o])) -> this lane's tile row (p1 was consumed above)
-    const float *uvec = L.sv + s * SV + V_U;
-#pragma unroll VFE_O_UNROLL
-    for (int o = 0; o < C2; ++o) {
-        float a = 0.f;
+    VFE_TR(4);   // u
+    // h2[row][o] = relu(b2[o] + m[row] * (sum_{i<16} p1[row][i] W2[o][i] + u[slot(row)][o])) -> tile, on the matrix cores.
+    // A[m][k]: lane (fn, fq) supplies p1[16b + fn][4s + fq] (read from the tile BEFORE any h2 is stored: LDS operations
+    // of one wave execute in program order); D: lane holds rows 16b + 4fq + e (e = 0..3) of column 16c + fn.
+    const int fn = lane & 15, fq = lane >> 4;
+    float a[4][4];
 #pragma unroll
-        for (int i = 0; i < C1; ++i) a = fmaf(wl[WL_W2A + o * C1 + i], p1[i], a);
-        a = fmaf(m, a + uvec[o], wl[WL_B2 + o]);
-        L.tile[lane * TS + o] = fmaxf(a, 0.f);
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[b][k] = L.tile[(16 * b + fn) * TS + 4 * k + fq];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        f32x4_t acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[b][k], F.wm[c][k], acc[c], 0, 0, 0);
+        const int row0 = 16 * b + 4 * fq;                     // the 4 rows of a lane share a voxel slot (R >= 8)
+        const f32x4_t mk4 = *reinterpret_cast<const f32x4_t *>(L.mk + row0);
+        const float *uvec = L.sv + (row0 / R) * SV + V_U;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float u = uvec[16 * c + fn];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                L.tile[(row0 + e) * TS + 16 * c + fn] = fmaxf(fmaf(mk4[e], acc[c][e] + u, F.b2r[c]), 0.f);
+        }
     }
     __builtin_amdgcn_wave_barrier();
+    VFE_TR(5);   // h2
 }
 
 // combine per-wave lane values (lane = channel) across the waves of the workgroup and write the slab
@@ -241,25 +335,22 @@ __device__ __forceinline__ void lane_sums_to_slab(const float (&vals)[N], float 
 }
 
 __device__ __forceinline__ void load_weights_lds(const VfeParams &P, float *wl) {
-    for (int idx = threadIdx.x; idx < C1 * C2; idx += NT) {
-        const int o = idx / C1, i = idx - o * C1;
-        wl[WL_W2A + idx] = P.w2[o * 32 + i];                 // first half of W2, [o][i]
-        const int i2 = idx / C2, o2 = idx - i2 * C2;
-        wl[WL_W2B + i2 * TS + o2] = P.w2[o2 * 32 + 16 + i2];  // second half transposed: [i][o] = W2[o][16+i]
-    }
     for (int idx = threadIdx.x; idx < C1 * CIN; idx += NT) wl[WL_W1 + idx] = P.w1[idx];
     if (threadIdx.x < C1) wl[WL_B1 + threadIdx.x] = P.b1[threadIdx.x];
-    if (threadIdx.x < C2) wl[WL_B2 + threadIdx.x] = P.b2[threadIdx.x];
     __syncthreads();
 }
 
 // run BODY<G>(first, n, item) for every item of this wave, class by class (wave-uniform branches)
 #define VFE_FOR_ITEMS(it, BODY)                                                                                       \
+    VFE_TR_DECL                                                                                                        \
     for (int item_ = blockIdx.x * NW + wave; item_ < (it).total; item_ += gridDim.x * NW) {                            \
         asm volatile("" ::: "memory"); /* uniform operands are re-read from LDS per item, not hoisted */               \
-        if (item_ < (it).itemsA) { BODY(8, 0, (it).nA, item_) }                                                         \
-        else if (item_ < (it).itemsA + (it).itemsB) { BODY(4, (it).nA, (it).nB, item_ - (it).itemsA) }                  \
-        else { BODY(1, (it).nA + (it).nB, (it).nC, item_ - (it).itemsA - (it).itemsB) }                                 \
+        VFE_TR(0);                                                                                                     \
+        if (item_ < (it).itemsA) { VFE_TR_CLASS(8); BODY(8, 0, (it).nA, item_) }                                        \
+        else if (item_ < (it).itemsA + (it).itemsB) { VFE_TR_CLASS(4); BODY(4, (it).nA, (it).nB, item_ - (it).itemsA) } \
+        else { VFE_TR_CLASS(1); BODY(1, (it).nA + (it).nB, (it).nC, item_ - (it).itemsA - (it).itemsB) }                \
+        VFE_TR(14);                                                                                                    \
+        VFE_TR_NEXT                                                                                                    \
     }
 
 // ---- pre-pass ---------------------------------------------------------------------------
@@ -280,34 +371,86 @@ __global__ void __launch_bounds__(256) k_vfe_rows(const float *__restrict__ feat
     if (lane == 0) rows[v] = (uint8_t)(last + 1);       // <= T
 }
 
-// stable partition of the voxel ids by class (one workgroup; K <= a few 100k): list = [A.. | B.. | C..]
-__global__ void __launch_bounds__(1024) k_vfe_partition(const uint8_t *__restrict__ rows, int64_t K, int32_t *__restrict__ list,
-                                                        int32_t *__restrict__ counts) {
-    __shared__ int cnt[3][1024];
-    const int tid = threadIdx.x;
-    const int64_t per = (K + 1023) / 1024, lo = tid * per, hi = lo + per < K ? lo + per : K;
+// stable partition of the voxel ids by class: list = [A.. | B.. | C..].  Workgroup b owns voxels [4096 b, 4096 b + 4096), 16
+// per thread.  There is no cross-workgroup hand-off: every workgroup counts the classes of ALL K row counts itself (K bytes,
+// 16 per load, L2-resident: ~40 loads per thread at K = 160k) to get the class totals and the counts in front of its chunk,
+// then scans its own 256 x 16 voxels with wave shuffles and writes them out in order.
+constexpr int PART_CHUNK = 4096;
+
+__device__ __forceinline__ void classify16(const uint4 &q, int64_t v0, int64_t K, int c[3]) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int r = (w[j >> 2] >> (8 * (j & 3))) & 255;
+        const bool in = v0 + j < K;
+        c[0] += in && r <= 8; c[1] += in && r > 8 && r <= 16; c[2] += in && r > 16;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_vfe_partition(const uint8_t *__restrict__ rows, int64_t K, int32_t *__restrict__ list,
+                                                       int32_t *__restrict__ counts) {
+    __shared__ int red[4][9];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n16 = (K + 15) >> 4, mine = (int64_t)blockIdx.x * (PART_CHUNK / 16);   // in units of 16 voxels
+    // (rows has room for a multiple of 16 bytes: the workspace plan aligns it; bytes past K are masked)
+    int before[3] = {0, 0, 0}, total[3] = {0, 0, 0};
+    for (int64_t i = tid; i < n16; i += 256) {
+        int c[3] = {0, 0, 0};
+        classify16(*reinterpret_cast<const uint4 *>(rows + i * 16), i * 16, K, c);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { total[k] += c[k]; before[k] += i < mine ? c[k] : 0; }
+    }
+    // own 16 voxels
+    const int64_t v0 = (mine + tid) * 16;
     int c[3] = {0, 0, 0};
-    for (int64_t v = lo; v < hi; ++v) {
-        const int r = rows[v];
-        ++c[r <= 8 ? 0 : (r <= 16 ? 1 : 2)];
+    uint4 q = make_uint4(0, 0, 0, 0);
+    if (v0 < K) {
+        q = *reinterpret_cast<const uint4 *>(rows + v0);
+        classify16(q, v0, K, c);
     }
-    for (int k = 0; k < 3; ++k) cnt[k][tid] = c[k];
+    int inc[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int x = c[k], t = total[k], bf = before[k];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int y = __shfl_up(x, o, 64);
+            if (lane >= o) x += y;
+            t += __shfl_xor(t, o, 64);
+            bf += __shfl_xor(bf, o, 64);
+        }
+        inc[k] = x;
+        if (lane == 63) red[wave][k] = x;
+        if (lane == 0) { red[wave][3 + k] = t; red[wave][6 + k] = bf; }
+    }
     __syncthreads();
-    // inclusive scan per class (Hillis-Steele over 1024 entries)
-    for (int off = 1; off < 1024; off <<= 1) {
-        int t[3];
-        for (int k = 0; k < 3; ++k) t[k] = tid >= off ? cnt[k][tid - off] : 0;
-        __syncthreads();
-        for (int k = 0; k < 3; ++k) cnt[k][tid] += t[k];
-        __syncthreads();
+    int pos[3], tot[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        int base = 0, t = 0, bf = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) base += red[w][k];
+            t += red[w][3 + k];
+            bf += red[w][6 + k];
+        }
+        tot[k] = t;
+        pos[k] = bf + base + inc[k] - c[k];
     }
-    const int nA = cnt[0][1023], nB = cnt[1][1023];
-    int pos[3] = {cnt[0][tid] - c[0], nA + cnt[1][tid] - c[1], nA + nB + cnt[2][tid] - c[2]};
-    for (int64_t v = lo; v < hi; ++v) {
-        const int r = rows[v];
-        list[pos[r <= 8 ? 0 : (r <= 16 ? 1 : 2)]++] = (int32_t)v;
+    pos[1] += tot[0];
+    pos[2] += tot[0] + tot[1];
+    if (v0 < K) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int r = (w[j >> 2] >> (8 * (j & 3))) & 255;
+            if (v0 + j < K) {   // (no dynamically indexed private array: three predicated stores)
+                if (r <= 8) list[pos[0]++] = (int32_t)(v0 + j);
+                else if (r <= 16) list[pos[1]++] = (int32_t)(v0 + j);
+                else list[pos[2]++] = (int32_t)(v0 + j);
+            }
+        }
     }
-    if (tid == 0) { counts[0] = nA; counts[1] = nB; counts[2] = cnt[2][1023]; }
+    if (blockIdx.x == 0 && tid == 0) { counts[0] = tot[0]; counts[1] = tot[1]; counts[2] = tot[2]; }
 }
 
 // ---- forward passes ---------------------------------------------------------------------
@@ -316,6 +459,7 @@ __global__ void __launch_bounds__(NT) k_vfe_p1(const float *__restrict__ feature
                                                float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VFE_TR_KERNEL(-1)
     const Items it = load_items(wk);
     float acc[2 * C1];
 #pragma unroll
@@ -344,12 +488,12 @@ __global__ void __launch_bounds__(NT) k_vfe_p1(const float *__restrict__ feature
 template <int G>
 __device__ __forceinline__ void p2_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
                                         int item, const float *wl, const float *stats, const WaveLds &L, int lane,
-                                        const float w2b[C1], float &s1, float &s2) {
+                                        const FwdRegs &F, float &s1, float &s2) {
     int v, r, s, j; float wgt;
     item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
     float x[CIN], m, h1[C1], p1[C1];
     load_row(feature, v, T, j, j < r, x, m);
-    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, w2b, h1, p1);
+    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, F, h1, p1);
     L.p1t[lane] = wgt;                          // row weights (p1t is free in this pass)
     __builtin_amdgcn_wave_barrier();
     for (int t = 0; t < 64; ++t) {              // lane = channel; idle rows weigh 0 and hold finite values
@@ -364,15 +508,15 @@ __global__ void __launch_bounds__(NT) k_vfe_p2(const float *__restrict__ feature
                                                const float *__restrict__ stats, float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VFE_TR_KERNEL(2)
     float *wl = smem;
     load_weights_lds(P, wl);
-    const WaveLds L = carve_lds(smem + WL_END, wave);
+    const WaveLds L = carve_lds<false>(smem + WL_END, wave);
     const Items it = load_items(wk);
-    float w2b[C1];
-#pragma unroll
-    for (int i = 0; i < C1; ++i) w2b[i] = wl[WL_W2B + i * TS + lane];
+    FwdRegs F;
+    load_fwd_regs(P, wl, lane, F);
     float s1 = 0.f, s2 = 0.f;
-#define BODY_P2(G, first, n, item) p2_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, w2b, s1, s2);
+#define BODY_P2(G, first, n, item) p2_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, F, s1, s2);
     VFE_FOR_ITEMS(it, BODY_P2)
 #undef BODY_P2
     __syncthreads();
@@ -384,14 +528,14 @@ __global__ void __launch_bounds__(NT) k_vfe_p2(const float *__restrict__ feature
 template <int G>
 __device__ __forceinline__ void p3_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
                                         int item, const float *wl, const float *stats, const WaveLds &L, int lane,
-                                        const float w2b[C1], float mean2, float S2, float be2,
+                                        const FwdRegs &F, float mean2, float S2, float be2,
                                         float *__restrict__ voxelwise) {
     constexpr int R = 64 / G;
     int v, r, s, j; float wgt;
     item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
     float x[CIN], m, h1[C1], p1[C1];
     load_row(feature, v, T, j, j < r, x, m);
-    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, w2b, h1, p1);
+    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, F, h1, p1);
     // lane = channel, per voxel: agg2 = max_t p2 ; vw_lo = max_t p2*m ; vw_hi = max_t agg2*m
     for (int ts = 0; ts < G; ++ts) {
         const int tv = uni(L.sid[ts]), tr = uni(L.sid[8 + ts]);
@@ -417,15 +561,15 @@ __global__ void __launch_bounds__(NT) k_vfe_p3(const float *__restrict__ feature
                                                const float *__restrict__ stats, float *__restrict__ voxelwise) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VFE_TR_KERNEL(3)
     float *wl = smem;
     load_weights_lds(P, wl);
-    const WaveLds L = carve_lds(smem + WL_END, wave);
+    const WaveLds L = carve_lds<false>(smem + WL_END, wave);
     const Items it = load_items(wk);
-    float w2b[C1];
-#pragma unroll
-    for (int i = 0; i < C1; ++i) w2b[i] = wl[WL_W2B + i * TS + lane];
+    FwdRegs F;
+    load_fwd_regs(P, wl, lane, F);
     const float mean2 = stats[ST2 + lane], S2 = stats[ST2 + 2 * C2 + lane], be2 = stats[ST2 + 3 * C2 + lane];
-#define BODY_P3(G, first, n, item) p3_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, w2b, mean2, S2, be2, voxelwise);
+#define BODY_P3(G, first, n, item) p3_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, F, mean2, S2, be2, voxelwise);
     VFE_FOR_ITEMS(it, BODY_P3)
 #undef BODY_P3
 }
@@ -486,25 +630,45 @@ __global__ void __launch_bounds__(256) k_vfe_finalize(const float *__restrict__ 
 // ---- backward passes --------------------------------------------------------------------
 // channel-lane analysis of layer-2 outputs for one voxel slot (rows row0 .. row0+tr-1): impulses of d_p2
 //   r1 = argmax_t p2*m (first), g1 = dvw[c]*m[r1] ; r2 = argmax_t p2, g2 = dvw[64+c]*m[a'], a' = argmax_t agg2*m
+// The loops over a slot's rows run in chunks of 8 with all LDS reads of a chunk issued before its compare chain (one wave
+// per SIMD: a read per iteration would pay the LDS latency tr times); rows >= tr of a chunk are read (they exist: R is a
+// multiple of 8) and skipped.
+template <int R>
 __device__ __forceinline__ void impulses(const WaveLds &L, int row0, int tr, int lane, float mean2, float S2, float be2,
                                          float dlo, float dhi, int &r1, float &g1, int &r2, float &g2, float &xh1,
                                          float &xh2, float inv2) {
     float agg = -INFINITY, vlo = -INFINITY;
     r1 = 0; r2 = 0;
     float h_r1 = 0.f, h_r2 = 0.f;
-    for (int t = 0; t < tr; ++t) {
-        const float h = L.tile[(row0 + t) * TS + lane];
-        const float p = fmaf(S2, h - mean2, be2);
-        const float pm = p * L.mk[row0 + t];
-        if (p > agg) { agg = p; r2 = t; h_r2 = h; }
-        if (pm > vlo) { vlo = pm; r1 = t; h_r1 = h; }
+#pragma unroll
+    for (int t0 = 0; t0 < R; t0 += 8) {
+        if (R > 8 && t0 >= tr) break;
+        float h[8], mk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { h[u] = L.tile[(row0 + t0 + u) * TS + lane]; mk[u] = L.mk[row0 + t0 + u]; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int t = t0 + u;
+            const float p = fmaf(S2, h[u] - mean2, be2);
+            const float pm = p * mk[u];
+            if (t < tr && p > agg) { agg = p; r2 = t; h_r2 = h[u]; }
+            if (t < tr && pm > vlo) { vlo = pm; r1 = t; h_r1 = h[u]; }
+        }
     }
     // a' = first t maximising agg*m[t]
     int ap = 0;
     float best = -INFINITY;
-    for (int t = 0; t < tr; ++t) {
-        const float q = agg * L.mk[row0 + t];
-        if (q > best) { best = q; ap = t; }
+#pragma unroll
+    for (int t0 = 0; t0 < R; t0 += 8) {
+        if (R > 8 && t0 >= tr) break;
+        float mk[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mk[u] = L.mk[row0 + t0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float q = agg * mk[u];
+            if (t0 + u < tr && q > best) { best = q; ap = t0 + u; }
+        }
     }
     g1 = dlo * L.mk[row0 + r1];
     g2 = dhi * L.mk[row0 + ap];
@@ -512,24 +676,39 @@ __device__ __forceinline__ void impulses(const WaveLds &L, int row0, int tr, int
     xh2 = (h_r2 - mean2) * inv2;
 }
 
+// d_voxelwise of the G voxels of an item for this channel lane, requested at the START of the item (the voxel ids come
+// straight from the work list) so that the loads are in flight during the forward recomputation
+template <int G>
+__device__ __forceinline__ void load_dvw(const WorkList &wk, int first, int n, int item, int lane,
+                                         const float *__restrict__ dvw, float dlo[G], float dhi[G]) {
+#pragma unroll
+    for (int ts = 0; ts < G; ++ts) {
+        const int idx = item * G + ts;
+        const int tv = idx < n ? wk.list[first + idx] : -1;
+        dlo[ts] = tv >= 0 ? dvw[(int64_t)tv * 128 + lane] : 0.f;
+        dhi[ts] = tv >= 0 ? dvw[(int64_t)tv * 128 + 64 + lane] : 0.f;
+    }
+}
+
 // backward pass 1: BN2 sums ; slab = [sum d_p2 (64) | sum d_p2*xhat2 (64)]
 template <int G>
 __device__ __forceinline__ void b1_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
                                         int item, const float *wl, const float *stats, const WaveLds &L, int lane,
-                                        const float w2b[C1], float mean2, float inv2, float S2, float be2,
+                                        const FwdRegs &F, float mean2, float inv2, float S2, float be2,
                                         const float *__restrict__ dvw, float &s1, float &s2) {
     constexpr int R = 64 / G;
     int v, r, s, j; float wgt;
     item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
-    float x[CIN], m, h1[C1], p1[C1];
+    float x[CIN], m, h1[C1], p1[C1], dlo[G], dhi[G];
+    load_dvw<G>(wk, first, n, item, lane, dvw, dlo, dhi);
     load_row(feature, v, T, j, j < r, x, m);
-    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, w2b, h1, p1);
+    forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, F, h1, p1);
+#pragma unroll
     for (int ts = 0; ts < G; ++ts) {
         const int tv = uni(L.sid[ts]), tr = uni(L.sid[8 + ts]);
         if (tv < 0) continue;
         int r1, r2; float g1, g2, xh1, xh2;
-        impulses(L, ts * R, tr, lane, mean2, S2, be2, dvw[(int64_t)tv * 128 + lane], dvw[(int64_t)tv * 128 + 64 + lane], r1, g1,
-                 r2, g2, xh1, xh2, inv2);
+        impulses<R>(L, ts * R, tr, lane, mean2, S2, be2, dlo[ts], dhi[ts], r1, g1, r2, g2, xh1, xh2, inv2);
         s1 += g1 + g2;
         s2 += g1 * xh1 + g2 * xh2;
     }
@@ -541,17 +720,17 @@ __global__ void __launch_bounds__(NT) k_vfe_b1(const float *__restrict__ feature
                                                float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VFE_TR_KERNEL(11)
     float *wl = smem;
     load_weights_lds(P, wl);
-    const WaveLds L = carve_lds(smem + WL_END, wave);
+    const WaveLds L = carve_lds<false>(smem + WL_END, wave);
     const Items it = load_items(wk);
-    float w2b[C1];
-#pragma unroll
-    for (int i = 0; i < C1; ++i) w2b[i] = wl[WL_W2B + i * TS + lane];
+    FwdRegs F;
+    load_fwd_regs(P, wl, lane, F);
     const float mean2 = stats[ST2 + lane], inv2 = stats[ST2 + C2 + lane], S2 = stats[ST2 + 2 * C2 + lane],
                 be2 = stats[ST2 + 3 * C2 + lane];
     float s1 = 0.f, s2 = 0.f;
-#define BODY_B1(G, first, n, item) b1_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, w2b, mean2, inv2, S2, be2, dvw, s1, s2);
+#define BODY_B1(G, first, n, item) b1_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, F, mean2, inv2, S2, be2, dvw, s1, s2);
     VFE_FOR_ITEMS(it, BODY_B1)
 #undef BODY_B1
     __syncthreads();
@@ -584,24 +763,29 @@ __global__ void __launch_bounds__(256) k_vfe_bn_bwd_finalize(const float *__rest
 // backward pass 2: layer-2 parameter grads, d_p1 rows -> workspace, BN1 sums
 //   slab = [db2 (64) | dW2 (64*32) | sum d_p1 (16) | sum d_p1*xhat1 (16)]
 struct B2Acc {
-    float db2, dw2a[C1], dw2b[C1], bn1[2 * C1];
+    float db2, dw2b[C1], bn1[2 * C1];
+    f32x4_t dw2m[4];   // dW2[o][i], i < 16, as MFMA accumulators: lane (fn, fq) holds o = 16b + 4fq + e, i = fn
+    float wd[C1];      // B operand of the d_p1 product: W2[4s + fq][fn]
+    float wb[C1];      // B operand of the d_agg1 product: W2[4s + fq][16 + fn]
 };
 
 template <int G>
 __device__ __forceinline__ void b2_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
                                         int item, const float *wl, const float *stats, const float *coef2, const WaveLds &L,
-                                        int lane, const float w2b[C1], float mean2, float inv2, float S2, float be2,
+                                        int lane, const FwdRegs &F, float mean2, float inv2, float S2, float be2,
                                         float c0, float c1, float c2, const float *__restrict__ dvw,
                                         float *__restrict__ dp1_ws, B2Acc &A) {
     constexpr int R = 64 / G;
     int v, r, s, j; float wgt;
     item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
     const bool active = j < r;
-    float x[CIN], m, h1[C1], p1[C1];
+    float x[CIN], m, h1[C1], p1[C1], dlo[G], dhi[G];
+    load_dvw<G>(wk, first, n, item, lane, dvw, dlo, dhi);
     load_row(feature, v, T, j, active, x, m);
-    forward_to_h2<G, true, true>(wl, stats, L, lane, v, r, s, j, x, m, w2b, h1, p1);
+    forward_to_h2<G, true, true>(wl, stats, L, lane, v, r, s, j, x, m, F, h1, p1);
     // lane = channel o, per voxel: d_pre2[t][o] = (h2>0) * (c0*d_p2 + w_t*(c1*(h2-mean) + c2)) written over h2 in the
-    // tile, with db2, s[o] = sum_t m_t d_pre2 and dW2a[o][i] += sum_t d_pre2[t][o]*p1m[t][i] on the way
+    // tile, with db2 and s[o] = sum_t m_t d_pre2 on the way
+#pragma unroll
     for (int ts = 0; ts < G; ++ts) {
         const int tv = uni(L.sid[ts]), tr = uni(L.sid[8 + ts]);
         if (tv < 0) {
@@ -609,46 +793,90 @@ __device__ __forceinline__ void b2_item(const float *__restrict__ feature, int T
             continue;
         }
         int r1, r2; float g1, g2, xh1, xh2;
-        impulses(L, ts * R, tr, lane, mean2, S2, be2, dvw[(int64_t)tv * 128 + lane], dvw[(int64_t)tv * 128 + 64 + lane], r1, g1,
-                 r2, g2, xh1, xh2, inv2);
+        impulses<R>(L, ts * R, tr, lane, mean2, S2, be2, dlo[ts], dhi[ts], r1, g1, r2, g2, xh1, xh2, inv2);
         float sm = 0.f;
-        for (int t = 0; t < tr; ++t) {
-            const int row = ts * R + t;
-            const float h = L.tile[row * TS + lane];
-            float dp = 0.f;
-            if (t == r1) dp += g1;
-            if (t == r2) dp += g2;
-            const float wt = t == tr - 1 ? (float)(T - tr + 1) : 1.f;
-            const float dh = fmaf(c0, dp, wt * fmaf(c1, h - mean2, c2));
-            const float d = h > 0.f ? dh : 0.f;
-            L.tile[row * TS + lane] = d;
-            A.db2 += d;
-            sm = fmaf(L.mk[row], d, sm);
 #pragma unroll
-            for (int i = 0; i < C1; ++i) A.dw2a[i] = fmaf(d, L.p1t[row * 16 + i], A.dw2a[i]);
+        for (int t0 = 0; t0 < R; t0 += 8) {
+            if (R > 8 && t0 >= tr) break;
+            float hh[8], mk[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { hh[u] = L.tile[(ts * R + t0 + u) * TS + lane]; mk[u] = L.mk[ts * R + t0 + u]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + u, row = ts * R + t;
+                if (t >= tr) continue;
+                const float h = hh[u];
+                float dp = 0.f;
+                if (t == r1) dp += g1;
+                if (t == r2) dp += g2;
+                const float wt = t == tr - 1 ? (float)(T - tr + 1) : 1.f;
+                const float dh = fmaf(c0, dp, wt * fmaf(c1, h - mean2, c2));
+                const float d = h > 0.f ? dh : 0.f;
+                L.tile[row * TS + lane] = d;
+                A.db2 += d;
+                sm = fmaf(mk[u], d, sm);
+            }
         }
 #pragma unroll
         for (int i = 0; i < C1; ++i) A.dw2b[i] = fmaf(L.sv[ts * SV + V_AGG1 + i], sm, A.dw2b[i]);
         L.sv[ts * SV + V_S + lane] = sm;
     }
     __builtin_amdgcn_wave_barrier();
-    // (slot, i') tasks: d_agg1[i'] = sum_o W2[o][16+i'] * s[o]
-    for (int task = lane; task < G * C1; task += 64) {
-        const int ts = task >> 4, c = task & 15;
-        float da = 0.f;
-        for (int o = 0; o < C2; ++o) da = fmaf(wl[WL_W2B + c * TS + o], L.sv[ts * SV + V_S + o], da);
-        L.sv[ts * SV + V_DAG1 + c] = da;
+    VFE_TR(6);   // b2: impulses + d_pre2
+    // d_agg1[slot][i'] = sum_o s[slot][o] * W2[o][16+i']: a (16 slots, G used) x 16 x 64 product = 16 MFMAs, the fmaf chain
+    // over o of the scalar form.  A[m = slot][k = o] from sv (rows >= G: zero), B[k = o][n = i'] in registers.
+    {
+        const int fn_ = lane & 15, fq_ = lane >> 4;
+        f32x4_t da = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float sa = fn_ < G ? L.sv[fn_ * SV + V_S + 4 * k + fq_] : 0.f;
+            da = __builtin_amdgcn_mfma_f32_16x16x4f32(sa, A.wb[k], da, 0, 0, 0);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * fq_ + e < G) L.sv[(4 * fq_ + e) * SV + V_DAG1 + fn_] = da[e];
     }
     __builtin_amdgcn_wave_barrier();
-    // row lanes: d_p1m[i] = sum_o d_pre2[o]*W2[o][i] ; d_p1[i] = d_p1m[i]*m + [t == am1[i]] * d_agg1[i]
+    VFE_TR(7);   // b2: d_agg1
+    // The two 64 x 64 x 16 products of the layer-2 backward on the matrix cores (exact fp32, each accumulator the fmaf
+    // chain of the scalar form in the same order; rows outside a voxel's r hold finite h2 and p1m = 0, so they add 0):
+    //   dW2[o][i] += sum_t d_pre2[t][o] * p1m[t][i]      A[m = o][k = t] from the tile (transposed), B[k = t][n = i] = p1t
+    //   d_p1m[t][i] = sum_o d_pre2[t][o] * W2[o][i]      A[m = t][k = o] from the tile, B[k = o][n = i] = W2 (registers)
+    const int fn = lane & 15, fq = lane >> 4;
+    {
+        float bt[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) bt[k] = L.p1t[(4 * k + fq) * 16 + fn];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                A.dw2m[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.tile[(4 * k + fq) * TS + 16 * b + fn], bt[k], A.dw2m[b], 0, 0, 0);
+    }
+    {
+        f32x4_t acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(L.tile[(16 * b + fn) * TS + 4 * k + fq], A.wd[k], acc[b], 0, 0, 0);
+        // D: lane holds rows 16b + 4fq + e of column i = fn -> p1t (its p1m rows were consumed above), back to row lanes
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) L.p1t[(16 * b + 4 * fq + e) * 16 + fn] = acc[b][e];
+    }
+    __builtin_amdgcn_wave_barrier();
+    VFE_TR(8);   // b2: the two MFMA products
+    // row lanes: d_p1[i] = d_p1m[i]*m + [t == am1[i]] * d_agg1[i]
     float dp1[C1];
 #pragma unroll
-    for (int i = 0; i < C1; ++i) dp1[i] = 0.f;
-#pragma unroll VFE_O_UNROLL
-    for (int o = 0; o < C2; ++o) {
-        const float d = L.tile[lane * TS + o];
-#pragma unroll
-        for (int i = 0; i < C1; ++i) dp1[i] = fmaf(d, wl[WL_W2A + o * C1 + i], dp1[i]);
+    for (int i = 0; i < C1; i += 4) {
+        const f32x4_t q = *reinterpret_cast<const f32x4_t *>(L.p1t + lane * 16 + i);
+        dp1[i] = q[0]; dp1[i + 1] = q[1]; dp1[i + 2] = q[2]; dp1[i + 3] = q[3];
     }
     const float *svs = L.sv + s * SV;
 #pragma unroll
@@ -677,6 +905,7 @@ __global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature
                                                float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VFE_TR_KERNEL(12)
     float *wl = smem;
     load_weights_lds(P, wl);
     // this kernel also keeps the BN statistics and the BN2 backward coefficients in LDS (512 more uniform floats)
@@ -685,20 +914,25 @@ __global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature
     for (int i = threadIdx.x; i < 3 * C2; i += NT) cf_l[i] = coef2_g[i];
     __syncthreads();
     const float *stats = st_l, *coef2 = cf_l;
-    const WaveLds L = carve_lds(smem + WL_END, wave);
+    const WaveLds L = carve_lds<true>(smem + WL_END, wave);
     const Items it = load_items(wk);
-    float w2b[C1];
-#pragma unroll
-    for (int i = 0; i < C1; ++i) w2b[i] = wl[WL_W2B + i * TS + lane];
+    FwdRegs F;
+    load_fwd_regs(P, wl, lane, F);
     const float mean2 = stats[ST2 + lane], inv2 = stats[ST2 + C2 + lane], S2 = stats[ST2 + 2 * C2 + lane],
                 be2 = stats[ST2 + 3 * C2 + lane];
     const float c0 = coef2[lane], c1 = coef2[C2 + lane], c2 = coef2[2 * C2 + lane];
     B2Acc A;
     A.db2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < C1; ++i) { A.dw2a[i] = 0.f; A.dw2b[i] = 0.f; A.bn1[i] = 0.f; A.bn1[C1 + i] = 0.f; }
+    for (int i = 0; i < C1; ++i) {
+        A.dw2b[i] = 0.f; A.bn1[i] = 0.f; A.bn1[C1 + i] = 0.f;
+        A.wd[i] = P.w2[(4 * i + (lane >> 4)) * 32 + (lane & 15)];
+        A.wb[i] = P.w2[(4 * i + (lane >> 4)) * 32 + 16 + (lane & 15)];
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) A.dw2m[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #define BODY_B2(G, first, n, item) \
-    b2_item<G>(feature, T, wk, first, n, item, wl, stats, coef2, L, lane, w2b, mean2, inv2, S2, be2, c0, c1, c2, dvw, dp1_ws, A);
+    b2_item<G>(feature, T, wk, first, n, item, wl, stats, coef2, L, lane, F, mean2, inv2, S2, be2, c0, c1, c2, dvw, dp1_ws, A);
     VFE_FOR_ITEMS(it, BODY_B2)
 #undef BODY_B2
     __syncthreads();
@@ -710,12 +944,11 @@ __global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature
         __syncthreads();
     }
     {
-        // dW2[o][i] = dw2a[i], dW2[o][16+i] = dw2b[i] ; combined through LDS as [j][lane] then transposed on store
+        // dW2[o][i] = dw2m (MFMA layout), dW2[o][16+i] = dw2b[i] ; combined through LDS as [j][o] then transposed on store
         const int n = 32 * 64;
-        for (int j = 0; j < C1; ++j) {
-            smem[wave * n + j * 64 + lane] = A.dw2a[j];
-            smem[wave * n + (C1 + j) * 64 + lane] = A.dw2b[j];
-        }
+        for (int b = 0; b < 4; ++b)
+            for (int e = 0; e < 4; ++e) smem[wave * n + (lane & 15) * 64 + 16 * b + 4 * (lane >> 4) + e] = A.dw2m[b][e];
+        for (int j = 0; j < C1; ++j) smem[wave * n + (C1 + j) * 64 + lane] = A.dw2b[j];
         __syncthreads();
         for (int i = threadIdx.x; i < n; i += NT) {
             const int j = i >> 6, o = i & 63;
@@ -734,6 +967,7 @@ __global__ void __launch_bounds__(NT) k_vfe_b3(const float *__restrict__ feature
                                                const float *__restrict__ dp1_ws, float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    VFE_TR_KERNEL(-1)
     const Items it = load_items(wk);
     float acc[C1 * CIN + C1];
 #pragma unroll
@@ -807,8 +1041,8 @@ __global__ void __launch_bounds__(256) k_vfe_reduce_multi(const ReduceJobs J, in
 }
 
 struct Plan {
-    int blocks;
-    size_t lds_small, lds_full;
+    int blocks, blocks_b2;   // pass b2 needs > 256 VGPRs: one wave per SIMD, two workgroups per CU
+    size_t lds_small, lds_full, lds_b2;
     size_t off_slabs, off_slabs3, off_coef, off_rows, off_list, off_counts, off_dp1, bytes;
 };
 
@@ -818,11 +1052,13 @@ Plan make_plan(int64_t K, int T) {
     if (b < 1) b = 1;
     if (b > VFE_BLOCKS_MAX) b = VFE_BLOCKS_MAX;
     p.blocks = (int)b;
+    p.blocks_b2 = b > 512 ? 512 : (int)b;
     p.lds_small = (size_t)NW * 32 * TS * sizeof(float);                                     // lane_sums_to_slab only
-    size_t full = (size_t)(WL_END + NW * WAVE_FLOATS) * sizeof(float);
+    p.lds_full = (size_t)(WL_END + NW * wave_floats<false>()) * sizeof(float);
+    size_t full = (size_t)(WL_END + NW * wave_floats<true>()) * sizeof(float);
     const size_t red = (size_t)NW * 32 * 64 * sizeof(float);   // slab combine area of pass b2
     if (full < red) full = red;
-    p.lds_full = full;
+    p.lds_b2 = full;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t r = off; off += vn_align(bytes); return r; };
     const size_t k1 = (size_t)(K > 0 ? K : 1);
@@ -843,7 +1079,12 @@ int set_lds_attrs() {
                              reinterpret_cast<const void *>(&k_vfe_p3), reinterpret_cast<const void *>(&k_vfe_b1),
                              reinterpret_cast<const void *>(&k_vfe_b2), reinterpret_cast<const void *>(&k_vfe_b3)};
         for (const void *f : fns) {
-            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#ifdef VFE_TRACE
+            const int max_dyn = 160 * 1024 - 1024;   // the trace build has a few static __shared__ words
+#else
+            const int max_dyn = 160 * 1024;
+#endif
+            const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_dyn);
             if (e != hipSuccess) return e;
         }
         return hipSuccess;
@@ -858,13 +1099,21 @@ int build_worklist(const float *feature, int64_t K, int T, char *ws, const Plan 
     int32_t *counts = reinterpret_cast<int32_t *>(ws + pl.off_counts);
     k_vfe_rows<<<(unsigned)vn_ceil_div(K, 4), 256, 0, st>>>(feature, K, T, rows);
     VN_LAUNCH_STATUS();
-    k_vfe_partition<<<1, 1024, 0, st>>>(rows, K, list, counts);
+    k_vfe_partition<<<(unsigned)vn_ceil_div(K, PART_CHUNK), 256, 0, st>>>(rows, K, list, counts);
     VN_LAUNCH_STATUS();
     *wk = WorkList{rows, list, counts};
     return VN_OK;
 }
 
 }  // namespace
+
+#ifdef VFE_TRACE
+extern "C" int vn_debug_vfe_trace(void *buf, int kernel) {
+    VN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_vfe_trace), &buf, sizeof(buf)));
+    VN_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_vfe_trace_kernel), &kernel, sizeof(kernel)));
+    return VN_OK;
+}
+#endif
 
 extern "C" size_t vn_vfe_workspace_bytes(int64_t K, int32_t T) {
     if (K < 0 || K >= (1ll << 31) / 64 || T <= 0 || T > 64) return 0;
@@ -945,13 +1194,13 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
     VN_LAUNCH_STATUS();
     k_vfe_bn_bwd_finalize<<<C2, 256, 0, st>>>(slabs, pl.blocks, SLAB_B1, 0, C2, rows, w->g2, stats + ST2, coef2, g->dg2, g->dbe2, eval);
     VN_LAUNCH_STATUS();
-    k_vfe_b2<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, d_voxelwise, coef2, dp1, slabs);
+    k_vfe_b2<<<pl.blocks_b2, NT, pl.lds_b2, st>>>(feature, T, P, wk, stats, d_voxelwise, coef2, dp1, slabs);
     VN_LAUNCH_STATUS();
-    k_vfe_bn_bwd_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, SLAB_B2, C2 + C2 * 32, C1, rows, w->g1, stats + ST1, coef1,
+    k_vfe_bn_bwd_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks_b2, SLAB_B2, C2 + C2 * 32, C1, rows, w->g1, stats + ST1, coef1,
                                             g->dg1, g->dbe1, eval);
     VN_LAUNCH_STATUS();
     float *slabs3 = reinterpret_cast<float *>(ws + pl.off_slabs3);
-    k_vfe_b3<<<pl.blocks, NT, pl.lds_small, st>>>(feature, T, P, wk, stats, coef1, dp1, slabs3);
+    k_vfe_b3<<<pl.blocks_b2, NT, pl.lds_small, st>>>(feature, T, P, wk, stats, coef1, dp1, slabs3);
     VN_LAUNCH_STATUS();
     {   // the four parameter-gradient reductions (db2, dW2 from pass b2's slab; dW1, db1 from pass b3's) in one launch
         ReduceJobs J{};
@@ -966,7 +1215,7 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
             first += (n[j] + 3) / 4;
         }
         J.first[4] = first;
-        k_vfe_reduce_multi<<<first, 256, 0, st>>>(J, pl.blocks);
+        k_vfe_reduce_multi<<<first, 256, 0, st>>>(J, pl.blocks_b2);
         VN_LAUNCH_STATUS();
     }
     return VN_OK;
