@@ -31,7 +31,7 @@ vw, stats, wst = M.featnet_forward(feat, params, bufs, True)
 dvw = torch.randn_like(vw)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 lib.vn_debug_vfe_trace.argtypes = [ctypes.c_void_p, ctypes.c_int]
-NWAVES, NITEMS, NP = 512 * 8, 60, 16
+NWAVES, NITEMS, NP = 1024 * 8, 60, 16   # VFE_BLOCKS_MAX workgroups x 8 wave slots (csrc/vfe.hip VFE_TR_SLOT)
 NAMES = {1: "inputs", 2: "layer1+bn1", 3: "agg1", 4: "u", 5: "h2 (mfma)", 6: "impulses+d_pre2", 7: "d_agg1", 8: "dW2+d_p1 (mfma)",
          14: "rest of item"}
 for kid, kname in ((2, "p2"), (3, "p3"), (11, "b1"), (12, "b2")):

@@ -43,10 +43,14 @@ constexpr int ST1 = 0, ST2 = 4 * C1;            // stats: [mean|invstd|S|beta] p
 constexpr int STATS_FLOATS = 4 * C1 + 4 * C2;   // 320
 constexpr int TS = 65;                          // tile row stride (floats)
 constexpr int NW = 2, NT = NW * 64;             // waves / threads per workgroup (LDS: 2 workgroups per CU)
-constexpr int VFE_BLOCKS_MAX = 768;              // three workgroups per CU (LDS: ~44 / 52 KB each)
+constexpr int VFE_BLOCKS_MAX = 1024;             // passes p2 / p3 / b1: four workgroups per CU (LDS 39.6 KB each, <= 256 VGPRs)
 // per-voxel-slot vectors in LDS (floats); odd stride: the 8 slots of a wave fall into different banks
-// (V_S aliases V_U: u is dead once h2 is in the tile, s is written after that)
-constexpr int V_AGG1 = 0, V_AM1 = 16, V_DAG1 = 32, V_U = 48, V_S = 48, SV = 113;
+// Pass b2 (B2 = true) keeps agg1 | am1 | d_agg1 | u (s aliases u: u is dead once h2 is in the tile, s is written after
+// that); the passes that only recompute the forward keep agg1 | u.
+constexpr int V_AGG1 = 0, V_AM1 = 16, V_DAG1 = 32;
+template <bool B2> constexpr int sv_u() { return B2 ? 48 : 16; }
+template <bool B2> constexpr int sv_stride() { return B2 ? 113 : 81; }
+constexpr int V_U = sv_u<true>(), V_S = V_U, SV = sv_stride<true>();   // (names used by pass b2's own code)
 // slab (per workgroup) float counts
 constexpr int SLAB_P1 = 64, SLAB_P2 = 2 * C2, SLAB_B1 = 2 * C2;
 constexpr int SLAB_B2 = C2 + C2 * 32 + 64;   // db2 | dW2[64][32] | bn1 sums (32 used, written 64 wide)
@@ -102,12 +106,13 @@ struct WorkList {
 // Only the first layer's 128 floats are here: the products with W2 run on the matrix cores or with per-lane register
 // operands (FwdRegs, B2Acc).
 constexpr int WL_W1 = 0, WL_B1 = 112, WL_SIZE = 128;   // floats
-constexpr int WL_ST = WL_SIZE, WL_CF = WL_ST + STATS_FLOATS, WL_END = WL_SIZE + 512;   // BN stats / BN2 backward coefficients
+constexpr int WL_ST = WL_SIZE, WL_CF = WL_ST + STATS_FLOATS, WL_END = WL_SIZE + 512;   // pass b2: BN stats / BN2 backward coefficients
+constexpr int W2_STAGE = 64 * 33;   // prologue only: W2 staged [64][33] in the (not yet used) per-wave area
 
-// per-wave LDS: tile | p1t | mk | slot vectors | slot ids.  Only pass b2 keeps the p1*mask rows; the others use 64 floats
-// of that region (row weights).  20.8 / 24.7 KB per wave: three 2-wave workgroups per CU.
+// per-wave LDS: tile | p1t (pass b2 only: the p1*mask rows) | mk | slot vectors | slot ids: 19.6 KB per wave (four 2-wave
+// workgroups per CU), 24.7 KB in pass b2.
 template <bool P1T>
-constexpr int wave_floats() { return 64 * TS + (P1T ? 64 * 16 : 64) + 64 + 8 * SV + 16; }
+constexpr int wave_floats() { return 64 * TS + (P1T ? 64 * 16 : 0) + 64 + 8 * sv_stride<P1T>() + 16; }
 
 struct WaveLds {
     float *tile;   // [64][65]
@@ -119,9 +124,10 @@ struct WaveLds {
 
 template <bool P1T>
 __device__ __forceinline__ WaveLds carve_lds(float *base, int wave) {
-    constexpr int NP = P1T ? 64 * 16 : 64;
+    constexpr int NP = P1T ? 64 * 16 : 0;
     float *p = base + (size_t)wave * wave_floats<P1T>();
-    return WaveLds{p, p + 64 * TS, p + 64 * TS + NP, p + 64 * TS + NP + 64, reinterpret_cast<int *>(p + 64 * TS + NP + 64 + 8 * SV)};
+    return WaveLds{p, p + 64 * TS, p + 64 * TS + NP, p + 64 * TS + NP + 64,
+                   reinterpret_cast<int *>(p + 64 * TS + NP + 64 + 8 * sv_stride<P1T>())};
 }
 
 // ---- items -----------------------------------------------------------------------------
@@ -176,42 +182,45 @@ __device__ __forceinline__ void layer1(const VfeParams &P, const float x[CIN], f
     }
 }
 
+// (W1 transposed in LDS as [i][16]: the 16 outputs are 16 independent chains, i outer, each still bias + i = 0..6 in order)
 __device__ __forceinline__ void layer1_lds(const float *__restrict__ wl, const float x[CIN], float h1[C1]) {
+    float a[C1];
 #pragma unroll
-    for (int o = 0; o < C1; ++o) {
-        float a = wl[WL_B1 + o];
+    for (int o = 0; o < C1; ++o) a[o] = wl[WL_B1 + o];
 #pragma unroll
-        for (int i = 0; i < CIN; ++i) a = fmaf(wl[WL_W1 + o * CIN + i], x[i], a);
-        h1[o] = fmaxf(a, 0.f);
-    }
+    for (int i = 0; i < CIN; ++i)
+#pragma unroll
+        for (int o = 0; o < C1; ++o) a[o] = fmaf(wl[WL_W1 + i * C1 + o], x[i], a[o]);
+#pragma unroll
+    for (int o = 0; o < C1; ++o) h1[o] = fmaxf(a[o], 0.f);
 }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // Per-lane operands of the second linear that stay in registers for the whole kernel:
-//   w2b[i]   = W2[lane][16 + i]                       (lane = output channel; the max-pooled half, applied per voxel)
+//   wu[c][s] = W2[16c + (lane & 15)][16 + 4s + (lane >> 4)]   the same for the max-pooled half, applied per voxel slot:
+//              u[slot][o] = sum_i agg1[slot][i] W2[o][16 + i], a (16 slots, G used) x 64 x 16 product = 16 MFMAs
 //   wm[c][s] = W2[16c + (lane & 15)][4s + (lane >> 4)] B operand of v_mfma_f32_16x16x4_f32 for the point-wise half:
 //              h2[row][o] = sum_i p1[row][i] W2[o][i] is a 64 x 64 x 16 product per wave item = 64 MFMAs of exact fp32
 //              (each accumulator is the fmaf chain over i = 0..15 of the scalar form, in the same order).  As fp32 FMAs
 //              with broadcast LDS weights the same product took ~4,500 of an item's ~5,500 instructions.
 //   b2r[c]   = b2[16c + (lane & 15)]
 struct FwdRegs {
-    float w2b[C1];
+    float wu[4][4];
     float wm[4][4];
     float b2r[4];
 };
 
-__device__ __forceinline__ void load_fwd_regs(const VfeParams &P, const float *wl, int lane, FwdRegs &F) {
-#pragma unroll
-    for (int i = 0; i < C1; i += 4) {
-        const float4 q = *reinterpret_cast<const float4 *>(P.w2 + lane * 32 + 16 + i);
-        F.w2b[i] = q.x; F.w2b[i + 1] = q.y; F.w2b[i + 2] = q.z; F.w2b[i + 3] = q.w;
-    }
+// (w2s: W2 staged as [64][33] by load_weights_lds — strided global loads of these operands cost 16 cache lines each)
+__device__ __forceinline__ void load_fwd_regs(const VfeParams &P, const float *w2s, int lane, FwdRegs &F) {
     const int fn = lane & 15, fq = lane >> 4;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) F.wm[c][s] = P.w2[(16 * c + fn) * 32 + 4 * s + fq];
+        for (int s = 0; s < 4; ++s) {
+            F.wm[c][s] = w2s[(16 * c + fn) * 33 + 4 * s + fq];
+            F.wu[c][s] = w2s[(16 * c + fn) * 33 + 16 + 4 * s + fq];
+        }
         F.b2r[c] = P.b2[16 * c + fn];
     }
 }
@@ -224,6 +233,7 @@ __device__ __forceinline__ void forward_to_h2(const float *__restrict__ wl, cons
                                               const float x[CIN], float m, const FwdRegs &F, float h1[C1],
                                               float p1[C1]) {
     constexpr int R = 64 / G;
+    constexpr int SV = sv_stride<WANT_P1T>(), V_U = sv_u<WANT_P1T>();   // (pass b2 is the one with WANT_P1T)
     VFE_TR(1);   // inputs loaded
     layer1_lds(wl, x, h1);
 #pragma unroll
@@ -252,16 +262,23 @@ __device__ __forceinline__ void forward_to_h2(const float *__restrict__ wl, cons
     __builtin_amdgcn_wave_barrier();
     VFE_TR(3);   // agg1
     // u[slot][o] = sum_i W2[o][16+i] * agg1[slot][i]   (lane = o)
-    {   // the G chains are independent: i outer, so that a wave alone on its SIMD has G FMAs in flight
-        float u[G];
+    {   // u[slot][o] on the matrix cores: A[m = slot][k = i] = agg1 (rows >= G: zero), D: lane holds slots 4fq + e, column 16c + fn
+        const int fn_ = lane & 15, fq_ = lane >> 4;
+        f32x4_t ua[4];
 #pragma unroll
-        for (int ts = 0; ts < G; ++ts) u[ts] = 0.f;
+        for (int c = 0; c < 4; ++c) ua[c] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < C1; ++i)
+        for (int k = 0; k < 4; ++k) {
+            const float au = fn_ < G ? L.sv[fn_ * SV + V_AGG1 + 4 * k + fq_] : 0.f;
 #pragma unroll
-            for (int ts = 0; ts < G; ++ts) u[ts] = fmaf(F.w2b[i], L.sv[ts * SV + V_AGG1 + i], u[ts]);
+            for (int c = 0; c < 4; ++c) ua[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(au, F.wu[c][k], ua[c], 0, 0, 0);
+        }
 #pragma unroll
-        for (int ts = 0; ts < G; ++ts) L.sv[ts * SV + V_U + lane] = u[ts];
+        for (int e = 0; e < 4; ++e)
+            if (4 * fq_ + e < G) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) L.sv[(4 * fq_ + e) * SV + V_U + 16 * c + fn_] = ua[c][e];
+            }
     }
     if (WANT_P1T) {
 #pragma unroll
@@ -334,9 +351,16 @@ __device__ __forceinline__ void lane_sums_to_slab(const float (&vals)[N], float 
     }
 }
 
-__device__ __forceinline__ void load_weights_lds(const VfeParams &P, float *wl) {
-    for (int idx = threadIdx.x; idx < C1 * CIN; idx += NT) wl[WL_W1 + idx] = P.w1[idx];
+// W1 / b1 -> wl (kept), W2 -> w2s as [64][33] (prologue only: the caller reads its register operands, then syncs again
+// before the per-wave areas that overlap w2s are used)
+__device__ __forceinline__ void load_weights_lds(const VfeParams &P, float *wl, float *w2s) {
+    for (int idx = threadIdx.x; idx < C1 * CIN; idx += NT) wl[WL_W1 + (idx % CIN) * C1 + idx / CIN] = P.w1[idx];   // [i][o]
     if (threadIdx.x < C1) wl[WL_B1 + threadIdx.x] = P.b1[threadIdx.x];
+    for (int idx = threadIdx.x; idx < C2 * 32 / 4; idx += NT) {
+        const float4 q = reinterpret_cast<const float4 *>(P.w2)[idx];
+        float *d = w2s + (idx >> 3) * 33 + (idx & 7) * 4;
+        d[0] = q.x; d[1] = q.y; d[2] = q.z; d[3] = q.w;
+    }
     __syncthreads();
 }
 
@@ -494,10 +518,10 @@ __device__ __forceinline__ void p2_item(const float *__restrict__ feature, int T
     float x[CIN], m, h1[C1], p1[C1];
     load_row(feature, v, T, j, j < r, x, m);
     forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, F, h1, p1);
-    L.p1t[lane] = wgt;                          // row weights (p1t is free in this pass)
+    L.mk[lane] = wgt;                           // row weights (the masks went into h2)
     __builtin_amdgcn_wave_barrier();
     for (int t = 0; t < 64; ++t) {              // lane = channel; idle rows weigh 0 and hold finite values
-        const float h = L.tile[t * TS + lane], wh = L.p1t[t] * h;
+        const float h = L.tile[t * TS + lane], wh = L.mk[t] * h;
         s1 += wh;
         s2 = fmaf(wh, h, s2);
     }
@@ -510,11 +534,12 @@ __global__ void __launch_bounds__(NT) k_vfe_p2(const float *__restrict__ feature
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(2)
     float *wl = smem;
-    load_weights_lds(P, wl);
-    const WaveLds L = carve_lds<false>(smem + WL_END, wave);
+    load_weights_lds(P, wl, smem + WL_SIZE);
+    const WaveLds L = carve_lds<false>(smem + WL_SIZE, wave);
     const Items it = load_items(wk);
     FwdRegs F;
-    load_fwd_regs(P, wl, lane, F);
+    load_fwd_regs(P, smem + WL_SIZE, lane, F);
+    __syncthreads();   // the staged W2 is overwritten by the per-wave areas from here on
     float s1 = 0.f, s2 = 0.f;
 #define BODY_P2(G, first, n, item) p2_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, F, s1, s2);
     VFE_FOR_ITEMS(it, BODY_P2)
@@ -563,11 +588,12 @@ __global__ void __launch_bounds__(NT) k_vfe_p3(const float *__restrict__ feature
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(3)
     float *wl = smem;
-    load_weights_lds(P, wl);
-    const WaveLds L = carve_lds<false>(smem + WL_END, wave);
+    load_weights_lds(P, wl, smem + WL_SIZE);
+    const WaveLds L = carve_lds<false>(smem + WL_SIZE, wave);
     const Items it = load_items(wk);
     FwdRegs F;
-    load_fwd_regs(P, wl, lane, F);
+    load_fwd_regs(P, smem + WL_SIZE, lane, F);
+    __syncthreads();   // the staged W2 is overwritten by the per-wave areas from here on
     const float mean2 = stats[ST2 + lane], S2 = stats[ST2 + 2 * C2 + lane], be2 = stats[ST2 + 3 * C2 + lane];
 #define BODY_P3(G, first, n, item) p3_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, F, mean2, S2, be2, voxelwise);
     VFE_FOR_ITEMS(it, BODY_P3)
@@ -637,54 +663,58 @@ template <int R>
 __device__ __forceinline__ void impulses(const WaveLds &L, int row0, int tr, int lane, float mean2, float S2, float be2,
                                          float dlo, float dhi, int &r1, float &g1, int &r2, float &g2, float &xh1,
                                          float &xh2, float inv2) {
+    // branch-free for R <= 16 (an empty slot has tr = 0 and d = 0: every update is predicated off), so that the G slots
+    // of an item are G independent instruction streams the scheduler can interleave; the mask of each argmax row is
+    // carried along instead of being re-read from LDS
     float agg = -INFINITY, vlo = -INFINITY;
     r1 = 0; r2 = 0;
-    float h_r1 = 0.f, h_r2 = 0.f;
+    float h_r1 = 0.f, h_r2 = 0.f, mk_r1 = 0.f;
 #pragma unroll
     for (int t0 = 0; t0 < R; t0 += 8) {
-        if (R > 8 && t0 >= tr) break;
-        float h[8], mk[8];
+        if (R > 16 && t0 >= tr) break;
+        float h[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { h[u] = L.tile[(row0 + t0 + u) * TS + lane]; mk[u] = L.mk[row0 + t0 + u]; }
+        for (int u = 0; u < 8; ++u) h[u] = L.tile[(row0 + t0 + u) * TS + lane];
+        const f32x4_t ma = *reinterpret_cast<const f32x4_t *>(L.mk + row0 + t0), mb = *reinterpret_cast<const f32x4_t *>(L.mk + row0 + t0 + 4);
+        const float mk[8] = {ma[0], ma[1], ma[2], ma[3], mb[0], mb[1], mb[2], mb[3]};
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int t = t0 + u;
             const float p = fmaf(S2, h[u] - mean2, be2);
             const float pm = p * mk[u];
-            if (t < tr && p > agg) { agg = p; r2 = t; h_r2 = h[u]; }
-            if (t < tr && pm > vlo) { vlo = pm; r1 = t; h_r1 = h[u]; }
+            const bool c2 = t < tr && p > agg, c1 = t < tr && pm > vlo;
+            agg = c2 ? p : agg; r2 = c2 ? t : r2; h_r2 = c2 ? h[u] : h_r2;
+            vlo = c1 ? pm : vlo; r1 = c1 ? t : r1; h_r1 = c1 ? h[u] : h_r1; mk_r1 = c1 ? mk[u] : mk_r1;
         }
     }
     // a' = first t maximising agg*m[t]
-    int ap = 0;
-    float best = -INFINITY;
+    float best = -INFINITY, mk_ap = 0.f;
 #pragma unroll
     for (int t0 = 0; t0 < R; t0 += 8) {
-        if (R > 8 && t0 >= tr) break;
-        float mk[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mk[u] = L.mk[row0 + t0 + u];
+        if (R > 16 && t0 >= tr) break;
+        const f32x4_t ma = *reinterpret_cast<const f32x4_t *>(L.mk + row0 + t0), mb = *reinterpret_cast<const f32x4_t *>(L.mk + row0 + t0 + 4);
+        const float mk[8] = {ma[0], ma[1], ma[2], ma[3], mb[0], mb[1], mb[2], mb[3]};
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const float q = agg * mk[u];
-            if (t0 + u < tr && q > best) { best = q; ap = t0 + u; }
+            const bool c = t0 + u < tr && q > best;
+            best = c ? q : best; mk_ap = c ? mk[u] : mk_ap;
         }
     }
-    g1 = dlo * L.mk[row0 + r1];
-    g2 = dhi * L.mk[row0 + ap];
+    g1 = dlo * mk_r1;
+    g2 = dhi * mk_ap;
     xh1 = (h_r1 - mean2) * inv2;
     xh2 = (h_r2 - mean2) * inv2;
 }
 
-// d_voxelwise of the G voxels of an item for this channel lane, requested at the START of the item (the voxel ids come
-// straight from the work list) so that the loads are in flight during the forward recomputation
+// d_voxelwise of the G voxels of an item for this channel lane, requested at the START of the item (slot ts's voxel id is
+// the one its first row lane holds) so that the loads are in flight during the forward recomputation
 template <int G>
-__device__ __forceinline__ void load_dvw(const WorkList &wk, int first, int n, int item, int lane,
-                                         const float *__restrict__ dvw, float dlo[G], float dhi[G]) {
+__device__ __forceinline__ void load_dvw(int v, int lane, const float *__restrict__ dvw, float dlo[G], float dhi[G]) {
+    constexpr int R = 64 / G;
 #pragma unroll
     for (int ts = 0; ts < G; ++ts) {
-        const int idx = item * G + ts;
-        const int tv = idx < n ? wk.list[first + idx] : -1;
+        const int tv = __builtin_amdgcn_readlane(v, ts * R);
         dlo[ts] = tv >= 0 ? dvw[(int64_t)tv * 128 + lane] : 0.f;
         dhi[ts] = tv >= 0 ? dvw[(int64_t)tv * 128 + 64 + lane] : 0.f;
     }
@@ -700,13 +730,12 @@ __device__ __forceinline__ void b1_item(const float *__restrict__ feature, int T
     int v, r, s, j; float wgt;
     item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
     float x[CIN], m, h1[C1], p1[C1], dlo[G], dhi[G];
-    load_dvw<G>(wk, first, n, item, lane, dvw, dlo, dhi);
+    load_dvw<G>(v, lane, dvw, dlo, dhi);
     load_row(feature, v, T, j, j < r, x, m);
     forward_to_h2<G, false, false>(wl, stats, L, lane, v, r, s, j, x, m, F, h1, p1);
 #pragma unroll
     for (int ts = 0; ts < G; ++ts) {
-        const int tv = uni(L.sid[ts]), tr = uni(L.sid[8 + ts]);
-        if (tv < 0) continue;
+        const int tr = uni(L.sid[8 + ts]);   // 0 for an empty slot: g1 = g2 = 0
         int r1, r2; float g1, g2, xh1, xh2;
         impulses<R>(L, ts * R, tr, lane, mean2, S2, be2, dlo[ts], dhi[ts], r1, g1, r2, g2, xh1, xh2, inv2);
         s1 += g1 + g2;
@@ -722,11 +751,12 @@ __global__ void __launch_bounds__(NT) k_vfe_b1(const float *__restrict__ feature
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(11)
     float *wl = smem;
-    load_weights_lds(P, wl);
-    const WaveLds L = carve_lds<false>(smem + WL_END, wave);
+    load_weights_lds(P, wl, smem + WL_SIZE);
+    const WaveLds L = carve_lds<false>(smem + WL_SIZE, wave);
     const Items it = load_items(wk);
     FwdRegs F;
-    load_fwd_regs(P, wl, lane, F);
+    load_fwd_regs(P, smem + WL_SIZE, lane, F);
+    __syncthreads();   // the staged W2 is overwritten by the per-wave areas from here on
     const float mean2 = stats[ST2 + lane], inv2 = stats[ST2 + C2 + lane], S2 = stats[ST2 + 2 * C2 + lane],
                 be2 = stats[ST2 + 3 * C2 + lane];
     float s1 = 0.f, s2 = 0.f;
@@ -780,39 +810,37 @@ __device__ __forceinline__ void b2_item(const float *__restrict__ feature, int T
     item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
     const bool active = j < r;
     float x[CIN], m, h1[C1], p1[C1], dlo[G], dhi[G];
-    load_dvw<G>(wk, first, n, item, lane, dvw, dlo, dhi);
+    load_dvw<G>(v, lane, dvw, dlo, dhi);
     load_row(feature, v, T, j, active, x, m);
     forward_to_h2<G, true, true>(wl, stats, L, lane, v, r, s, j, x, m, F, h1, p1);
     // lane = channel o, per voxel: d_pre2[t][o] = (h2>0) * (c0*d_p2 + w_t*(c1*(h2-mean) + c2)) written over h2 in the
     // tile, with db2 and s[o] = sum_t m_t d_pre2 on the way
 #pragma unroll
     for (int ts = 0; ts < G; ++ts) {
-        const int tv = uni(L.sid[ts]), tr = uni(L.sid[8 + ts]);
-        if (tv < 0) {
-            L.sv[ts * SV + V_S + lane] = 0.f;
-            continue;
-        }
+        const int tr = uni(L.sid[8 + ts]);   // 0 for an empty slot: nothing is written, s = 0
         int r1, r2; float g1, g2, xh1, xh2;
         impulses<R>(L, ts * R, tr, lane, mean2, S2, be2, dlo[ts], dhi[ts], r1, g1, r2, g2, xh1, xh2, inv2);
         float sm = 0.f;
+        const float wlast = (float)(T - tr + 1);
 #pragma unroll
         for (int t0 = 0; t0 < R; t0 += 8) {
-            if (R > 8 && t0 >= tr) break;
-            float hh[8], mk[8];
+            if (R > 16 && t0 >= tr) break;
+            float hh[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { hh[u] = L.tile[(ts * R + t0 + u) * TS + lane]; mk[u] = L.mk[ts * R + t0 + u]; }
+            for (int u = 0; u < 8; ++u) hh[u] = L.tile[(ts * R + t0 + u) * TS + lane];
+            const f32x4_t ma = *reinterpret_cast<const f32x4_t *>(L.mk + ts * R + t0), mb = *reinterpret_cast<const f32x4_t *>(L.mk + ts * R + t0 + 4);
+            const float mk[8] = {ma[0], ma[1], ma[2], ma[3], mb[0], mb[1], mb[2], mb[3]};
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int t = t0 + u, row = ts * R + t;
-                if (t >= tr) continue;
                 const float h = hh[u];
                 float dp = 0.f;
                 if (t == r1) dp += g1;
                 if (t == r2) dp += g2;
-                const float wt = t == tr - 1 ? (float)(T - tr + 1) : 1.f;
+                const float wt = t == tr - 1 ? wlast : 1.f;
                 const float dh = fmaf(c0, dp, wt * fmaf(c1, h - mean2, c2));
-                const float d = h > 0.f ? dh : 0.f;
-                L.tile[row * TS + lane] = d;
+                const float d = (t < tr && h > 0.f) ? dh : 0.f;
+                if (t < tr) L.tile[row * TS + lane] = d;   // (rows >= tr keep their finite h2: they meet p1m = 0 below)
                 A.db2 += d;
                 sm = fmaf(mk[u], d, sm);
             }
@@ -907,7 +935,7 @@ __global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(12)
     float *wl = smem;
-    load_weights_lds(P, wl);
+    load_weights_lds(P, wl, smem + WL_END);
     // this kernel also keeps the BN statistics and the BN2 backward coefficients in LDS (512 more uniform floats)
     float *st_l = smem + WL_ST, *cf_l = smem + WL_CF;
     for (int i = threadIdx.x; i < STATS_FLOATS; i += NT) st_l[i] = stats_g[i];
@@ -917,7 +945,7 @@ __global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature
     const WaveLds L = carve_lds<true>(smem + WL_END, wave);
     const Items it = load_items(wk);
     FwdRegs F;
-    load_fwd_regs(P, wl, lane, F);
+    load_fwd_regs(P, smem + WL_END, lane, F);
     const float mean2 = stats[ST2 + lane], inv2 = stats[ST2 + C2 + lane], S2 = stats[ST2 + 2 * C2 + lane],
                 be2 = stats[ST2 + 3 * C2 + lane];
     const float c0 = coef2[lane], c1 = coef2[C2 + lane], c2 = coef2[2 * C2 + lane];
@@ -926,9 +954,10 @@ __global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature
 #pragma unroll
     for (int i = 0; i < C1; ++i) {
         A.dw2b[i] = 0.f; A.bn1[i] = 0.f; A.bn1[C1 + i] = 0.f;
-        A.wd[i] = P.w2[(4 * i + (lane >> 4)) * 32 + (lane & 15)];
-        A.wb[i] = P.w2[(4 * i + (lane >> 4)) * 32 + 16 + (lane & 15)];
+        A.wd[i] = smem[WL_END + (4 * i + (lane >> 4)) * 33 + (lane & 15)];
+        A.wb[i] = smem[WL_END + (4 * i + (lane >> 4)) * 33 + 16 + (lane & 15)];
     }
+    __syncthreads();   // the staged W2 is overwritten by the per-wave areas from here on
 #pragma unroll
     for (int b = 0; b < 4; ++b) A.dw2m[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #define BODY_B2(G, first, n, item) \
@@ -1041,7 +1070,7 @@ __global__ void __launch_bounds__(256) k_vfe_reduce_multi(const ReduceJobs J, in
 }
 
 struct Plan {
-    int blocks, blocks_b2;   // pass b2 needs > 256 VGPRs: one wave per SIMD, two workgroups per CU
+    int blocks, blocks_b2;   // pass b2 needs > 256 VGPRs: one wave per SIMD, 512 resident workgroups
     size_t lds_small, lds_full, lds_b2;
     size_t off_slabs, off_slabs3, off_coef, off_rows, off_list, off_counts, off_dp1, bytes;
 };
@@ -1054,7 +1083,8 @@ Plan make_plan(int64_t K, int T) {
     p.blocks = (int)b;
     p.blocks_b2 = b > 512 ? 512 : (int)b;
     p.lds_small = (size_t)NW * 32 * TS * sizeof(float);                                     // lane_sums_to_slab only
-    p.lds_full = (size_t)(WL_END + NW * wave_floats<false>()) * sizeof(float);
+    p.lds_full = (size_t)(WL_SIZE + NW * wave_floats<false>()) * sizeof(float);
+    static_assert(W2_STAGE <= NW * wave_floats<false>(), "the W2 staging area must fit the per-wave areas");
     size_t full = (size_t)(WL_END + NW * wave_floats<true>()) * sizeof(float);
     const size_t red = (size_t)NW * 32 * 64 * sizeof(float);   // slab combine area of pass b2
     if (full < red) full = red;
