@@ -358,8 +358,9 @@ typedef struct {
     int32_t mode;            /* 0 bf16, 1 fp32 */
     int32_t training;        /* BatchNorm: batch statistics + running-stat update, or running statistics */
     int32_t sparse_first;
-    int32_t prepared;        /* forward: vn_net_prepare has already been issued for this step (weights packed, first layer's
-                              * site list / index grid / bias fill done) and the caller has ordered it before this call */
+    int32_t prepared;        /* forward: vn_net_prepare has already been issued for this step on the same vnNet (weights packed,
+                              * first layer's site list / index grid / bias fill); vn_net_forward orders itself behind it
+                              * (two events: the first layer's needs, then the rest of the packing) */
     int32_t bucket_events;   /* single-call backward with a side stream: unpack each parameter group's weight gradients on the
                               * side stream at the group's end and record "group final" events (vn_net_wait_bucket);
                               * implies that the caller joins the side stream (as defer_join) */
@@ -412,7 +413,9 @@ int vn_net_timing_read(vnNet *net, vnTimingRecord *out, int32_t cap, int32_t *co
 int vn_net_wait_bucket(vnNet *net, int32_t bucket, vnStream stream);
 /* The part of the forward that does not depend on the voxel features (weight packing; sparse first layer: active
  * sites, voxel index grid, bias fill): may be issued on another stream while the VFE forward runs; then set
- * cfg->prepared for vn_net_forward and make its stream wait for this one. */
+ * cfg->prepared for vn_net_forward.  The forward's stream need not wait for this one: vn_net_prepare records, on the
+ * vnNet, one event behind what the first layer needs (issued first) and one behind the rest of the weight packing, and
+ * vn_net_forward waits for the first at its start and for the second in front of the second layer. */
 int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
                    const int64_t *coord, int64_t K, void *workspace, size_t workspace_bytes, vnStream stream);
 int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,

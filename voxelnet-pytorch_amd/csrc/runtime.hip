@@ -393,6 +393,11 @@ struct vnTimeSlot {
 };
 struct vnNet {
     hipEvent_t bucket_ev[4][2];
+    // vn_net_prepare on a stream of its own records [0] behind what the FIRST layer needs (its packed weights, the site
+    // list, the index grid) and [1] behind the rest of the weight packing; vn_net_forward (cfg->prepared) waits for [0]
+    // at its start and for [1] in front of the second layer, so the ~65 us of packing are off the start of the step
+    hipEvent_t prep_ev[2];
+    bool prep_recorded;
     hipEvent_t ring[64];
     unsigned next;
     hipEvent_t next_event() { return ring[next++ & 63]; }
@@ -424,6 +429,7 @@ extern "C" int vn_net_create(vnNet **out) {
     for (int b = 0; b < 4 && err == hipSuccess; ++b)
         for (int w = 0; w < 2 && err == hipSuccess; ++w) err = hipEventCreateWithFlags(&n->bucket_ev[b][w], hipEventDisableTiming);
     for (int i = 0; i < 64 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&n->ring[i], hipEventDisableTiming);
+    for (int i = 0; i < 2 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&n->prep_ev[i], hipEventDisableTiming);
     if (err != hipSuccess) {
         vn_net_destroy(n);
         return (int)err;
@@ -439,6 +445,8 @@ extern "C" int vn_net_destroy(vnNet *n) {
             if (n->bucket_ev[b][w]) (void)hipEventDestroy(n->bucket_ev[b][w]);
     for (int i = 0; i < 64; ++i)
         if (n->ring[i]) (void)hipEventDestroy(n->ring[i]);
+    for (int i = 0; i < 2; ++i)
+        if (n->prep_ev[i]) (void)hipEventDestroy(n->prep_ev[i]);
     for (int i = 0; i < n->t_made; ++i) {
         (void)hipEventDestroy(n->slots[i].e0);
         (void)hipEventDestroy(n->slots[i].e1);
@@ -540,15 +548,43 @@ extern "C" size_t vn_net_workspace_bytes(const vnNetConfig *cfg, int64_t K) {
 // output.  vn_net_forward does it itself unless cfg->prepared says vn_net_prepare already did (on another stream,
 // beside the VFE forward).
 static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const vnLayerParams *L, const float *heads_w,
-                       const int64_t *coord, int64_t K, vnStream stream) {
+                       const int64_t *coord, int64_t K, vnStream stream, bool own_stream) {
     const int training = cfg->training;
+    // own_stream (vn_net_prepare): the first layer's forward weights are packed by a launch of their own, in front of the
+    // site list; everything else is packed behind it (see vnNet::prep_ev)
+    auto first_needs = [&]() -> int {
+        if (cfg->sparse_first) {
+            const Spec &sp = P.spec[0];
+            const Rows &y = P.y[0];
+            const Rows xin = dense_rows(nullptr, P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
+            vnConv g = fwd_geom(sp, xin, P.odims[0], y);
+            // y holds the conv bias at the ~90 % of sites no occupied voxel reaches.  When every consumer of y walks the flags /
+            // the active-site list (flagged forward apply; list-based BatchNorm backward: P.list_bwd), those rows are never
+            // read and the 180 MB fill is skipped (round 3)
+            const bool y_dense_readers = !(training ? (P.list_bwd && (m0_bn_knob() & 1)) : (m0_bn_knob() & 1));
+            if (y_dense_readers)
+                RTT(T_FIRST, 0, 0.0, rows_bytes(y), stream, vn_fill_rows(y.ptr, (vnDtype)y.dtype, y.M(), sp.cout, sp.cout, L[0].bias, stream));
+            RTT(T_FIRST, 0, 0.0, 0.0, stream, vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
+            RTT(T_FIRST, 0, 0.0, 4.0 * cfg->B * cfg->D * cfg->H * cfg->W, stream,
+                vn_voxel_index_grid(coord, K, cfg->B, cfg->D, cfg->H, cfg->W, P.igrid, stream));
+        }
+        return VN_OK;
+    };
+    if (own_stream) {
+        const Spec &sp = P.spec[0];
+        vnPackJob j0{L[0].weight, P.wp_f[0], sp.cout, sp.cin, sp.k[0] * sp.k[1] * sp.k[2], sp.transposed ? 2 : 0, 0, sp.cin_fold, P.adt, 0};
+        RTT(T_PACK, 0, 0.0, (double)j0.c_out * j0.c_in * j0.taps * (4 + P.esz), stream, vn_pack_weights_batch(&j0, 1, stream));
+        RT(first_needs());
+        VN_HIP(hipEventRecord(net->prep_ev[0], vn_stream(stream)));
+    }
     {   // every layer's weights -> MFMA operand layout, forward and (training) data-gradient orientation: one launch
         vnPackJob jobs[2 * NL + 2];
         int nj = 0;
         for (int l = 0; l < NL; ++l) {
             const Spec &sp = P.spec[l];
             const int taps = sp.k[0] * sp.k[1] * sp.k[2];
-            jobs[nj++] = vnPackJob{L[l].weight, P.wp_f[l], sp.cout, sp.cin, taps, sp.transposed ? 2 : 0, 0, sp.cin_fold, P.adt, 0};
+            if (!(own_stream && l == 0))
+                jobs[nj++] = vnPackJob{L[l].weight, P.wp_f[l], sp.cout, sp.cin, taps, sp.transposed ? 2 : 0, 0, sp.cin_fold, P.adt, 0};
             if (training) {
                 const bool first_sparse = l == 0 && cfg->sparse_first;
                 jobs[nj++] = vnPackJob{L[l].weight, P.wp_d[l], sp.cout, sp.cin, taps, sp.transposed ? 3 : 1, 0,
@@ -561,20 +597,11 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
         for (int j = 0; j < nj; ++j) pbytes += (double)jobs[j].c_out * jobs[j].c_in * jobs[j].taps * (4 + P.esz);
         RTT(T_PACK, -1, 0.0, pbytes, stream, vn_pack_weights_batch(jobs, nj, stream));
     }
-    if (cfg->sparse_first) {
-        const Spec &sp = P.spec[0];
-        const Rows &y = P.y[0];
-        const Rows xin = dense_rows(nullptr, P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
-        vnConv g = fwd_geom(sp, xin, P.odims[0], y);
-        // y holds the conv bias at the ~90 % of sites no occupied voxel reaches.  When every consumer of y walks the flags /
-        // the active-site list (flagged forward apply; list-based BatchNorm backward: P.list_bwd), those rows are never
-        // read and the 180 MB fill is skipped (round 3)
-        const bool y_dense_readers = !(training ? (P.list_bwd && (m0_bn_knob() & 1)) : (m0_bn_knob() & 1));
-        if (y_dense_readers)
-            RTT(T_FIRST, 0, 0.0, rows_bytes(y), stream, vn_fill_rows(y.ptr, (vnDtype)y.dtype, y.M(), sp.cout, sp.cout, L[0].bias, stream));
-        RTT(T_FIRST, 0, 0.0, 0.0, stream, vn_active_sites(coord, K, &g, P.aws, P.aws_bytes, P.alist, P.acap, P.acount, stream));
-        RTT(T_FIRST, 0, 0.0, 4.0 * cfg->B * cfg->D * cfg->H * cfg->W, stream,
-            vn_voxel_index_grid(coord, K, cfg->B, cfg->D, cfg->H, cfg->W, P.igrid, stream));
+    if (own_stream) {
+        VN_HIP(hipEventRecord(net->prep_ev[1], vn_stream(stream)));
+        net->prep_recorded = true;
+    } else {
+        RT(first_needs());
     }
     return VN_OK;
 }
@@ -585,7 +612,7 @@ extern "C" int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerP
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
     if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
-    return net_prepare(net, cfg, P, L, heads_w, coord, K, stream);
+    return net_prepare(net, cfg, P, L, heads_w, coord, K, stream, true);
 }
 
 extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w,
@@ -602,7 +629,9 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
     const float mom = 0.1f, eps = 1e-5f;
     const int relu_fl = P.round_act ? 3 : 1;    // (bit 1: the activation is rounded to the nearest bf16 value — diagnostic)
     // (no memset: every statistics buffer of the forward is a per-workgroup slab written with plain stores)
-    if (!cfg->prepared) RT(net_prepare(net, cfg, P, L, heads_w, coord, K, stream));
+    if (!cfg->prepared) RT(net_prepare(net, cfg, P, L, heads_w, coord, K, stream, false));
+    const bool prep_wait = cfg->prepared && net->prep_recorded;   // (a caller that joined the prepare stream itself loses nothing)
+    if (prep_wait) VN_HIP(hipStreamWaitEvent(hs, net->prep_ev[0], 0));
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
     Rows x1{}, x2{};
     // deconv1 / deconv2 only feed the concat: with a side stream they run beside block2 / block3 (whose 100x88 and
@@ -618,6 +647,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
             VN_HIP(hipEventRecord(e, hs));
             VN_HIP(hipStreamWaitEvent(ss, e, 0));
         }
+        if (l == 1 && prep_wait) VN_HIP(hipStreamWaitEvent(hs, net->prep_ev[1], 0));   // the other layers' packed weights
         const vnStream stream = on_side ? side_stream : main_stream;   // (shadows the parameter inside the loop body)
         if (l == L_D1) x = x1;                 // deconv1 and block2 both read the block1 output
         if (l == L_B2) x = x1;

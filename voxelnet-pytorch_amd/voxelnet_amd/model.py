@@ -15,6 +15,7 @@ never called — every forward/backward goes through the C ABI via the
 torch.autograd.Functions below.  There is no CPU path: CPU tensors raise.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -624,7 +625,9 @@ class _DetectorFn(torch.autograd.Function):
                     vw_rows = torch.empty((vw.shape[0], 128), dtype=torch.bfloat16, device=vw.device)
                     _lib.call("vn_cast_rows", vw.data_ptr(), _lib.VN_F32, 128, vw.shape[0], 128, vw_rows.data_ptr(),
                               _lib.VN_BF16, 128, 0, E.stream())
-                if side is not None:
+                # (no join of the side stream here: vn_net_forward waits for vn_net_prepare's two events itself — the first
+                # layer's needs at its start, the rest of the weight packing in front of the second layer)
+                if side is not None and os.environ.get("VN_PREP_JOIN") == "1":     # A/B aid: the round-2 full join
                     torch.cuda.current_stream().wait_stream(side_t)
                 hf, wf = H // mid._block1_stride, W // mid._block1_stride
                 prob = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=vw.device)
