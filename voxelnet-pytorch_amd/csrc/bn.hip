@@ -151,36 +151,48 @@ __global__ void __launch_bounds__(256) k_bn_finalize_slab(const float *__restric
                                                           const float *__restrict__ beta, float *running_mean,
                                                           float *running_var, float momentum, float eps,
                                                           float *__restrict__ stats) {
-    __shared__ double r1[256], r2[256];
+    // This launch sits on the dependency chain 46 times per step and is pure latency: the per-channel parameters are
+    // requested before the slab loop (not after the reduction: one memory round trip less), and the 256 partial sums
+    // meet through wave shuffles + one barrier (fixed order: deterministic) instead of an 8-barrier LDS tree.
+    __shared__ double r1[4], r2[4];
     const int c = blockIdx.x;
+    float p_shift = 0.f, p_gamma = 0.f, p_beta = 0.f, p_rm = 0.f, p_rv = 0.f;
+    if (threadIdx.x == 0) {
+        p_shift = shift ? shift[c] : 0.f;
+        p_gamma = gamma[c];
+        p_beta = beta[c];
+        if (running_mean) p_rm = running_mean[c];
+        if (running_var) p_rv = running_var[c];
+    }
     double s1 = 0.0, s2 = 0.0;
     for (int64_t r = threadIdx.x; r < rows; r += 256) {
         s1 += (double)slab[(r * 2 + 0) * C + c];
         s2 += (double)slab[(r * 2 + 1) * C + c];
     }
-    r1[threadIdx.x] = s1;
-    r2[threadIdx.x] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
     }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        const double t1 = (r1[0] + r1[1]) + (r1[2] + r1[3]), t2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
         const double n = (double)M;
-        const double ms = r1[0] / n;
-        double var = r2[0] / n - ms * ms;
+        const double ms = t1 / n;
+        double var = t2 / n - ms * ms;
         if (var < 0.0) var = 0.0;
-        const double mean = ms + (shift ? (double)shift[c] : 0.0);
-        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        const double mean = ms + (double)p_shift;
+        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * p_rm + momentum * mean);
         if (running_var) {
             const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            running_var[c] = (float)((1.0 - momentum) * p_rv + momentum * unb);
         }
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         stats[c] = (float)mean;
         stats[C + c] = invstd;
-        stats[2 * C + c] = gamma[c] * invstd;
-        stats[3 * C + c] = beta[c];
+        stats[2 * C + c] = p_gamma * invstd;
+        stats[3 * C + c] = p_beta;
     }
 }
 
@@ -335,29 +347,31 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize_slab(const float *__res
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ stats, float *__restrict__ coef,
                                                               float *__restrict__ d_gamma, float *__restrict__ d_beta) {
-    __shared__ double r1[256], r2[256];
+    __shared__ double r1[4], r2[4];   // (same shape as k_bn_finalize_slab: parameters first, shuffles + one barrier)
     const int c = blockIdx.x;
+    float invstd = 0.f, p_gamma = 0.f;
+    if (threadIdx.x == 0) { invstd = stats[C + c]; p_gamma = gamma[c]; }
     double s1 = 0.0, s2 = 0.0;
     for (int r = threadIdx.x; r < rows; r += 256) {
         s1 += (double)slab[((size_t)r * 2 + 0) * C + c];
         s2 += (double)slab[((size_t)r * 2 + 1) * C + c];
     }
-    r1[threadIdx.x] = s1;
-    r2[threadIdx.x] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
     }
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        const double t1 = (r1[0] + r1[1]) + (r1[2] + r1[3]), t2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
         const double n = (double)M;
-        const float invstd = stats[C + c];
-        const float S = gamma[c] * invstd;
-        if (d_gamma) d_gamma[c] = (float)r2[0];
-        if (d_beta) d_beta[c] = (float)r1[0];
+        const float S = p_gamma * invstd;
+        if (d_gamma) d_gamma[c] = (float)t2;
+        if (d_beta) d_beta[c] = (float)t1;
         coef[c] = S;
-        coef[C + c] = -S * invstd * (float)(r2[0] / n);
-        coef[2 * C + c] = -S * (float)(r1[0] / n);
+        coef[C + c] = -S * invstd * (float)(t2 / n);
+        coef[2 * C + c] = -S * (float)(t1 / n);
     }
 }
 

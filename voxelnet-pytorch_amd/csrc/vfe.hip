@@ -603,21 +603,21 @@ __global__ void __launch_bounds__(NT) k_vfe_p3(const float *__restrict__ feature
 // block-wide sum of slab columns: pair (c, C + c) of every slab, in double (fixed order -> deterministic)
 __device__ __forceinline__ void slab_pair_sum(const float *__restrict__ slabs, int nslabs, int stride, int off, int C,
                                               int c, double &o1, double &o2) {
-    __shared__ double r1[256], r2[256];
+    __shared__ double r1[4], r2[4];   // wave shuffles + one barrier (these launches are pure latency on the chain)
     double s1 = 0.0, s2 = 0.0;
     for (int b = threadIdx.x; b < nslabs; b += 256) {
         s1 += slabs[(size_t)b * stride + off + c];
         s2 += slabs[(size_t)b * stride + off + C + c];
     }
-    r1[threadIdx.x] = s1;
-    r2[threadIdx.x] = s2;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if (threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
-        __syncthreads();
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o, 64);
+        s2 += __shfl_xor(s2, o, 64);
     }
-    o1 = r1[0];
-    o2 = r2[0];
+    if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s1; r2[threadIdx.x >> 6] = s2; }
+    __syncthreads();
+    o1 = (r1[0] + r1[1]) + (r1[2] + r1[3]);
+    o2 = (r2[0] + r2[1]) + (r2[2] + r2[3]);
 }
 
 // slabs -> stats (train) or running stats -> stats (eval); one workgroup per channel
@@ -628,6 +628,8 @@ __global__ void __launch_bounds__(256) k_vfe_finalize(const float *__restrict__ 
                                                       float momentum, float eps, float *__restrict__ st) {
     const int c = blockIdx.x;
     double mean, var;
+    float p_gamma = 0.f, p_beta = 0.f, p_rm = 0.f, p_rv = 0.f;   // requested before the slab loop, not behind the reduction
+    if (threadIdx.x == 0) { p_gamma = gamma[c]; p_beta = beta[c]; p_rm = running_mean[c]; p_rv = running_var[c]; }
     if (training) {
         double s1, s2;
         slab_pair_sum(slabs, nslabs, slab_stride, 0, C, c, s1, s2);
@@ -636,20 +638,20 @@ __global__ void __launch_bounds__(256) k_vfe_finalize(const float *__restrict__ 
         var = s2 / n - mean * mean;
         if (var < 0.0) var = 0.0;
         if (threadIdx.x == 0) {
-            running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+            running_mean[c] = (float)((1.0 - momentum) * p_rm + momentum * mean);
             const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unb);
+            running_var[c] = (float)((1.0 - momentum) * p_rv + momentum * unb);
         }
     } else {
-        mean = running_mean[c];
-        var = running_var[c];
+        mean = p_rm;
+        var = p_rv;
     }
     if (threadIdx.x == 0) {
         const float invstd = (float)(1.0 / sqrt(var + (double)eps));
         st[c] = (float)mean;
         st[C + c] = invstd;
-        st[2 * C + c] = gamma[c] * invstd;
-        st[3 * C + c] = beta[c];
+        st[2 * C + c] = p_gamma * invstd;
+        st[3 * C + c] = p_beta;
     }
 }
 
