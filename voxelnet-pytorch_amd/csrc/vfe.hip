@@ -1048,19 +1048,22 @@ __global__ void __launch_bounds__(256) k_vfe_reduce(const float *__restrict__ sl
 struct ReduceJobs {
     const float *slabs[4];
     float *out[4];
-    int stride[4], off[4], n[4], first[5];
+    int stride[4], off[4], n[4], first[5], nslabs[4];
 };
-__global__ void __launch_bounds__(256) k_vfe_reduce_multi(const ReduceJobs J, int nslabs) {
+__global__ void __launch_bounds__(256) k_vfe_reduce_multi(const ReduceJobs J) {
     int j = 0;
 #pragma unroll
     for (int q = 1; q < 4; ++q)
         if ((int)blockIdx.x >= J.first[q]) j = q;
     const float *slabs = J.slabs[0];
     float *out = J.out[0];
-    int stride = J.stride[0], off = J.off[0], n = J.n[0], first = J.first[0];
+    int stride = J.stride[0], off = J.off[0], n = J.n[0], first = J.first[0], nslabs = J.nslabs[0];
 #pragma unroll
     for (int q = 1; q < 4; ++q)          // (static indices: no dynamic index into the by-value parameter struct)
-        if (j == q) { slabs = J.slabs[q]; out = J.out[q]; stride = J.stride[q]; off = J.off[q]; n = J.n[q]; first = J.first[q]; }
+        if (j == q) {
+            slabs = J.slabs[q]; out = J.out[q]; stride = J.stride[q]; off = J.off[q]; n = J.n[q]; first = J.first[q];
+            nslabs = J.nslabs[q];
+        }
     const int i = ((int)blockIdx.x - first) * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= n) return;
@@ -1232,7 +1235,7 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
                                             g->dg1, g->dbe1, eval);
     VN_LAUNCH_STATUS();
     float *slabs3 = reinterpret_cast<float *>(ws + pl.off_slabs3);
-    k_vfe_b3<<<pl.blocks_b2, NT, pl.lds_small, st>>>(feature, T, P, wk, stats, coef1, dp1, slabs3);
+    k_vfe_b3<<<pl.blocks, NT, pl.lds_small, st>>>(feature, T, P, wk, stats, coef1, dp1, slabs3);
     VN_LAUNCH_STATUS();
     {   // the four parameter-gradient reductions (db2, dW2 from pass b2's slab; dW1, db1 from pass b3's) in one launch
         ReduceJobs J{};
@@ -1243,11 +1246,12 @@ extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVf
         int first = 0;
         for (int j = 0; j < 4; ++j) {
             J.slabs[j] = sl[j]; J.out[j] = out[j]; J.stride[j] = stride[j]; J.off[j] = off[j]; J.n[j] = n[j];
+            J.nslabs[j] = j < 2 ? pl.blocks_b2 : pl.blocks;   // pass b3 (no LDS tile, 255 VGPRs) runs with the full grid
             J.first[j] = first;
             first += (n[j] + 3) / 4;
         }
         J.first[4] = first;
-        k_vfe_reduce_multi<<<first, 256, 0, st>>>(J, pl.blocks_b2);
+        k_vfe_reduce_multi<<<first, 256, 0, st>>>(J);
         VN_LAUNCH_STATUS();
     }
     return VN_OK;
