@@ -8,9 +8,12 @@
 //   h2 = relu(out1 W2^T + b2); p2 = BN2(h2); out2 = [p2, max_T p2] * mask
 //   voxelwise = max_T out2                                 model.py:100
 //
-// HBM-bound by design: the only tensors that touch HBM are the (K,T,7) input,
+// Little HBM traffic by design — the only tensors that touch HBM are the (K,T,7) input,
 // the (K,128) output and (backward) one (K,r,16) gradient; the (K,T,32) and
-// (K,T,128) intermediates of the reference are recomputed per pass in registers.
+// (K,T,128) intermediates of the reference are recomputed per pass in registers —
+// so what bounds these kernels is latency: a wave item is a chain of dependent phases
+// (loads -> layer 1 -> per-voxel max -> layer 2 -> per-voxel analysis), and the lever is
+// how many waves a SIMD holds (LDS per wave, VGPRs), not bytes.
 // Train-mode BatchNorm statistics are global over all K*T rows (padded slots
 // included), so the forward is 3 passes (stats1, stats2, output) and the backward
 // 3 passes (BN2 sums, BN1 sums + layer-2 grads, layer-1 grads) with tiny finalize
@@ -29,9 +32,14 @@
 // KITTI voxels average ~4 points of T=35, so this is ~8x less arithmetic and 8x less input traffic.
 // PACKING.  A wave holds 64 rows: G voxels x R=64/G row lanes.  Voxels are binned (stable, deterministic) by r into
 // classes G=8 (r<=8), G=4 (r<=16) and G=1 (r<=64); a wave item is G voxels of one class.  Row-lane phases (the
-// skinny 7->16 and 32->64 MLPs as fp32 FMAs with broadcast LDS weights; no MFMA at these shapes) see 64 busy lanes;
-// channel-lane phases (max-pool / argmax / BN sums over a voxel's rows) run lane = channel per voxel over a per-wave
-// LDS tile [64][65].
+// 7->16 linear as fp32 FMAs with broadcast LDS weights) see 64 busy lanes; every product with W2 — 64 rows x 64 x 16 per
+// item, three of them in the backward — runs on v_mfma_f32_16x16x4_f32 (exact fp32, the same fmaf chain as the scalar
+// form) with per-lane register operands; channel-lane phases (max-pool / argmax / BN sums over a voxel's rows) run
+// lane = channel per voxel over a per-wave LDS tile [64][65].
+// NEXT (not built): the channel-lane phases on the MFMA OUTPUT registers instead of the tile — a lane of the D layout
+// holds rows 16b + 4(lane>>4) + e of channel 16c + (lane&15), so a voxel's rows (R = 8 / 16 / 64) are 4 registers x
+// 2 / 4 / 4 lanes (x 4 blocks): the per-voxel argmaxes become 4 in-lane compares + 1-2 shuffle steps for ALL slots at
+// once instead of G sequential slot loops, and passes p2 / p3 / b1 would not need the tile at all.
 // Partial sums stay in registers across a wave's items, are combined per workgroup through LDS and written as one
 // slab per workgroup; reduce kernels sum the slabs in a fixed order (deterministic, double precision).
 #include "common.h"
