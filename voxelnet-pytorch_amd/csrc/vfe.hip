@@ -52,6 +52,8 @@ constexpr int STATS_FLOATS = 4 * C1 + 4 * C2;   // 320
 constexpr int TS = 65;                          // tile row stride (floats)
 constexpr int NW = 2, NT = NW * 64;             // waves / threads per workgroup (LDS: 2 workgroups per CU)
 constexpr int VFE_BLOCKS_MAX = 1024;             // passes p2 / p3 / b1: four workgroups per CU (LDS 39.6 KB each, <= 256 VGPRs)
+// (k_vfe_p2 / p3 / b1 carry amdgpu_waves_per_eu(2, 2): two waves per SIMD is what their grid and LDS are sized for, and a
+// build that drifts over 256 VGPRs — it happened with one more pointer argument — silently halves their occupancy)
 // per-voxel-slot vectors in LDS (floats); odd stride: the 8 slots of a wave fall into different banks
 // Pass b2 (B2 = true) keeps agg1 | am1 | d_agg1 | u (s aliases u: u is dead once h2 is in the tile, s is written after
 // that); the passes that only recompute the forward keep agg1 | u.
@@ -536,7 +538,7 @@ __device__ __forceinline__ void p2_item(const float *__restrict__ feature, int T
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ void __launch_bounds__(NT) k_vfe_p2(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_vfe_p2(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
                                                const float *__restrict__ stats, float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -590,7 +592,7 @@ __device__ __forceinline__ void p3_item(const float *__restrict__ feature, int T
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ void __launch_bounds__(NT) k_vfe_p3(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_vfe_p3(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
                                                const float *__restrict__ stats, float *__restrict__ voxelwise) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -754,7 +756,7 @@ __device__ __forceinline__ void b1_item(const float *__restrict__ feature, int T
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ void __launch_bounds__(NT) k_vfe_b1(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_vfe_b1(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
                                                const float *__restrict__ stats, const float *__restrict__ dvw,
                                                float *__restrict__ slabs) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
