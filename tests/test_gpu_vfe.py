@@ -87,3 +87,33 @@ def test_vfe_effective_rows_match_oracle(T, dense):
     grads2 = M.featnet_backward(fd, wst2, stats, up.to(DEV), params)
     for a, b in zip(grads, grads2):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("K", [1, 17, 4095, 4097, 8200])
+def test_vfe_partition_chunk_boundaries(K):
+    """k_vfe_partition hands 4096 voxels to a workgroup, 16 per thread (one 16-byte load of row counts): voxel counts
+    around those boundaries, all three packing classes mixed, forward + backward against the float64 oracle."""
+    from voxelnet_amd import model as M
+    T = 35
+    pool = _features(T, 7)
+    rng = np.random.default_rng(K)
+    feat = torch.from_numpy(pool[rng.integers(0, pool.shape[0], size=K)])
+    sd = tr.make_state_dict("Car")
+    keys = M.VFE_KEYS
+    bufk = ["feature_net.vfe_1.bn.running_mean", "feature_net.vfe_1.bn.running_var",
+            "feature_net.vfe_2.bn.running_mean", "feature_net.vfe_2.bn.running_var"]
+    sd64 = {k: (v.double().clone() if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+    leaves = {k: sd64[k].requires_grad_(True) for k in keys}
+    work = dict(sd64)
+    work.update(leaves)
+    ref = tr.voxel_features(feat.double(), work, True)
+    up = torch.from_numpy(np.random.default_rng(9).standard_normal((K, 128)).astype(np.float32))
+    ref.backward(up.double())
+    params = [sd[k].clone().to(DEV) for k in keys]
+    bufs = [sd[k].clone().to(DEV) for k in bufk]
+    fd = feat.to(DEV)
+    vw, stats, wst = M.featnet_forward(fd, params, bufs, True)
+    assert rel_err(vw, ref) < 1e-4
+    grads = M.featnet_backward(fd, wst, stats, up.to(DEV), params)
+    for g, k in zip(grads, keys):
+        assert rel_err(g, leaves[k].grad) < 1e-3, k
