@@ -175,7 +175,7 @@ def main():
     from voxelnet_amd import parallel, synth
     from voxelnet_amd.config import GRADIENT_CLIP, LR, grid_config
     from voxelnet_amd.optim import ClipSGD
-    from voxelnet_amd.voxelize import VoxelBuffers, voxelize_device_async
+    from voxelnet_amd.voxelize import VoxelBatch, VoxelBuffers, voxelize_device_async
 
     cfg_index, workload_id, cls, T, default_batch, cfg_desc = CONFIGS[args.config]
     B = args.batch or default_batch
@@ -255,6 +255,10 @@ def main():
             feats.append(f)
             coords.append(c)
         torch.cuda.current_stream().wait_event(handles[-1].event)
+        # the model's first act is to concatenate the per-frame tensors (RPN3D.detect): done here on the voxelizer's stream,
+        # one step ahead like the voxelization itself (voxelize.VoxelBatch; DeviceCollate does the same)
+        feats = VoxelBatch.ahead(feats, vox_stream, torch.float32)
+        coords = VoxelBatch.ahead(coords, vox_stream, torch.int64)
         launch_voxelize()
         if args.static_voxels:
             torch.cuda.synchronize()
@@ -276,7 +280,12 @@ def main():
         torch.autograd.backward([prob, reg], list(upstream))
         return prob.flatten()[0]
 
+    gap_events = [] if os.environ.get("VN_BENCH_GAPS") else None   # diagnostic: idle time of the training stream between steps
+
     def step_eager():
+        if gap_events is not None:
+            g0 = torch.cuda.Event(enable_timing=True)
+            g0.record()
         feats, coords = voxelize_batch()
         loss = fwd_bwd(feats, coords)
         if not args.static_voxels:         # this step's slot may be re-used once the backward (queued above) is done
@@ -299,6 +308,10 @@ def main():
             torch.nn.utils.clip_grad_norm_(state["params"], GRADIENT_CLIP)  # train.py:153
         state["opt"].step()                                                # train.py:154 (ClipSGD: both lines)
         state["opt"].zero_grad(set_to_none=True)                           # train.py:155
+        if gap_events is not None:
+            g1 = torch.cuda.Event(enable_timing=True)
+            g1.record()
+            gap_events.append((g0, g1))
         return loss
 
     def sync_all():
@@ -321,6 +334,13 @@ def main():
     t_enq = time.perf_counter() - t0       # host time to enqueue the K steps (the GPU may still be running)
     sync_all()
     dt = time.perf_counter() - t0
+    if gap_events is not None and rank == 0:
+        ge = gap_events[-args.steps:]
+        gaps = sorted(ge[i][1].elapsed_time(ge[i + 1][0]) * 1e3 for i in range(len(ge) - 1))
+        inside = sorted(a.elapsed_time(b) * 1e3 for a, b in ge)
+        print("VN_BENCH_GAPS: training-stream time between the last launch of a step and the first of the next: median %.1f us, "
+              "p90 %.1f, max %.1f; first-to-last launch of a step: median %.1f us"
+              % (gaps[len(gaps) // 2], gaps[int(len(gaps) * 0.9)], gaps[-1], inside[len(inside) // 2]), file=sys.stderr)
     # ---- the spread: the same timed region again, --windows - 1 times (every rank: a step holds the collectives)
     window_dts = [dt]
     for _ in range(max(0, args.windows - 1)):

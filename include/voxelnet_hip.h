@@ -415,7 +415,10 @@ int vn_net_wait_bucket(vnNet *net, int32_t bucket, vnStream stream);
  * sites, voxel index grid, bias fill): may be issued on another stream while the VFE forward runs; then set
  * cfg->prepared for vn_net_forward.  The forward's stream need not wait for this one: vn_net_prepare records, on the
  * vnNet, one event behind what the first layer needs (issued first) and one behind the rest of the weight packing, and
- * vn_net_forward waits for the first at its start and for the second in front of the second layer. */
+ * vn_net_forward waits for the first at its start and for the second in front of the second layer.
+ * Two-call form: heads_w == NULL issues only the first layer's needs (event 0) and returns; the next call, with heads_w,
+ * issues only the rest (event 1) — for a caller whose heads_w is itself produced on that stream (a concatenation of the
+ * two heads' parameters) and should not sit in front of the site list. */
 int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
                    const int64_t *coord, int64_t K, void *workspace, size_t workspace_bytes, vnStream stream);
 int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,

@@ -398,6 +398,7 @@ struct vnNet {
     // at its start and for [1] in front of the second layer, so the ~65 us of packing are off the start of the step
     hipEvent_t prep_ev[2];
     bool prep_recorded;
+    bool prep_first_done;   // vn_net_prepare was called with heads_w == NULL: the next call issues only the rest
     hipEvent_t ring[64];
     unsigned next;
     hipEvent_t next_event() { return ring[next++ & 63]; }
@@ -570,12 +571,19 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
         }
         return VN_OK;
     };
-    if (own_stream) {
+    if (!own_stream && !heads_w) return VN_EINVAL;
+    const bool rest_only = own_stream && heads_w && net->prep_first_done;   // second call of the two-call protocol
+    net->prep_first_done = false;
+    if (own_stream && !rest_only) {
         const Spec &sp = P.spec[0];
         vnPackJob j0{L[0].weight, P.wp_f[0], sp.cout, sp.cin, sp.k[0] * sp.k[1] * sp.k[2], sp.transposed ? 2 : 0, 0, sp.cin_fold, P.adt, 0};
         RTT(T_PACK, 0, 0.0, (double)j0.c_out * j0.c_in * j0.taps * (4 + P.esz), stream, vn_pack_weights_batch(&j0, 1, stream));
         RT(first_needs());
         VN_HIP(hipEventRecord(net->prep_ev[0], vn_stream(stream)));
+        if (!heads_w) {   // first call of the two-call protocol: the caller has more to queue (e.g. the heads' concatenation)
+            net->prep_first_done = true;
+            return VN_OK;
+        }
     }
     {   // every layer's weights -> MFMA operand layout, forward and (training) data-gradient orientation: one launch
         vnPackJob jobs[2 * NL + 2];
@@ -608,7 +616,7 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
 
 extern "C" int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w,
                               const int64_t *coord, int64_t K, void *workspace, size_t workspace_bytes, vnStream stream) {
-    VN_CHECK_ARG(net && cfg && L && heads_w && workspace && K >= 0 && (!cfg->sparse_first || coord));
+    VN_CHECK_ARG(net && cfg && L && workspace && K >= 0 && (!cfg->sparse_first || coord));
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
     if (workspace_bytes < P.bytes) return VN_EWORKSPACE;

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from .config import grid_config
-from .voxelize import voxelize_device_async
+from .voxelize import VoxelBatch, voxelize_device_async
 
 
 def _read_image(path):
@@ -108,6 +108,10 @@ class DeviceCollate:
             torch.cuda.current_stream().wait_event(handles[-1][0].event)       # consumer stream after the voxelizer
             for t in feats + coords + nums:
                 t.record_stream(torch.cuda.current_stream())
+            # the concatenations the model starts with (RPN3D.detect), made here on the pipeline's stream: off the train
+            # step's dependency chain
+            feats = VoxelBatch.ahead(feats, self.stream, torch.float32)
+            coords = VoxelBatch.ahead(coords, self.stream, torch.int64)
         return ([p[0] for p in parts], np.array([p[3] for p in parts] + [None], dtype=object)[:-1], feats, nums, coords,
                 np.array([p[1] for p in parts] + [None], dtype=object)[:-1],
                 np.array([p[2] for p in parts] + [None], dtype=object)[:-1])

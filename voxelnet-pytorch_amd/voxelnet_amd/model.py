@@ -209,6 +209,17 @@ class _VFELayerFn(torch.autograd.Function):
         return dx, None, dw, db, dg, dbe, None, None
 
 
+def _batch_cat(parts, dtype):
+    """the per-sample tensors of a batch as one (sum K_i, ...) tensor; a voxelize.VoxelBatch brings the concatenation
+    along (made on the input pipeline's stream one step ahead), a plain list / tuple is concatenated here"""
+    take = getattr(parts, "take", None)
+    ready = take() if take is not None else None
+    if ready is not None and ready.dtype == dtype:
+        return ready
+    t = parts[0] if len(parts) == 1 else torch.cat(list(parts), dim=0)
+    return t.contiguous().to(dtype)
+
+
 class VFELayer(nn.Module):
     """model.py:60-82.  Holds fcn (Linear+ReLU) and bn exactly like the reference.  Inside FeatureLearningNet both
     layers and the voxel max run fused (csrc/vfe.hip); called on its own — forward(inputs (K,T,cin), mask (K,T,1)) ->
@@ -339,8 +350,7 @@ class FeatureLearningNet(nn.Module):
 
     def forward(self, feature, coordinate):
         bs = len(feature)
-        feature = torch.cat(list(feature), dim=0).contiguous().float()
-        coordinate = torch.cat(list(coordinate), dim=0).contiguous().long()
+        feature, coordinate = _batch_cat(feature, torch.float32), _batch_cat(coordinate, torch.int64)
         out = _FeatureNetFn.apply(feature, coordinate, bs, self._grid.dims, self.training, self._bufs(),
                                   *_vfe_weights(self))
         self._tick()
@@ -592,17 +602,6 @@ class _DetectorFn(torch.autograd.Function):
                 cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, 1 if mode == "fp32" else 0, int(training), int(sparse), 0, 0)
                 cfg.grad_storage = int(rpn.grad_storage) & (16 if mode == "fp32" else 15)
                 side = rpn._side_stream(dev_) if rpn.overlap_wgrad else None
-                if side is not None:
-                    # the (16,768) / (16,) concatenations of the two heads' parameters: two small launches, read first by the
-                    # weight packing on the side stream — issued there, not in front of the VFE forward on the main stream
-                    side_t = rpn.__dict__["_side"]
-                    side_t.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(side_t):
-                        heads = _heads_params([f.detach() for f in flat[-4:]])
-                    for t_ in heads.values():
-                        t_.record_stream(torch.cuda.current_stream())
-                else:
-                    heads = _heads_params([f.detach() for f in flat[-4:]])
                 arr, _ = _native_layer_arrays(mid)
                 lib = _lib.load()
                 ws_bytes = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
@@ -610,11 +609,24 @@ class _DetectorFn(torch.autograd.Function):
                     raise _lib.VoxelnetHipError("vn_net_workspace_bytes: unsupported network configuration")
                 ws = rpn._ws_acquire(ws_bytes, dev_)
                 if side is not None:
-                    # what does not depend on the voxel features (weight packing, the first layer's site list / index
-                    # grid / bias fill) runs on the side stream beside the VFE forward
+                    # what does not depend on the voxel features runs on the side stream beside the VFE forward, the first
+                    # layer's needs first (its packed weights, the site list, the index grid: vn_net_prepare's two-call
+                    # form), then the (16,768) / (16,) concatenations of the two heads' parameters — two small launches the
+                    # weight packing reads — and the rest of the packing
+                    side_t = rpn.__dict__["_side"]
+                    side_t.wait_stream(torch.cuda.current_stream())
+                    if os.environ.get("VN_PREP_JOIN") != "1":      # ("1": the round-2 schedule, for A/B runs against older builds)
+                        _lib.call("vn_net_prepare", rpn._net_handle(dev_), ctypes.byref(cfg), arr, None, coord.data_ptr(), K,
+                                  ws.data_ptr(), ws_bytes, side)
+                    with torch.cuda.stream(side_t):
+                        heads = _heads_params([f.detach() for f in flat[-4:]])
+                    for t_ in heads.values():
+                        t_.record_stream(torch.cuda.current_stream())
                     _lib.call("vn_net_prepare", rpn._net_handle(dev_), ctypes.byref(cfg), arr, heads["weight"].data_ptr(), coord.data_ptr(), K,
                               ws.data_ptr(), ws_bytes, side)
                     cfg.prepared = 1
+                else:
+                    heads = _heads_params([f.detach() for f in flat[-4:]])
                 vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
                 # With the sparse first Conv3d (rulebook evaluation: voxel rows x packed weights, then a gather-sum per
                 # active site) the dense (B,10,400,352,128) grid of model.py:102-106 is never built.
@@ -1046,8 +1058,7 @@ class RPN3D(nn.Module):
     def detect(self, voxel_features, voxel_coordinates):
         """feature_net + middle_rpn (model.py:305-306), fused."""
         bs = len(voxel_features)
-        feature = (voxel_features[0] if bs == 1 else torch.cat(list(voxel_features), dim=0)).contiguous().float()
-        coord = (voxel_coordinates[0] if bs == 1 else torch.cat(list(voxel_coordinates), dim=0)).contiguous().long()
+        feature, coord = _batch_cat(voxel_features, torch.float32), _batch_cat(voxel_coordinates, torch.int64)
         flat = self._flat_params()
         if (self._native_ok(_mode()) and self.training and self.direct_grads and torch.is_grad_enabled() and feature.is_cuda
                 and self._all_need_grad(flat)):
