@@ -999,23 +999,20 @@ __global__ void __launch_bounds__(256) k_act_delta_rows(const void *__restrict__
 __global__ void __launch_bounds__(256) k_wgrad_const_add(float *__restrict__ dw, const float *__restrict__ slab, int nb, int Co,
                                                          int Ci, int kD, const float *__restrict__ stats,
                                                          const float *__restrict__ inactive, int ydt, int adt, int relu) {
-    __shared__ double red[256];
     __shared__ double sums[9];         // Tot, then the eight edges
     __shared__ float box[9];
     const int co = blockIdx.x;
-    for (int k = 0; k < 9; ++k) {
+    // (this launch ends the side stream's tail: the nine column sums go to the four waves, shuffle-reduced, one barrier —
+    //  they were nine 8-barrier LDS trees in a row)
+    for (int k = threadIdx.x >> 6; k < 9; k += 4) {
         const int r0 = k == 0 ? 0 : nb + (k - 1) * BOX_EB, rn = k == 0 ? nb : BOX_EB;
         double a = 0.0;
-        for (int r = threadIdx.x; r < rn; r += 256) a += (double)slab[(size_t)(r0 + r) * Co + co];
-        red[threadIdx.x] = a;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) sums[k] = red[0];
-        __syncthreads();
+        for (int r = threadIdx.x & 63; r < rn; r += 64) a += (double)slab[(size_t)(r0 + r) * Co + co];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+        if ((threadIdx.x & 63) == 0) sums[k] = a;
     }
+    __syncthreads();
     if (threadIdx.x < 9) {
         const int hc = threadIdx.x / 3, wc = threadIdx.x % 3;
         double v = sums[0];
