@@ -67,6 +67,7 @@ struct PackJobs {
 struct UnpackJobs {
     int32_t n;
     int32_t block_begin[PACK_MAX_JOBS + 1];
+    int32_t tn[PACK_MAX_JOBS];          // mode 0: torch rows (n) per workgroup tile
     vnUnpackJob job[PACK_MAX_JOBS];
 };
 
@@ -100,26 +101,74 @@ __global__ void __launch_bounds__(256) k_pack_weights_batch(const PackJobs t) {
     }
 }
 
+// The torch layout keeps the taps of one (co, ci) pair together, the packed layout keeps one tap's (n, k) matrix together:
+// a thread-per-element unpack stores 4-byte words `taps` floats apart (partial-line writes; the launch cost 2 % of the
+// train step).  So a workgroup owns a TILE of the torch layout and goes through LDS: coalesced (summed) reads of the
+// packed rows, then one contiguous run of stores per torch row.
+//   mode 0 (torch[(n c_in + fold(k)) taps + tap]): tn whole n rows (every k, every tap: the fold permutes k inside a row);
+//   mode 2 (torch[(k c_out + n) taps + tap], fold 1): 16 n x 16 k, every tap — 16 runs of 16 x taps floats.
+// block_begin counts tiles; t.tn[j] = rows per tile of job j (mode 0).
+constexpr int UNPACK_LDS_FLOATS = 8192;   // 32 KB
+
+__device__ __forceinline__ float4 unpack_sum(const vnUnpackJob &q, int64_t i) {
+    const int chunks = q.chunks > 1 ? q.chunks : 1;
+    float4 v = *reinterpret_cast<const float4 *>(q.dw_packed + i);
+    int c = 1;
+    for (; c + 8 <= chunks; c += 8) {                                 // eight partial slabs in flight, added in order
+        float4 u[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) u[e] = *reinterpret_cast<const float4 *>(q.dw_packed + (int64_t)(c + e) * q.chunk_stride + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v.x += u[e].x; v.y += u[e].y; v.z += u[e].z; v.w += u[e].w; }
+    }
+    for (; c < chunks; ++c) {                                         // fixed order
+        const float4 u = *reinterpret_cast<const float4 *>(q.dw_packed + (int64_t)c * q.chunk_stride + i);
+        v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    return v;
+}
+
 __global__ void __launch_bounds__(256) k_unpack_wgrads_batch(const UnpackJobs t) {
+    __shared__ __attribute__((aligned(16))) float tile[UNPACK_LDS_FLOATS];
     const int j = find_job(t.block_begin, t.n);
     const vnUnpackJob &q = t.job[j];
-    const int nb = t.block_begin[j + 1] - t.block_begin[j], b = blockIdx.x - t.block_begin[j];
-    const int chunks = q.chunks > 1 ? q.chunks : 1;
-    const int64_t total4 = (int64_t)q.taps * q.c_out * q.c_in / 4;      // c_in % 4 == 0 (checked on the host)
-    for (int64_t i4 = (int64_t)b * 256 + threadIdx.x; i4 < total4; i4 += (int64_t)nb * 256) {
-        const int64_t i = i4 * 4;
-        const int k = (int)(i % q.c_in);
-        const int n = (int)((i / q.c_in) % q.c_out);
-        const int tap = (int)(i / ((int64_t)q.c_in * q.c_out));
-        float4 v = *reinterpret_cast<const float4 *>(q.dw_packed + i);
-        for (int c = 1; c < chunks; ++c) {                                // fixed order
-            const float4 u = *reinterpret_cast<const float4 *>(q.dw_packed + (int64_t)c * q.chunk_stride + i);
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-        }
-        const float e[4] = {v.x, v.y, v.z, v.w};
+    const int b = blockIdx.x - t.block_begin[j];
+    const int taps = q.taps, cin = q.c_in, cout = q.c_out;
+    if (q.mode == 0) {
+        const int tn = t.tn[j], n0 = b * tn, rows = n0 + tn <= cout ? tn : cout - n0;
+        const int k4n = cin >> 2, row_floats = cin * taps, per = cin / q.cin_fold;
+        // packed -> LDS in torch order: tile[nl][fold(k) * taps + tap]
+        for (int e = threadIdx.x; e < taps * rows * k4n; e += 256) {
+            const int k4 = e % k4n, nl = (e / k4n) % rows, tap = e / (k4n * rows);
+            const float4 v = unpack_sum(q, ((int64_t)tap * cout + n0 + nl) * cin + k4 * 4);
+            const float ev[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int d = 0; d < 4; ++d)
-            q.dw[torch_index(q.mode, q.c_out, q.c_in, q.taps, tap, n, k + d, q.cin_fold)] = e[d];
+            for (int d = 0; d < 4; ++d) {
+                const int k = k4 * 4 + d, ci = q.cin_fold > 1 ? (k % per) * q.cin_fold + k / per : k;
+                tile[nl * row_floats + ci * taps + tap] = ev[d];
+            }
+        }
+        __syncthreads();
+        float *dst = q.dw + (int64_t)n0 * row_floats;      // rows n0 .. n0 + rows - 1 are one contiguous run
+        for (int e = threadIdx.x; e < rows * row_floats; e += 256) dst[e] = tile[e];
+    } else {
+        const int tiles_k = (cin + 15) >> 4, tnb = b / tiles_k, tkb = b - tnb * tiles_k;
+        const int n0 = tnb * 16, k0 = tkb * 16;
+        const int nn = n0 + 16 <= cout ? 16 : cout - n0, kk = k0 + 16 <= cin ? 16 : cin - k0;   // (cin % 4 == 0)
+        const int run = nn * taps;                                   // floats of one k's run inside this tile
+        // packed -> LDS: tile[kl][nl * taps + tap]
+        for (int e = threadIdx.x; e < taps * nn * (kk >> 2); e += 256) {
+            const int k4 = e % (kk >> 2), nl = (e / (kk >> 2)) % nn, tap = e / ((kk >> 2) * nn);
+            const float4 v = unpack_sum(q, ((int64_t)tap * cout + n0 + nl) * cin + k0 + k4 * 4);
+            const float ev[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) tile[(k4 * 4 + d) * run + nl * taps + tap] = ev[d];
+        }
+        __syncthreads();
+        for (int e = threadIdx.x; e < kk * run; e += 256) {
+            const int kl = e / run, r = e - kl * run;
+            q.dw[((int64_t)(k0 + kl) * cout + n0) * taps + r] = tile[e];
+        }
     }
 }
 
@@ -367,8 +416,19 @@ extern "C" int vn_unpack_wgrads_batch(const vnUnpackJob *jobs, int32_t n, vnStre
             VN_CHECK_ARG(q.cin_fold >= 1 && q.c_in % q.cin_fold == 0);
             VN_CHECK_ARG(q.chunks <= 1 || q.chunk_stride >= (int64_t)q.taps * q.c_out * q.c_in);
             VN_CHECK_ARG((q.c_in & 3) == 0 && (q.chunk_stride & 3) == 0 && (reinterpret_cast<uintptr_t>(q.dw_packed) & 15) == 0);
-            int64_t nb = vn_ceil_div((int64_t)q.taps * q.c_out * q.c_in, 256 * 4);   // one float4 per thread
-            if (nb > 2048) nb = 2048;
+            int64_t nb;
+            if (q.mode == 0) {   // whole torch rows per tile, as many as fit the LDS tile (at most 2)
+                const int64_t row_floats = (int64_t)q.c_in * q.taps;
+                if (row_floats > 8192) return VN_EUNSUPPORTED;
+                int tn = (int)(8192 / row_floats);
+                if (tn > 2) tn = 2;          // (latency-bound: many small tiles — 2 rows measured against 8)
+                t.tn[j] = tn;
+                nb = vn_ceil_div(q.c_out, tn);
+            } else {
+                if (q.cin_fold != 1 || (int64_t)16 * 16 * q.taps > 8192) return VN_EUNSUPPORTED;
+                t.tn[j] = 16;
+                nb = vn_ceil_div(q.c_out, 16) * vn_ceil_div(q.c_in, 16);
+            }
             t.job[j] = q;
             t.block_begin[j] = blocks;
             blocks += (int)nb;
