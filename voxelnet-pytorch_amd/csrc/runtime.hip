@@ -339,12 +339,24 @@ static int dup_mask() {
     static const int v = vn_knob("VN_DUP", 0);
     return v;
 }
+// -DVN_DIAG_SKIP builds only (tools/skip_costs.sh; never the product library): VN_SKIP (bit = VN_T_* kind) drops every
+// launch of that kind — the results are wrong, the step-time difference is what that family costs INSIDE the step
+// (its place on the two streams, its HBM traffic beside the other stream), which the summed kernel times do not say
+#ifdef VN_DIAG_SKIP
+static int skip_mask() {
+    static const int v = getenv("VN_SKIP") ? atoi(getenv("VN_SKIP")) : 0;
+    return v;
+}
+#define VN_SKIPPED(kind) (skip_mask() & (1 << (kind)))
+#else
+#define VN_SKIPPED(kind) 0
+#endif
 // a launch of the executor, bracketed by timing events on ITS stream when the context is in timing mode
 #define RTT(kind, layer, flops, bytes, st, call) do {                                                           \
         vnTimeSlot *ts_ = nullptr;                                                                              \
         if (net->timing && !(ts_ = net->time_begin((kind), (layer), (double)(flops), (double)(bytes), vn_stream(st)))) \
             return VN_EINVAL;                                                                                   \
-        {                                                                                                       \
+        if (!VN_SKIPPED(kind)) {                                                                                \
             const int rc_ = (call);                                                                             \
             if (rc_ != VN_OK) {                                                                                 \
                 if (ts_) --net->t_used;   /* e1 was never recorded: drop the slot, vn_net_timing_read would fail on it */ \
@@ -399,6 +411,11 @@ struct vnNet {
     hipEvent_t prep_ev[2];
     bool prep_recorded;
     bool prep_first_done;   // vn_net_prepare was called with heads_w == NULL: the next call issues only the rest
+    // the data-gradient orientation of the packed weights is first read by the BACKWARD: vn_net_prepare leaves those jobs
+    // here and vn_net_forward issues them on the side stream behind deconv2, beside block3's small images (CUs to spare)
+    // instead of beside the first layers (where the launch cost 0.03 ms of step time)
+    vnPackJob deferred_pack[NL + 1];
+    int n_deferred;
     hipEvent_t ring[64];
     unsigned next;
     hipEvent_t next_event() { return ring[next++ & 63]; }
@@ -588,6 +605,7 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
     {   // every layer's weights -> MFMA operand layout, forward and (training) data-gradient orientation: one launch
         vnPackJob jobs[2 * NL + 2];
         int nj = 0;
+        net->n_deferred = 0;
         for (int l = 0; l < NL; ++l) {
             const Spec &sp = P.spec[l];
             const int taps = sp.k[0] * sp.k[1] * sp.k[2];
@@ -595,12 +613,18 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
                 jobs[nj++] = vnPackJob{L[l].weight, P.wp_f[l], sp.cout, sp.cin, taps, sp.transposed ? 2 : 0, 0, sp.cin_fold, P.adt, 0};
             if (training) {
                 const bool first_sparse = l == 0 && cfg->sparse_first;
-                jobs[nj++] = vnPackJob{L[l].weight, P.wp_d[l], sp.cout, sp.cin, taps, sp.transposed ? 3 : 1, 0,
-                                       first_sparse ? 1 : sp.cin_fold, P.adt, 0};
+                const vnPackJob jd{L[l].weight, P.wp_d[l], sp.cout, sp.cin, taps, sp.transposed ? 3 : 1, 0,
+                                   first_sparse ? 1 : sp.cin_fold, P.adt, 0};
+                if (own_stream) net->deferred_pack[net->n_deferred++] = jd;
+                else jobs[nj++] = jd;
             }
         }
         jobs[nj++] = vnPackJob{heads_w, P.hwp_f, 16, 768, 1, 0, 0, 1, P.adt, 0};
-        if (training) jobs[nj++] = vnPackJob{heads_w, P.hwp_d, 16, 768, 1, 1, 0, 1, P.adt, 0};
+        if (training) {
+            const vnPackJob jd{heads_w, P.hwp_d, 16, 768, 1, 1, 0, 1, P.adt, 0};
+            if (own_stream) net->deferred_pack[net->n_deferred++] = jd;
+            else jobs[nj++] = jd;
+        }
         double pbytes = 0.0;
         for (int j = 0; j < nj; ++j) pbytes += (double)jobs[j].c_out * jobs[j].c_in * jobs[j].taps * (4 + P.esz);
         RTT(T_PACK, -1, 0.0, pbytes, stream, vn_pack_weights_batch(jobs, nj, stream));
@@ -713,6 +737,13 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
         if (!sp.transposed) x = a;
         if (l == L_D1 - 1) x1 = a;
         if (l == L_D2 - 1) x2 = a;
+        if (l == L_D2 && net->n_deferred > 0) {   // vn_net_prepare's data-gradient packs: behind deconv2, on its stream
+            double pb = 0.0;
+            for (int j = 0; j < net->n_deferred; ++j)
+                pb += (double)net->deferred_pack[j].c_out * net->deferred_pack[j].c_in * net->deferred_pack[j].taps * (4 + P.esz);
+            RTT(T_PACK, -1, 0.0, pb, stream, vn_pack_weights_batch(net->deferred_pack, net->n_deferred, stream));
+            net->n_deferred = 0;
+        }
     }
     if (ss != hs) {   // join before the heads read the concat
         hipEvent_t e = net->next_event();
