@@ -68,15 +68,19 @@ __device__ __forceinline__ int chunk_swz(int row) {
     return ((row & 3) << 1) | (((row >> 3) & 1) << 3);   // 256-B rows
 }
 
-template <int TN, int TK, bool F32, int TPB>   // wave tile in units of 16 channels; 2x2 waves; taps per workgroup
-__global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
+// wave tile in units of 16 channels; 2 x WKW waves (WKW = 4: eight waves on the same 128 x 128 tile, two waves per SIMD
+// at one workgroup per CU — these launches have ~256 workgroups); taps per workgroup
+template <int TN, int TK, bool F32, int TPB, int WKW = 2>
+__global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
+    constexpr int NWV = 2 * WKW;                            // waves per workgroup
     constexpr int ESZ = F32 ? 4 : 2;
     constexpr int ROWS = F32 ? 32 : 64;                     // sites per stage (same bytes either way)
-    constexpr int DN = 32 * TN, DK = 32 * TK;
+    constexpr int DN = 32 * TN, DK = 16 * WKW * TK;
     constexpr int RBN = DN * ESZ, RBK = DK * ESZ;           // LDS row bytes
     constexpr int TILE_N = ROWS * RBN, TILE_K = ROWS * RBK; // bytes per stage
     constexpr int STAGE = TILE_N + TPB * TILE_K;            // one `rows` slab shared by TPB gathered slabs
-    constexpr int IN = TILE_N / 4096, IK = TILE_K / 4096;   // DMA instructions per wave per stage (per tile)
+    constexpr int IN = TILE_N / (1024 * NWV), IK = TILE_K / (1024 * NWV);   // DMA instructions per wave per stage (per tile)
+    static_assert(TILE_N % (1024 * NWV) == 0 && TILE_K % (1024 * NWV) == 0, "tile bytes per stage must split over the waves");
     constexpr int LPR_N = RBN / 16, LPR_K = RBK / 16;       // lanes per row
     constexpr int TW = TPB + 1;                             // table words per row: TPB source offsets + row offset
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -84,7 +88,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wn = wave >> 1, wk = wave & 1;
+    const int wn = wave / WKW, wk = wave % WKW;
     const int tile = blockIdx.z;
     const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
     const int n0 = tn * DN, k0 = tk * DK;
@@ -204,22 +208,22 @@ __global__ void __launch_bounds__(256, 2) k_wgrad(const WGParams p) {
         char *ln = smem + buf * STAGE + wave * 1024;
 #pragma unroll
         for (int i = 0; i < IN; ++i) {
-            const int r = ((i * 4 + wave) * 1024) / RBN + lane / LPR_N;
+            const int r = ((i * NWV + wave) * 1024) / RBN + lane / LPR_N;
             const int c = (lane % LPR_N) ^ chunk_swz<RBN, F32>(r);
             const uint32_t ro = t[r * TW + TPB];
             const bool ok = ro != WG_OOB && (n0 + c * (16 / ESZ)) < p.N;
-            lds_dma16(rs_r, ln + i * 4096, ok ? ro + (uint32_t)c * 16u : WG_OOB, r_col);
+            lds_dma16(rs_r, ln + i * (1024 * NWV), ok ? ro + (uint32_t)c * 16u : WG_OOB, r_col);
         }
 #pragma unroll
         for (int j = 0; j < TPB; ++j) {
             char *lk = smem + buf * STAGE + TILE_N + j * TILE_K + wave * 1024;
 #pragma unroll
             for (int i = 0; i < IK; ++i) {
-                const int r = ((i * 4 + wave) * 1024) / RBK + lane / LPR_K;
+                const int r = ((i * NWV + wave) * 1024) / RBK + lane / LPR_K;
                 const int c = (lane % LPR_K) ^ chunk_swz<RBK, F32>(r);
                 const uint32_t so = t[r * TW + j];
                 const bool ok = so != WG_OOB && (k0 + c * (16 / ESZ)) < p.C;
-                lds_dma16(rs_s, lk + i * 4096, ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
+                lds_dma16(rs_s, lk + i * (1024 * NWV), ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
             }
         }
     };
@@ -546,15 +550,15 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
         }
 }
 
-template <int TN, int TK, bool F32, int TPB>
+template <int TN, int TK, bool F32, int TPB, int WKW = 2>
 int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
-    constexpr int DN = 32 * TN, DK = 32 * TK;
+    constexpr int DN = 32 * TN, DK = 16 * WKW * TK;
     // same stage bytes for bf16 (64 sites) and fp32 (32 sites); + the row table
     constexpr size_t lds = 2u * 64u * (DN + TPB * DK) * 2u + 2u * 64u * (TPB + 1) * 4u;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK, F32, TPB>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK, F32, TPB, WKW>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    k_wgrad<TN, TK, F32, TPB><<<grid, 256, lds, st>>>(p);
+    k_wgrad<TN, TK, F32, TPB, WKW><<<grid, 128 * WKW, lds, st>>>(p);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -804,14 +808,22 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     const dim3 grid((unsigned)chunks, (unsigned)groups, (unsigned)(tiles_n * tiles_k));
     hipStream_t st = vn_stream(stream);
     int rc;
-    if (tri) rc = k128 ? launch_wgrad<2, 4, false, 3>(p, grid, st) : launch_wgrad<2, 2, false, 3>(p, grid, st);
+    static const int tri_waves = vn_knob("VN_WG_TRI_WAVES", 8);   // waves per workgroup of the three-tap tiles (4: round 2)
+    if (tri && tri_waves == 8) rc = k128 ? launch_wgrad<2, 2, false, 3, 4>(p, grid, st) : launch_wgrad<2, 1, false, 3, 4>(p, grid, st);
+    else if (tri) rc = k128 ? launch_wgrad<2, 4, false, 3>(p, grid, st) : launch_wgrad<2, 2, false, 3>(p, grid, st);
     else if (f32) {
         if (n128 && k128) rc = launch_wgrad<4, 4, true, 1>(p, grid, st);
         else if (n128) rc = launch_wgrad<4, 2, true, 1>(p, grid, st);
         else if (k128) rc = launch_wgrad<2, 4, true, 1>(p, grid, st);
         else rc = launch_wgrad<2, 2, true, 1>(p, grid, st);
     } else {
-        if (n128 && k128) rc = launch_wgrad<4, 4, false, 1>(p, grid, st);
+        static const int wg_waves = vn_knob("VN_WG_WAVES", 8);   // waves per workgroup of the 128 x 128 bf16 tile (4: round 2)
+        if (wg_waves == 8) {
+            if (n128 && k128) rc = launch_wgrad<4, 2, false, 1, 4>(p, grid, st);
+            else if (n128) rc = launch_wgrad<4, 1, false, 1, 4>(p, grid, st);
+            else if (k128) rc = launch_wgrad<2, 2, false, 1, 4>(p, grid, st);
+            else rc = launch_wgrad<2, 1, false, 1, 4>(p, grid, st);
+        } else if (n128 && k128) rc = launch_wgrad<4, 4, false, 1>(p, grid, st);
         else if (n128) rc = launch_wgrad<4, 2, false, 1>(p, grid, st);
         else if (k128) rc = launch_wgrad<2, 4, false, 1>(p, grid, st);
         else rc = launch_wgrad<2, 2, false, 1>(p, grid, st);
