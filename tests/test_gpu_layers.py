@@ -216,6 +216,40 @@ def test_batched_pack_unpack_matches_single_calls():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("co,ci,taps,mode,fold,chunks", [
+    (50, 36, 9, 0, 1, 1), (70, 20, 27, 2, 1, 1), (3, 8, 16, 0, 1, 3), (17, 4, 1, 2, 1, 2), (128, 256, 16, 0, 1, 11),
+    (64, 64, 27, 2, 1, 20), (130, 128, 9, 0, 2, 9), (16, 768, 1, 0, 1, 17)])
+def test_unpack_tiles_edge_shapes(co, ci, taps, mode, fold, chunks):
+    """k_unpack_wgrads_batch works on tiles of the torch layout (whole rows in mode 0, 16 x 16 x taps in mode 2): shapes that do
+    not divide into tiles, one to twenty row chunks (the eight-in-flight sum and its remainder loop), the BEV fold — against
+    the index map written out in numpy (csrc/layout.hip torch_index), bit for bit (the chunk sum in the same order)."""
+    from voxelnet_amd import _lib, engine as E
+    DEV = "cuda:0"
+    rng = np.random.default_rng(co * 1000 + ci + taps)
+    n = co * ci * taps
+    stride = n + 64
+    parts = rng.standard_normal((chunks, stride)).astype(np.float32)
+    acc = parts[0, :n].copy()
+    for c in range(1, chunks):
+        acc = acc + parts[c, :n]                        # fp32, in order
+    packed = acc.reshape(taps, co, ci)                  # [tap][n][k]
+    k = np.arange(ci)
+    cif = (k % (ci // fold)) * fold + k // (ci // fold) if fold > 1 else k
+    want = np.zeros(n, dtype=np.float32)
+    if mode == 0:                                       # torch[(n * ci + fold(k)) * taps + tap]
+        w3 = want.reshape(co, ci, taps)
+        w3[:, cif, :] = packed.transpose(1, 2, 0)
+    else:                                               # torch[(k * co + n) * taps + tap]
+        w3 = want.reshape(ci, co, taps)
+        w3[:, :, :] = packed.transpose(2, 1, 0)
+    dwp = torch.from_numpy(parts.reshape(-1)).to(DEV)
+    out = torch.full((n,), float("nan"), device=DEV)
+    jobs = (_lib.VnUnpackJob * 1)()
+    jobs[0] = _lib.VnUnpackJob(dwp.data_ptr(), out.data_ptr(), co, ci, taps, mode, fold, chunks, stride)
+    _lib.call("vn_unpack_wgrads_batch", jobs, 1, E.stream())
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
 def test_unpack_sums_chunk_partials():
     """vnUnpackJob.chunks: dw = sum over the row-chunk partials (vn_conv_wgrad_partials' layout), fixed order"""
     from voxelnet_amd import _lib, engine as E
