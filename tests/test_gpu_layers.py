@@ -189,7 +189,9 @@ def test_batched_pack_unpack_matches_single_calls():
     DEV = "cuda:0"
     torch.manual_seed(5)
     cases = [(64, 128, 27, 0, 1), (64, 128, 27, 1, 1), (256, 128, 4, 2, 1), (256, 128, 4, 3, 1), (128, 128, 9, 0, 2),
-             (128, 128, 9, 1, 2), (16, 768, 1, 0, 1)]
+             (128, 128, 9, 1, 2), (16, 768, 1, 0, 1),
+             # shapes that do not divide into the batched kernel's LDS tiles (2 rows; 32 x 8), the fold in the row-tile modes
+             (50, 36, 9, 1, 1), (70, 20, 27, 2, 1), (3, 8, 16, 3, 1), (130, 128, 9, 3, 2), (5, 40, 1, 0, 1), (16, 768, 1, 1, 1)]
     ws, singles, jobs = [], [], (_lib.VnPackJob * len(cases))()
     batch = []
     for i, (co, ci, taps, mode, fold) in enumerate(cases):

@@ -57,11 +57,13 @@ __global__ void __launch_bounds__(256) k_unpack_wgrad(const float *__restrict__ 
     }
 }
 
+constexpr int UNPACK_LDS_FLOATS = 8192;   // 32 KB: the LDS tile of the batched pack / unpack kernels
 // ---- batched forms: every layer of the network in ONE launch (48 + 24 launches of ~5 us of dispatch each otherwise)
 constexpr int PACK_MAX_JOBS = 56;
 struct PackJobs {
     int32_t n;
     int32_t block_begin[PACK_MAX_JOBS + 1];
+    int32_t tiled[PACK_MAX_JOBS];       // 0: one thread per element; 1: row tiles (modes 0, 3); 2: 32 x 8 tiles (modes 1, 2)
     vnPackJob job[PACK_MAX_JOBS];
 };
 struct UnpackJobs {
@@ -77,7 +79,62 @@ __device__ __forceinline__ int find_job(const int32_t *block_begin, int n) {
     return j;
 }
 
+// The mirror image of k_unpack_wgrads_batch: one thread per packed element reads the torch tensor 4 bytes at a time,
+// `taps` floats apart.  bf16 jobs without the three-part split go through LDS instead — a workgroup reads whole contiguous
+// runs of the torch layout and writes contiguous packed rows:
+//   row tiles  (modes 0 and 3: the packed row index n is the torch tensor's OUTER index): two n per workgroup — their
+//              (inner, tap) runs -> LDS -> `taps` packed rows of K bf16 each;
+//   32 x 8 tiles (modes 1 and 2, no fold: n is the torch tensor's MIDDLE index): 32 k x 8 n x taps — per k a run of
+//              8 x taps floats -> LDS -> per (tap, n) 32 consecutive bf16.
 __global__ void __launch_bounds__(256) k_pack_weights_batch(const PackJobs t) {
+    __shared__ __attribute__((aligned(16))) float tile[UNPACK_LDS_FLOATS];
+    {
+        const int j0 = find_job(t.block_begin, t.n);
+        const vnPackJob &q = t.job[j0];
+        const int b = blockIdx.x - t.block_begin[j0];
+        const int taps = q.taps;
+        bf16_t *out = static_cast<bf16_t *>(q.packed);
+        if (t.tiled[j0] == 1) {
+            // mode 0: n = co, inner = ci (folded), K = c_in; mode 3: n = ci (folded), inner = co, K = c_out
+            const int N = q.mode == 0 ? q.c_out : q.c_in, K = q.mode == 0 ? q.c_in : q.c_out;
+            const int per = q.c_in / q.cin_fold;
+            const int row_floats = K * taps;
+            const int rows = 2 * b + 2 <= N ? 2 : N - 2 * b;
+            for (int r = 0; r < rows; ++r) {
+                const int n = 2 * b + r;
+                // torch outer index of packed row n: mode 0 -> co = n; mode 3 -> ci = fold(n)
+                const int outer = q.mode == 0 ? n : (q.cin_fold > 1 ? (n % per) * q.cin_fold + n / per : n);
+                const float *src = q.w + (int64_t)outer * row_floats;
+                for (int e = threadIdx.x; e < row_floats; e += 256) tile[r * row_floats + e] = src[e];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < rows * taps * K; e += 256) {
+                const int k = e % K, tap = (e / K) % taps, r = e / (K * taps);
+                // torch inner index of packed column k: mode 0 -> ci = fold(k); mode 3 -> co = k
+                const int inner = (q.mode == 0 && q.cin_fold > 1) ? (k % per) * q.cin_fold + k / per : k;
+                out[((int64_t)tap * N + 2 * b + r) * K + k] = (bf16_t)tile[r * row_floats + inner * taps + tap];
+            }
+            return;
+        }
+        if (t.tiled[j0] == 2) {
+            // mode 1: n = ci, k = co, torch[(k c_in + n) taps + tap]; mode 2: n = co, k = ci, torch[(k c_out + n) taps + tap]
+            const int N = q.mode == 2 ? q.c_out : q.c_in, K = q.mode == 2 ? q.c_in : q.c_out;
+            const int tiles_n = (N + 7) >> 3, tkb = b / tiles_n, tnb = b - tkb * tiles_n;
+            const int k0 = tkb * 32, n0 = tnb * 8;
+            const int kk = k0 + 32 <= K ? 32 : K - k0, nn = n0 + 8 <= N ? 8 : N - n0;
+            const int run = nn * taps;
+            for (int e = threadIdx.x; e < kk * run; e += 256) {
+                const int kl = e / run, r = e - kl * run;
+                tile[e] = q.w[((int64_t)(k0 + kl) * N + n0) * taps + r];
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < taps * nn * kk; e += 256) {
+                const int kl = e % kk, nl = (e / kk) % nn, tap = e / (kk * nn);
+                out[((int64_t)tap * N + n0 + nl) * K + k0 + kl] = (bf16_t)tile[kl * run + nl * taps + tap];
+            }
+            return;
+        }
+    }
     const int j = find_job(t.block_begin, t.n);
     const vnPackJob &q = t.job[j];
     const int nb = t.block_begin[j + 1] - t.block_begin[j], b = blockIdx.x - t.block_begin[j];
@@ -108,7 +165,6 @@ __global__ void __launch_bounds__(256) k_pack_weights_batch(const PackJobs t) {
 //   mode 0 (torch[(n c_in + fold(k)) taps + tap]): tn whole n rows (every k, every tap: the fold permutes k inside a row);
 //   mode 2 (torch[(k c_out + n) taps + tap], fold 1): 16 n x 16 k, every tap — 16 runs of 16 x taps floats.
 // block_begin counts tiles; t.tn[j] = rows per tile of job j (mode 0).
-constexpr int UNPACK_LDS_FLOATS = 8192;   // 32 KB
 
 __device__ __forceinline__ float4 unpack_sum(const vnUnpackJob &q, int64_t i) {
     const int chunks = q.chunks > 1 ? q.chunks : 1;
@@ -393,6 +449,18 @@ extern "C" int vn_pack_weights_batch(const vnPackJob *jobs, int32_t n, vnStream 
             const int64_t total = (int64_t)q.taps * q.c_out * q.c_in * (q.split3 ? 3 : 1);
             int64_t nb = vn_ceil_div(total, 256 * 8);          // 8 elements per thread
             if (nb > 256) nb = 256;
+            t.tiled[j] = 0;
+            if (q.packed_dtype == VN_BF16 && !q.split3) {
+                const int N = (q.mode == 0 || q.mode == 2) ? q.c_out : q.c_in;
+                const int K = (q.mode == 0 || q.mode == 2) ? q.c_in : q.c_out;
+                if ((q.mode == 0 || q.mode == 3) && (int64_t)2 * K * q.taps <= 8192) {
+                    t.tiled[j] = 1;
+                    nb = vn_ceil_div(N, 2);
+                } else if ((q.mode == 1 || q.mode == 2) && q.cin_fold == 1 && (int64_t)32 * 8 * q.taps <= 8192) {
+                    t.tiled[j] = 2;
+                    nb = vn_ceil_div(K, 32) * vn_ceil_div(N, 8);
+                }
+            }
             t.job[j] = q;
             t.block_begin[j] = blocks;
             blocks += (int)nb;
