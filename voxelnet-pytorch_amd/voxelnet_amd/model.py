@@ -209,6 +209,15 @@ class _VFELayerFn(torch.autograd.Function):
         return dx, None, dw, db, dg, dbe, None, None
 
 
+def _parts_to(parts, device):
+    """[t.to(device) for t in parts] (model.py:302-303) — but a voxelize.VoxelBatch whose tensors already live there is
+    returned as it is, with the concatenation it carries"""
+    dev = torch.device(device)
+    if getattr(parts, "cat", None) is not None and all(t.device == dev for t in parts):
+        return parts
+    return [t.to(device) for t in parts]
+
+
 def _batch_cat(parts, dtype):
     """the per-sample tensors of a batch as one (sum K_i, ...) tensor; a voxelize.VoxelBatch brings the concatenation
     along (made on the input pipeline's stream one step ahead), a plain list / tuple is concatenated here"""
@@ -1090,8 +1099,8 @@ class RPN3D(nn.Module):
 
     def forward(self, x, device, targets=None):
         label, voxel_features, voxel_coordinates = x[1], x[2], x[4]
-        voxel_features = [f.to(device) for f in voxel_features]          # model.py:302-303
-        voxel_coordinates = [c.to(device) for c in voxel_coordinates]
+        voxel_features = _parts_to(voxel_features, device)               # model.py:302-303
+        voxel_coordinates = _parts_to(voxel_coordinates, device)
         # model.py:309 generates the targets AFTER the network ran; they depend on the labels only, so here their three small
         # launches (and the host-side box parsing) are issued first, on a stream of their own, and run beside the VFE /
         # first layers; the loss waits for them (529 -> 545 point-clouds/s with the targets generated inside the step)
