@@ -70,3 +70,36 @@ def test_device_batches_match_the_oracle_voxelizer(tmp_path):
     out = model(batches[0], DEV)
     out[2].backward()
     assert torch.isfinite(out[2]).item() and all(p.grad is not None for p in model.parameters())
+
+
+def test_voxel_batch_carries_the_concatenation(tmp_path):
+    """DeviceCollate hands the model voxelize.VoxelBatch lists: plain lists of the per-sample tensors (indexing, len, iteration
+    as collate_fn's lists, dataset.py:80-96) that also carry torch.cat of themselves, made on the pipeline's stream — and
+    RPN3D.forward gives the same bits whether it gets them or plain lists (which it concatenates itself)."""
+    from voxelnet_amd import dataset as D
+    from voxelnet_amd import model as M
+    from voxelnet_amd.voxelize import VoxelBatch
+    root = str(tmp_path / "kitti")
+    _make_kitti(root, 2)
+    ds = D.KITTIDataset(root, shuffle=False, augment=False)
+    batch = D.DeviceCollate(DEV, "Car", shuffle_points=False)([ds[0], ds[1]])
+    feats, coords = batch[2], batch[4]
+    assert isinstance(feats, VoxelBatch) and isinstance(coords, VoxelBatch) and isinstance(feats, list) and len(feats) == 2
+    torch.cuda.synchronize()
+    assert torch.equal(feats.cat, torch.cat(list(feats))) and torch.equal(coords.cat, torch.cat(list(coords)))
+    assert feats.cat.dtype == torch.float32 and coords.cat.dtype == torch.int64
+    assert M._parts_to(feats, DEV) is feats                       # RPN3D.forward keeps the object (and its concatenation)
+    torch.manual_seed(3)
+    m = M.RPN3D("Car").to(DEV).train()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    out_a = m(batch, DEV)
+    out_a[2].backward()
+    ga = {n: p.grad.clone() for n, p in m.named_parameters()}
+    m.load_state_dict(sd)
+    m.zero_grad(set_to_none=True)
+    plain = tuple(list(x) if isinstance(x, VoxelBatch) else x for x in batch)
+    out_b = m(plain, DEV)
+    out_b[2].backward()
+    assert torch.equal(out_a[0], out_b[0]) and torch.equal(out_a[1], out_b[1]) and torch.equal(out_a[2], out_b[2])
+    for n, p in m.named_parameters():
+        assert torch.equal(ga[n], p.grad), n
