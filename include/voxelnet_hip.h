@@ -330,7 +330,10 @@ int vn_unpack_wgrads_batch(const vnUnpackJob *jobs /* host array */, int32_t n, 
  * R_rect_4x4: HOST pointers to the float32 matrices load_calib returns (row-major).  A point survives when reflectance
  * > 0, its rectified camera z >= 0 and its rounded pixel satisfies 0 < col < image_cols, 0 < row < image_rows (float32
  * arithmetic, np.round = round half to even).  out_points (capacity n rows) receives the survivors in input order,
- * out_index (n int32, may be NULL) their input row numbers, *out_count (device int32) their number.  Asynchronous.
+ * out_index (n int32, may be NULL) their input row numbers, *out_count (device int32) their number; rows
+ * [*out_count, n) of out_points are filled with NaN points, which every range test drops (vn_voxelize_index on all n
+ * rows gives the result of the first *out_count rows bit for bit), so the input pipeline never reads the count back.
+ * Asynchronous.
  * ---------------------------------------------------------------------- */
 size_t vn_fov_crop_workspace_bytes(int64_t n);
 int vn_fov_crop(const float *points, int64_t n, const float *P_3x4, const float *Tr_velo_to_cam_4x4,

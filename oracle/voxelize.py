@@ -39,9 +39,11 @@ def build():
 def _lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "liboracle.so")
-        if not os.path.exists(path):
-            build()
+        path = os.environ.get("VN_ORACLE_LIB")        # tests/test_sanitizers.py: the ASan build (oracle/Makefile `asan`)
+        if not path:
+            path = os.path.join(_HERE, "liboracle.so")
+            if not os.path.exists(path):
+                build()
         lib = ctypes.CDLL(path)
         lib.vn_oracle_voxelize.restype = ctypes.c_int64
         lib.vn_oracle_voxelize.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(_Grid),

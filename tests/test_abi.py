@@ -70,3 +70,22 @@ def test_state_dict_matches_reference_keys():
         assert set(sd) == set(ref)
         assert all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in ref)
         assert sum(p.numel() for p in m.parameters()) == 6809392 and len(list(m.parameters())) == 104
+
+
+def test_every_tuning_knob_is_listed_and_the_environment_is_read_in_one_place():
+    """common.h: vn_knob() is the ONLY place the library reads the environment, and vn_build_info() reports every override.
+    A knob that is not in abi.hip's KNOBS table would silently return its default (round-3 advisor finding): every
+    vn_knob("NAME") in the sources must be listed, and no source but abi.hip may call getenv."""
+    csrc = os.path.join(ROOT, "voxelnet-pytorch_amd", "csrc")
+    table = re.search(r"KNOBS\[\]\s*=\s*\{([^}]*)\}", open(os.path.join(csrc, "abi.hip")).read()).group(1)
+    listed = set(re.findall(r'"(VN_[A-Z0-9_]+)"', table))
+    used = set()
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h", ".inc")):
+            continue
+        text = open(os.path.join(csrc, f)).read()
+        used |= set(re.findall(r'vn_knob\(\s*"(VN_[A-Z0-9_]+)"', text))
+        if f != "abi.hip":
+            assert "getenv" not in text, f"{f} reads the environment itself; route it through vn_knob()"
+    assert used <= listed, f"knobs missing from abi.hip's KNOBS table: {sorted(used - listed)}"
+    assert listed <= used, f"stale entries in abi.hip's KNOBS table: {sorted(listed - used)}"

@@ -103,3 +103,39 @@ def test_voxel_batch_carries_the_concatenation(tmp_path):
     assert torch.equal(out_a[0], out_b[0]) and torch.equal(out_a[1], out_b[1]) and torch.equal(out_a[2], out_b[2])
     for n, p in m.named_parameters():
         assert torch.equal(ga[n], p.grad), n
+
+
+def test_batcher_queues_a_batch_concatenation_before_the_next_batch_pipeline_work(tmp_path, monkeypatch):
+    """Round-3 advisor finding: DeviceBatcher launched batch i+1 before it concatenated batch i, so step i's
+    concatenation sat on the pipeline stream behind batch i+1's copies, crop and voxelization.  The order on the pipeline
+    stream must be launch(0), concat(0), launch(1), concat(1), launch(2) ... (bench.py's order), and every batch must
+    still carry its concatenation."""
+    from voxelnet_amd import dataset as D
+    from voxelnet_amd.voxelize import VoxelBatch
+    root = str(tmp_path / "kitti")
+    _make_kitti(root, 6)
+    ds = D.KITTIDataset(root, shuffle=False, augment=False)
+    loader = torch.utils.data.DataLoader(ds, batch_size=2, shuffle=False, collate_fn=list, num_workers=0)
+    log = []
+    real_launch, real_ahead = D.DeviceCollate.launch, VoxelBatch.ahead.__func__
+    n_launch = [0]
+
+    def launch(self, parts):
+        log.append(("launch", n_launch[0]))
+        n_launch[0] += 1
+        return real_launch(self, parts)
+
+    def ahead(cls, tensors, stream, dtype):
+        if dtype == torch.float32:
+            log.append(("concat", None))
+        return real_ahead(cls, tensors, stream, dtype)
+    monkeypatch.setattr(D.DeviceCollate, "launch", launch)
+    monkeypatch.setattr(VoxelBatch, "ahead", classmethod(ahead))
+    batches = list(D.DeviceBatcher(loader, DEV, "Car", shuffle_points=False))
+    kinds = [k for k, _ in log]
+    assert kinds == ["launch", "concat", "launch", "concat", "launch", "concat"], kinds
+    assert len(batches) == 3
+    torch.cuda.synchronize()
+    for b in batches:
+        assert isinstance(b[2], VoxelBatch) and torch.equal(b[2].cat, torch.cat(list(b[2])))
+        assert torch.equal(b[4].cat, torch.cat(list(b[4])))

@@ -79,3 +79,30 @@ def test_device_batcher_crops_raw_sweeps(golden, tmp_path):
         ref = ov.voxelize(cropped, "Car")
         assert np.array_equal(batch[2][i].cpu().numpy(), ref["feature_buffer"])
         assert np.array_equal(batch[4][i].cpu().numpy()[:, 1:], ref["coordinate_buffer"])
+
+
+def test_padded_crop_feeds_the_voxelizer_without_a_read_back(golden):
+    """fov_crop_device(padded=True): the capacity-sized buffer with NaN points past the device-side count (no host
+    synchronisation) voxelizes to the same bits as the cropped cloud — what DeviceCollate hands the voxelizer."""
+    from oracle import voxelize as ov
+    from voxelnet_amd.config import grid_config
+    from voxelnet_amd.fov import fov_crop_device
+    from voxelnet_amd.voxelize import voxelize_device
+    g = golden("fov_crop")
+    rows, cols = (int(v) for v in g["image_shape"])
+    rng = np.random.default_rng(11)
+    n = 60_000
+    pts = np.stack([rng.uniform(-10, 70, n), rng.uniform(-40, 40, n), rng.uniform(-3, 1, n), rng.uniform(0, 1, n)], 1).astype(np.float32)
+    ref, _ = of.fov_crop(pts, g["P"], g["Tr"], g["R"], rows, cols)
+    out, count = fov_crop_device(torch.from_numpy(pts).to(DEV), g["P"], g["Tr"], g["R"], rows, cols, padded=True)
+    assert out.shape == (n, 4) and count.dtype == torch.int32 and count.is_cuda
+    k = int(count.item())
+    assert k == ref.shape[0] and 0 < k < n
+    o = out.cpu().numpy()
+    assert np.array_equal(o[:k], ref) and np.isnan(o[k:]).all()
+    grid = grid_config("Car")
+    f, c, m = voxelize_device(out, grid, 0, coord_cols=3)
+    want = ov.voxelize(ref, "Car")
+    assert np.array_equal(c.cpu().numpy(), want["coordinate_buffer"])
+    assert np.array_equal(m.cpu().numpy(), want["number_buffer"])
+    assert np.array_equal(f.cpu().numpy(), want["feature_buffer"])

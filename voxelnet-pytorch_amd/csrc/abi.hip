@@ -8,7 +8,7 @@ extern "C" int vn_abi_version(void) { return 3; }
 
 namespace {
 // every tuning aid of the library (vn_knob): kernel-selection overrides used for A/B measurements (tools/README.md)
-const char *const KNOBS[] = {"VN_BN_HOIST", "VN_BOX_SIDE", "VN_BOX_ZERO", "VN_DUP", "VN_EARLY_DECONV", "VN_EARLY_UNPACK", "VN_FUSE_BWD_REDUCE", "VN_GG_CONFIG", "VN_GG_ROWS_CONFIG", "VN_HEADS_BLOCKS", "VN_HEADS_STREAM", "VN_M0_BN", "VN_M0_MAIN", "VN_PATCH", "VN_PATCH2D", "VN_PATCH2D_WAVES", "VN_PATCH_P0", "VN_PATCH_P1", "VN_WGP_BLOCKS", "VN_WGRAD_PATCH", "VN_WG_BLOCKS", "VN_WG_TRI_WAVES", "VN_WG_WAVES"};
+const char *const KNOBS[] = {"VN_BN_HOIST", "VN_BOX_SIDE", "VN_BOX_ZERO", "VN_DUP", "VN_EARLY_DECONV", "VN_EARLY_UNPACK", "VN_FUSE_BWD_REDUCE", "VN_GG_CONFIG", "VN_GG_ROWS_CONFIG", "VN_HEADS_BLOCKS", "VN_HEADS_STREAM", "VN_M0_BN", "VN_M0_MAIN", "VN_PATCH", "VN_PATCH2D", "VN_PATCH2D_WAVES", "VN_PATCH_P0", "VN_PATCH_P1", "VN_SKIP", "VN_WGP_BLOCKS", "VN_WGRAD_PATCH", "VN_WG_BLOCKS", "VN_WG_TRI_WAVES", "VN_WG_WAVES"};
 constexpr int NKNOBS = sizeof(KNOBS) / sizeof(KNOBS[0]);
 }  // namespace
 
@@ -18,6 +18,17 @@ int vn_knob(const char *name, int dflt) {
             const char *e = getenv(name);
             return e && *e ? atoi(e) : dflt;
         }
+    // a name missing from the table would make the knob a silent no-op: say so, once per name (stderr; no abort: this is a
+    // tuning aid of a library, and the default is what the product runs)
+    static std::mutex mu;
+    static const char *seen[16];
+    static int nseen = 0;
+    std::lock_guard<std::mutex> lock(mu);
+    for (int i = 0; i < nseen; ++i)
+        if (!strcmp(seen[i], name)) return dflt;
+    if (nseen < 16) seen[nseen++] = name;
+    fprintf(stderr, "libvoxelnet_hip: vn_knob(\"%s\") is not in the KNOBS table of csrc/abi.hip — the default %d is used and the "
+                    "environment is NOT read\n", name, dflt);
     return dflt;
 }
 

@@ -742,7 +742,7 @@ inline int apply_epl(int64_t total) {
     return r < 1 ? 1 : (r > 4 ? 4 : (int)r);
 }
 inline int apply_hoist() {   // tuning aid VN_BN_HOIST: the plain forward apply keeps its per-channel constants in registers
-    static const int v = [] { const char *e = getenv("VN_BN_HOIST"); return e && *e ? atoi(e) : 1; }();
+    static const int v = vn_knob("VN_BN_HOIST", 1);
     return v;
 }
 inline bool rows_ok(int C, int64_t stride) { return C >= 8 && (C & 7) == 0 && C <= 2048 && (stride & 7) == 0; }

@@ -77,7 +77,7 @@ __global__ void __launch_bounds__(1024) k_fov_scan(int32_t *__restrict__ block_c
 
 __global__ void __launch_bounds__(256) k_fov_compact(const float4 *__restrict__ pts, int64_t n, const uint8_t *__restrict__ flags,
                                                      const int32_t *__restrict__ block_offsets, float4 *__restrict__ out,
-                                                     int32_t *__restrict__ index) {
+                                                     int32_t *__restrict__ index, const int32_t *__restrict__ count) {
     __shared__ int wsum[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool keep = i < n && flags[i];
@@ -91,6 +91,13 @@ __global__ void __launch_bounds__(256) k_fov_compact(const float4 *__restrict__ 
         const int dst = base + __popcll(m & ((1ull << lane) - 1ull));
         out[dst] = pts[i];
         if (index) index[dst] = (int32_t)i;
+    }
+    // rows past the count: NaN points.  Every range test downstream drops them (the voxelizer's key compares fail on a
+    // NaN), so a consumer may run on the whole capacity-sized buffer without reading the count back to the host.
+    // (Row i >= count is written by nobody else: survivors only land below the count.)
+    if (i < n && i >= (int64_t)count[0]) {
+        const float q = __builtin_nanf("");
+        out[i] = make_float4(q, q, q, q);
     }
 }
 
@@ -125,7 +132,7 @@ extern "C" int vn_fov_crop(const float *points, int64_t n, const float *P_3x4, c
     k_fov_scan<<<1, 1024, 0, st>>>(counts, nb, out_count);
     VN_LAUNCH_STATUS();
     k_fov_compact<<<nb, 256, 0, st>>>(reinterpret_cast<const float4 *>(points), n, flags, counts,
-                                      reinterpret_cast<float4 *>(out_points), out_index);
+                                      reinterpret_cast<float4 *>(out_points), out_index, out_count);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -344,7 +344,7 @@ static int dup_mask() {
 // (its place on the two streams, its HBM traffic beside the other stream), which the summed kernel times do not say
 #ifdef VN_DIAG_SKIP
 static int skip_mask() {
-    static const int v = getenv("VN_SKIP") ? atoi(getenv("VN_SKIP")) : 0;
+    static const int v = vn_knob("VN_SKIP", 0);
     return v;
 }
 #define VN_SKIPPED(kind) (skip_mask() & (1 << (kind)))

@@ -92,11 +92,19 @@ class DeviceCollate:
                     from .fov import fov_crop_device, load_calib
                     P, Tr, R = load_calib(os.path.join(self.fov_calib_dir, str(p[0]) + ".txt"))
                     rows, cols = p[1].shape[:2] if p[1] is not None else self.image_shape
-                    pts = fov_crop_device(pts, P, Tr, R, rows, cols)
+                    # padded form: no 4-byte read-back per sample (it would stall the host behind everything queued
+                    # on this stream); the rows past the device-side count are NaN points, which the voxelizer drops
+                    pts, _ = fov_crop_device(pts, P, Tr, R, rows, cols, padded=True)
                 handles.append((voxelize_device_async(pts, self.grid, b, coord_cols=4), pts, host))
         return parts, handles
 
-    def finish(self, launched):
+    def concat(self, launched):
+        """second stage, still on the pipeline's stream: slice the capacity-sized outputs to K and make the concatenations
+        the model starts with (RPN3D.detect) — off the train step's dependency chain.  `DeviceBatcher` calls this for
+        batch i BEFORE it launches batch i+1, so the concatenation of batch i is queued behind batch i's own voxelizer
+        only (queued behind the next batch's copies, crop and voxelization it would make step i wait for all of them)."""
+        if len(launched) == 5:
+            return launched
         parts, handles = launched
         feats, nums, coords = [], [], []
         for h, _, _ in handles:
@@ -105,13 +113,16 @@ class DeviceCollate:
             coords.append(c)
             nums.append(n)
         if handles:
-            torch.cuda.current_stream().wait_event(handles[-1][0].event)       # consumer stream after the voxelizer
-            for t in feats + coords + nums:
-                t.record_stream(torch.cuda.current_stream())
-            # the concatenations the model starts with (RPN3D.detect), made here on the pipeline's stream: off the train
-            # step's dependency chain
             feats = VoxelBatch.ahead(feats, self.stream, torch.float32)
             coords = VoxelBatch.ahead(coords, self.stream, torch.int64)
+        return parts, handles, feats, nums, coords
+
+    def finish(self, launched):
+        parts, handles, feats, nums, coords = self.concat(launched)
+        if handles:
+            torch.cuda.current_stream().wait_event(handles[-1][0].event)       # consumer stream after the voxelizer
+            for t in list(feats) + list(coords) + nums:
+                t.record_stream(torch.cuda.current_stream())
         return ([p[0] for p in parts], np.array([p[3] for p in parts] + [None], dtype=object)[:-1], feats, nums, coords,
                 np.array([p[1] for p in parts] + [None], dtype=object)[:-1],
                 np.array([p[2] for p in parts] + [None], dtype=object)[:-1])
@@ -136,6 +147,8 @@ class DeviceBatcher:
         it = iter(self.loader)
         pending = None
         for parts in it:
+            if pending is not None:
+                pending = self.collate.concat(pending)     # batch i's concatenation in front of batch i+1's pipeline work
             launched = self.collate.launch(parts)
             if pending is not None:
                 yield self.collate.finish(pending)

@@ -22,10 +22,13 @@ def load_calib(calib_path):
     return P.astype(np.float32), Tr.astype(np.float32), R.astype(np.float32)
 
 
-def fov_crop_device(points, P, Tr_velo_to_cam, R_cam_to_rect, image_rows, image_cols, return_index=False):
+def fov_crop_device(points, P, Tr_velo_to_cam, R_cam_to_rect, image_rows, image_cols, return_index=False, padded=False):
     """points: (N,4) float32 CUDA tensor [x,y,z,reflectance].  -> the surviving rows in input order (a view of a
     capacity-sized buffer, sliced to the count: one device->host read of 4 bytes on the current stream)
-    [, their input row numbers (int32)]."""
+    [, their input row numbers (int32)].
+    padded=True: no host synchronisation — returns (the whole capacity-sized (N,4) buffer whose rows past the count are
+    NaN points, the count as a device int32 tensor); the voxelizer drops NaN points like any out-of-range point, so
+    voxelizing the padded buffer equals voxelizing the cropped cloud bit for bit (the input pipeline's form)."""
     if not (torch.is_tensor(points) and points.is_cuda and points.dtype == torch.float32 and points.dim() == 2
             and points.shape[1] == 4):
         raise _lib.VoxelnetHipError("fov_crop_device needs an (N,4) float32 HIP tensor (there is no CPU path)")
@@ -44,5 +47,7 @@ def fov_crop_device(points, P, Tr_velo_to_cam, R_cam_to_rect, image_rows, image_
         _lib.call("vn_fov_crop", points.data_ptr(), n, mats[0].ctypes.data, mats[1].ctypes.data, mats[2].ctypes.data,
                   int(image_rows), int(image_cols), out.data_ptr(), index.data_ptr() if index is not None else None,
                   count.data_ptr(), ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if padded:
+            return (out[:n], count, index) if return_index else (out[:n], count)
         k = int(count.item())
     return (out[:k], index[:k]) if return_index else out[:k]
