@@ -474,6 +474,20 @@ int vn_bn_stats(const void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stri
 int vn_bn_finalize(const double *sums, int64_t M, int32_t C, int32_t fold, const float *shift,
                    const float *gamma, const float *beta, float *running_mean, float *running_var,
                    int32_t training, float momentum, float eps, float *stats, vnStream stream);
+/* vn_bn_finalize_slab + vn_bn_apply in ONE launch (round 4: the small layers' finalize launches are pure latency on the
+ * step's dependency chain): a workgroup owns 8 channels x a range of rows, reduces its 64 B of every slab row in the
+ * order vn_bn_finalize_slab uses and applies; stats, running statistics and a are bit-identical to the two calls. */
+int vn_bn_finalize_apply_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *shift,
+                              const float *gamma, const float *beta, float *running_mean, float *running_var,
+                              float momentum, float eps, float *stats, const void *y, vnDtype y_dtype,
+                              int64_t y_stride, int32_t relu, void *a, vnDtype a_dtype, int64_t a_stride,
+                              vnStream stream);
+/* vn_bn_bwd_finalize_slab + vn_bn_bwd_apply in ONE launch, same construction: coef, d_gamma, d_beta and dy bit-identical. */
+int vn_bn_bwd_finalize_apply_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *gamma,
+                                  const float *stats, float *coef, float *d_gamma, float *d_beta, const void *da,
+                                  vnDtype da_dtype, int64_t da_stride, const void *y, vnDtype y_dtype,
+                                  int64_t y_stride, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
+                                  vnStream stream);
 /* same, from a vn_conv_gather_gemm stats slab: float[rows][2][C] partial sums of (y - shift) */
 int vn_bn_finalize_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *shift,
                         const float *gamma, const float *beta, float *running_mean, float *running_var,

@@ -17,6 +17,7 @@ Bars, written out below where they are asserted:
 Any wrong tap, shifted halo row, swapped tile or stale LDS stage is an O(1) error on the affected elements.
 Checked by breaking k_wgrad_patch's tap shift (tw -> tw+1 for one tap): m1/m2 fail with rel-L2 ~0.3."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -132,19 +133,24 @@ def plan_ids(_lib, spec, B, in_dims):
             lib.vn_conv_wgrad_plan_id(ctypes.byref(gw), 0, 0))
 
 
+# weight-gradient kernel of the wide stride-1 3x3 layers: 44 = the single-tap 128 x 128 row form (default), 202 = the
+# 128 x 64 nine-tap patch tile when the whole test process runs under VN_WGRAD_PATCH=3 (tools/final_run.sh runs this file
+# a second time that way, so the alternative kernel keeps its half-ulp coverage)
+WG9 = 202 if (int(os.environ.get("VN_WGRAD_PATCH", "1")) & 2) else 44
+
 # name, kind, dim, cin, cout, k, stride, pad | test (B, input spatial) | production (B, input spatial) it stands for |
 # expected (forward, data-gradient, weight-gradient) kernel ids (vn_conv_plan_id / vn_conv_wgrad_plan_id)
 CASES = [
     ("middle_layer.1", "conv", 3, 64, 64, 3, (1, 1, 1), (0, 1, 1), (1, (4, 134, 140)), (2, (5, 400, 352)), (103, 103, 200)),
     ("middle_layer.2", "conv", 3, 64, 64, 3, (2, 1, 1), (1, 1, 1), (1, (3, 134, 140)), (2, (3, 400, 352)), (103, 103, 200)),
     ("block1.0", "conv", 2, 128, 128, 3, (2, 2), (1, 1), (2, (400, 352)), (2, (400, 352)), (4, 1, 44)),
-    ("block1.1", "conv", 2, 128, 128, 3, (1, 1), (1, 1), (1, (134, 140)), (2, (200, 176)), (100, 100, 44)),
-    ("deconv1", "deconv", 2, 128, 256, 3, (1, 1), (1, 1), (1, (134, 140)), (2, (200, 176)), (100, 100, 44)),
+    ("block1.1", "conv", 2, 128, 128, 3, (1, 1), (1, 1), (1, (134, 140)), (2, (200, 176)), (100, 100, WG9)),
+    ("deconv1", "deconv", 2, 128, 256, 3, (1, 1), (1, 1), (1, (134, 140)), (2, (200, 176)), (100, 100, WG9)),
     ("block2.0", "conv", 2, 128, 128, 3, (2, 2), (1, 1), (2, (200, 176)), (2, (200, 176)), (1, 4, 44)),
-    ("block2.1", "conv", 2, 128, 128, 3, (1, 1), (1, 1), (2, (100, 88)), (2, (100, 88)), (123, 123, 44)),
+    ("block2.1", "conv", 2, 128, 128, 3, (1, 1), (1, 1), (2, (100, 88)), (2, (100, 88)), (123, 123, WG9)),
     ("deconv2", "deconv", 2, 128, 256, 2, (2, 2), (0, 0), (2, (100, 88)), (2, (100, 88)), (4, 1, 44)),
     ("block3.0", "conv", 2, 128, 256, 3, (2, 2), (1, 1), (2, (100, 88)), (2, (100, 88)), (2, 1, 44)),
-    ("block3.1", "conv", 2, 256, 256, 3, (1, 1), (1, 1), (2, (50, 44)), (2, (50, 44)), (123, 123, 44)),
+    ("block3.1", "conv", 2, 256, 256, 3, (1, 1), (1, 1), (2, (50, 44)), (2, (50, 44)), (123, 123, WG9)),
     ("deconv3", "deconv", 2, 256, 256, 4, (4, 4), (0, 0), (2, (50, 44)), (2, (50, 44)), (4, 2, 44)),
 ]
 

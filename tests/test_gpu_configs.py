@@ -87,6 +87,50 @@ def test_ped_full_size_fp32_maps_and_bf16_step():
     M.set_precision("bf16")
 
 
+def test_car_full_size_batch2_fp32_maps():
+    """BASELINE configs[1] — the shape the metric is quoted on: car grid 10 x 400 x 352, T = 35, BATCH 2 (train-mode
+    BatchNorm statistics over both frames; the full-size car tests of test_gpu_model.py are batch 1): RPN maps of the fp32
+    parity mode vs the reference op sequence (model.py:91-108, 257-281) on this box's CPU, same voxel buffers,
+    <= 1e-3 of the map maximum (BASELINE.json north_star); the benchmarked bf16 mode's distance is reported."""
+    from voxelnet_amd import model as M
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import grid_config
+    grid = grid_config("Car")
+    assert grid.dims == (10, 400, 352) and grid.T == 35 and grid.block1_stride == 2
+    frames = synth.workload_frames(1, batch=2)                    # bench.py's frames (BASELINE configs[1])
+    feats, coords = voxelize_frames(frames, grid)
+    assert len(feats) == 2 and feats[0].shape[1:] == (35, 7)
+    sd = tr.make_state_dict("Car")
+    with torch.no_grad():
+        dense = tr.feature_net([f.cpu() for f in feats], [c.cpu() for c in coords], dict(sd), grid.dims, True)
+        rp, rr = tr.middle_rpn(dense, dict(sd), "Car", True)
+    assert rp.shape == (2, 2, 200, 176) and rr.shape == (2, 14, 200, 176)
+    try:
+        M.set_precision("fp32")
+        m = M.RPN3D("Car")
+        m.load_state_dict(tr.make_state_dict("Car"))
+        m = m.to(DEV).train()
+        with torch.no_grad():
+            prob, reg = m.detect(feats, coords)
+        ep, er = rel_err(prob, rp), rel_err(reg, rr)
+        print(f"car full size batch 2, fp32 mode vs CPU oracle: prob {ep:.2e}, reg {er:.2e}")
+        assert ep < 1e-3 and er < 1e-3, (ep, er)
+        # per sample too: a batch-index mix-up would survive a whole-batch maximum only by luck, not a per-sample one
+        for b in range(2):
+            assert rel_err(prob[b], rp[b]) < 1e-3 and rel_err(reg[b], rr[b]) < 1e-3, b
+        M.set_precision("bf16")
+        m = M.RPN3D("Car")
+        m.load_state_dict(tr.make_state_dict("Car"))
+        m = m.to(DEV).train()
+        with torch.no_grad():
+            prob, reg = m.detect(feats, coords)
+        eb = rel_err(prob, rp), rel_err(reg, rr)
+        print(f"car full size batch 2, bf16 mode vs CPU oracle: prob {eb[0]:.2e}, reg {eb[1]:.2e} (reported; bars: test_gpu_bf16_parity.py)")
+        assert eb[0] < 0.25 and eb[1] < 0.25
+    finally:
+        M.set_precision("bf16")
+
+
 def vfe_oracle_float64(feature, sd, chunk=4096):
     """model.py:93-100 (both VFELayers, model.py:74-82, and the voxel max) in float64, evaluated in three passes over
     chunks of voxels so that the (K,T,128) intermediates of K = 160k, T = 64 never exist at once (train-mode BatchNorm:

@@ -416,6 +416,10 @@ struct vnNet {
     // instead of beside the first layers (where the launch cost 0.03 ms of step time)
     vnPackJob deferred_pack[NL + 1];
     int n_deferred;
+    // round 4: the weight gradients of independent layers run CONCURRENTLY, dealt over the caller's side stream and these
+    // extra streams of the context (tuning aid VN_WG_STREAMS = total number, 1 = the side stream alone); the 128 x 64
+    // nine-tap tile (k_wgrad_patch<2>) takes a quarter of the CUs per launch, so several of them fit beside the main chain
+    hipStream_t wg_stream[3];
     hipEvent_t ring[64];
     unsigned next;
     hipEvent_t next_event() { return ring[next++ & 63]; }
@@ -448,6 +452,7 @@ extern "C" int vn_net_create(vnNet **out) {
         for (int w = 0; w < 2 && err == hipSuccess; ++w) err = hipEventCreateWithFlags(&n->bucket_ev[b][w], hipEventDisableTiming);
     for (int i = 0; i < 64 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&n->ring[i], hipEventDisableTiming);
     for (int i = 0; i < 2 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&n->prep_ev[i], hipEventDisableTiming);
+    for (int i = 0; i < 3 && err == hipSuccess; ++i) err = hipStreamCreateWithFlags(&n->wg_stream[i], hipStreamNonBlocking);
     if (err != hipSuccess) {
         vn_net_destroy(n);
         return (int)err;
@@ -465,6 +470,8 @@ extern "C" int vn_net_destroy(vnNet *n) {
         if (n->ring[i]) (void)hipEventDestroy(n->ring[i]);
     for (int i = 0; i < 2; ++i)
         if (n->prep_ev[i]) (void)hipEventDestroy(n->prep_ev[i]);
+    for (int i = 0; i < 3; ++i)
+        if (n->wg_stream[i]) (void)hipStreamDestroy(n->wg_stream[i]);
     for (int i = 0; i < n->t_made; ++i) {
         (void)hipEventDestroy(n->slots[i].e0);
         (void)hipEventDestroy(n->slots[i].e1);
@@ -547,6 +554,15 @@ int fuse_bwd_reduce_on() {   // tuning aid VN_FUSE_BWD_REDUCE=0: every BatchNorm
 // summing it (measured: 509.7 vs 508.7 point-clouds/s — not worth a shortcut that drops the rounding noise of dy)
 int box_zero_total() {
     static const int v = vn_knob("VN_BOX_ZERO", 0);
+    return v;
+}
+// BatchNorm finalize + apply as one launch (vn_bn_finalize_apply_slab / vn_bn_bwd_finalize_apply_slab) on the layers with
+// at most VN_BN_FUSE_ROWS rows (tuning aid; default 0 = the two launches everywhere).  Bit-identical results, one launch
+// less per BatchNorm and direction — and no faster: round 4 measured the fused launch at >= 6.1 us on the 100 x 88 /
+// 50 x 44 layers against 2.2 + 2.4 us + one boundary for the pair (two dependent memory phases either way), 558 vs 561
+// point-clouds/s with the small layers fused, 527 with the 200 x 176 ones too (16-B pieces of every row per workgroup)
+int64_t bn_fuse_rows() {
+    static const int v = vn_knob("VN_BN_FUSE_ROWS", 0);
     return v;
 }
 int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, int relu, vnStream st) {
@@ -711,7 +727,14 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
             RTT(T_CONV_FWD, l, layer_flops(sp, P.in_dims[l], P.odims[l], cfg->B), rows_bytes(x) + rows_bytes(y), stream,
                 vn_conv_gather_gemm(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, &g, 0, slab, stream));
         }
-        if (slab) {
+        const Rows &a = P.a[l];
+        const bool fuse_fin = slab && M <= bn_fuse_rows() && l != L_M2 && !(l == 0 && cfg->sparse_first);
+        if (fuse_fin) {
+            RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y) + 8.0 * P.slab_rows[l] * sp.cout, stream,
+                vn_bn_finalize_apply_slab(slab, P.slab_rows[l], M, sp.cout, L[l].bias, L[l].gamma, L[l].beta, L[l].running_mean,
+                                          L[l].running_var, mom, eps, P.stats[l], y.ptr, (vnDtype)y.dtype, y.sW, relu_fl, a.ptr,
+                                          (vnDtype)a.dtype, a.sW, stream));
+        } else if (slab) {
             RTT(T_BN_FINALIZE, l, 0.0, 8.0 * P.slab_rows[l] * sp.cout, stream,
                 vn_bn_finalize_slab(slab, P.slab_rows[l], M, sp.cout, L[l].bias, L[l].gamma, L[l].beta, L[l].running_mean,
                                     L[l].running_var, mom, eps, P.stats[l], stream));
@@ -721,8 +744,9 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
             RT(vn_bn_finalize(training ? P.fsums[l] : nullptr, M, sp.cout, 1, L[l].bias, L[l].gamma, L[l].beta,
                               L[l].running_mean, L[l].running_var, training, mom, eps, P.stats[l], stream));
         }
-        const Rows &a = P.a[l];
-        if (l == L_M2) {   // BEV fold: channel d*64 + c of the (B,1,H,W,128) activation
+        if (fuse_fin) {
+            // (applied by the finalize launch above)
+        } else if (l == L_M2) {   // BEV fold: channel d*64 + c of the (B,1,H,W,128) activation
             RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream,
                 vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], relu_fl, a.ptr,
                                 (vnDtype)a.dtype, 128, stream));
@@ -815,12 +839,32 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // data-gradient / BatchNorm-backward launches: fork when dy exists, join before the segment's unpack.
     hipStream_t ws = side_stream ? vn_stream(side_stream) : hs;
     const vnStream wstream = side_stream ? side_stream : stream;
+    hipEvent_t last_fork = nullptr;
     auto fork = [&]() -> int {
         if (ws == hs) return VN_OK;
         hipEvent_t e = net->next_event();
         if (!e) return VN_EINVAL;
         VN_HIP(hipEventRecord(e, hs));
         VN_HIP(hipStreamWaitEvent(ws, e, 0));
+        last_fork = e;
+        return VN_OK;
+    };
+    // extra weight-gradient streams (vnNet::wg_stream): a queued weight gradient goes to stream (counter mod n_wg), 0 = the
+    // side stream itself; the others wait for the fork event first and are joined into the side stream before anything
+    // there reads a partial slab (the unpacks)
+    static const int wg_streams_knob = vn_knob("VN_WG_STREAMS", 1);
+    const int n_wg = ws == hs ? 1 : (wg_streams_knob < 1 ? 1 : (wg_streams_knob > 4 ? 4 : wg_streams_knob));
+    unsigned wg_rr = 0;
+    bool wg_used[3] = {false, false, false};
+    auto join_wg = [&]() -> int {
+        for (int i = 0; i < 3; ++i) {
+            if (!wg_used[i]) continue;
+            hipEvent_t e = net->next_event();
+            if (!e) return VN_EINVAL;
+            VN_HIP(hipEventRecord(e, net->wg_stream[i]));
+            VN_HIP(hipStreamWaitEvent(ws, e, 0));
+            wg_used[i] = false;
+        }
         return VN_OK;
     };
     bool heads_forked = false;     // the side stream already waits for the main stream's state after the heads
@@ -927,7 +971,19 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     auto flush = [&]() -> int {
         if (npend == 0) return VN_OK;
         RT(fork());
-        for (int i = 0; i < npend; ++i) RT(launch_wgrad(pending[i], wstream));
+        for (int i = 0; i < npend; ++i) {
+            const int l = pending[i];
+            // (layers 0 and 1 keep the side stream: their sparse routes are launch sequences with the box sums / unpack)
+            const unsigned k = (n_wg > 1 && l >= 2 && last_fork) ? (wg_rr++ % (unsigned)n_wg) : 0u;
+            if (k == 0) {
+                RT(launch_wgrad(l, wstream));
+            } else {
+                hipStream_t xs = net->wg_stream[k - 1];
+                VN_HIP(hipStreamWaitEvent(xs, last_fork, 0));
+                RT(launch_wgrad(l, reinterpret_cast<vnStream>(xs)));
+                wg_used[k - 1] = true;
+            }
+        }
         npend = 0;
         return VN_OK;
     };
@@ -999,10 +1055,19 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
                                       P.bslab[l], ls));
             const int64_t brows = fused_rows[l] > 0 ? fused_rows[l] : P.bslab_rows[l];
+            const bool fuse_fin = M <= bn_fuse_rows() && !(l == 0 && cfg->sparse_first);
+            if (fuse_fin)
+                RTT(T_BN_BWD_APPLY, l, 0.0, 3.0 * rows_bytes(y) + 8.0 * brows * C, ls,
+                    vn_bn_bwd_finalize_apply_slab(P.bslab[l], brows, M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
+                                                  G[l].beta, da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, 1,
+                                                  dy.ptr, (vnDtype)dy.dtype, dy.sW, ls));
+            else
             RTT(T_BN_FINALIZE, l, 0.0, 8.0 * brows * C, ls,
                 vn_bn_bwd_finalize_slab(P.bslab[l], brows, M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
                                         G[l].beta, ls));
-            if (l == 0 && cfg->sparse_first && !(m0_bn_knob() & 4))
+            if (fuse_fin) {
+                // (applied by the finalize launch above)
+            } else if (l == 0 && cfg->sparse_first && !(m0_bn_knob() & 4))
                 RTT(T_BN_BWD_APPLY, l, 0.0, 0.0, ls,
                     vn_bn_bwd_apply_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
                                             P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW,
@@ -1021,8 +1086,18 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         zj.ptr[zj.n] = G[l].bias; zj.len[zj.n] = C; ++zj.n;          // bias before a train-mode BN: gradient exactly 0
         const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
         // weight gradient: at once when this layer runs on the side stream itself, else queued for the next flush
+        // (tuning aid VN_WG_EARLY, bit l: layer l's weight gradient is forked HERE, in front of its data gradient — it only
+        //  needs dy — instead of behind it with the next flush)
+        static const int wg_early = vn_knob("VN_WG_EARLY", 0);
+        const bool w_early = ws != hs && !on_side && single_call && l >= 1 && ((wg_early >> l) & 1);
         if (on_side) RT(launch_wgrad(l, wstream));
         else if (l == 0 && m0_on_main) RT(launch_wgrad(l, stream));
+        else if (w_early) {
+            const bool had = npend > 0;
+            RT(flush());               // (forks once if anything was queued: the same point of the main stream)
+            if (!had) RT(fork());
+            RT(launch_wgrad(l, wstream));
+        }
         else pending[npend++] = l;
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
@@ -1107,6 +1182,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     int u_done = 0, z_done = 0;
     auto bucket_done = [&](int b) -> int {
         RT(flush());
+        RT(join_wg());
         if (b == 3 && m0_on_main) RT(fork());     // the first layer's partials come from the main stream
         RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack + u_done, nu - u_done), wstream, vn_unpack_wgrads_batch(unpack + u_done, nu - u_done, wstream));
         RT(after_unpack(u_done, nu, wstream));
@@ -1138,6 +1214,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             // measure nothing: 470) and after each Conv3d
             if ((l >= L_B1 && l < L_D1) || l == L_B2 || l == L_B3 || l <= L_M2) RT(flush());
             if (l == L_B1 && tail_balance && early_unpack_on) {
+                RT(join_wg());
                 RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack, nu), wstream, vn_unpack_wgrads_batch(unpack, nu, wstream));
                 RT(after_unpack(0, nu, wstream));
                 u_early = nu;
@@ -1151,6 +1228,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         }
     }
     RT(flush());
+    RT(join_wg());
     if (bucket_ev) return VN_OK;   // everything unpacked / zeroed per group; the caller joins the side stream
     if (ws != hs && cfg->defer_join && seg_end == NL + 1) {
         // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream

@@ -375,28 +375,41 @@ struct WPParams {
     uint32_t src_bytes, rows_bytes;
 };
 
-__global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
+// NH = number of 64-channel halves of the `rows` tile: NH = 1 is the 64 x 64 x nine-tap tile of the 64-channel Conv3d
+// layers (four waves); NH = 2 (round 4) a 128 x 64 x nine-tap tile on EIGHT waves for the 128- / 256-channel 2-D layers:
+// wave (wn, wk) owns rows channels 64 wn .. 64 wn + 63 x source channels 16 wk .. 16 wk + 15 of all nine taps (144
+// accumulator registers, two waves per SIMD).  A stage of 64 sites stages 16 KB of `rows` + 13.8 KB of patch for
+// 9 x 128 x 64 x 64 MACs: 6.3 staged bytes per kMAC against 30.5 for the single-tap 128 x 128 row form (k_wgrad<4,2,.,1,4>),
+// whose step time is its LDS-DMA issue + per-stage synchronisation.  The partial-sum traffic of a weight gradient is
+// 4 B x (tile elements) per workgroup whatever the tile shape, i.e. it only depends on the sites per workgroup; at equal
+// sites per workgroup this tile needs 4.5x fewer workgroups than the single-tap one (2 instead of 9 per row chunk at
+// 128 -> 128 channels): the launch leaves three quarters of the CUs to the main stream's data gradients.
+template <int NH>
+__global__ void __launch_bounds__(256 * NH, 2) k_wgrad_patch(const WPParams p) {
     // LDS patch: 6 lines of 32 rows (18 used: 16 sites + halo) x 128 B.  The line pitch of 32 rows keeps the bank
     // swizzle (a function of row bits 1 and 3) independent of the line, so a tap shift (th lines, tw rows) changes a
     // lane's read address by a compile-time immediate (th) plus one of three precomputed per-lane offsets (tw): the
     // 72 transposed reads of a stage need no address arithmetic.
+    constexpr int NWV = 4 * NH;                              // waves per workgroup
     constexpr int TH = 4, TW = 16, PH = TH + 2, LP = 32;      // 64 sites
-    constexpr int RB = 128;                                  // LDS row bytes: 64 bf16 channels
-    constexpr int TILE_N = 64 * RB;                          // 8 KiB
+    constexpr int RB = 128;                                  // patch row bytes: 64 bf16 source channels
+    constexpr int RBN = 128 * NH;                            // `rows` tile row bytes: 64 NH bf16 channels
+    constexpr int TILE_N = 64 * RBN;                         // 8 / 16 KiB
     constexpr int PATCH = PH * LP * RB;                      // 24 KiB (6 x 18 rows of it loaded)
     constexpr int STAGE = TILE_N + PATCH;
-    constexpr int IN = TILE_N / 4096;                        // DMA instructions per wave: rows tile (2)
+    constexpr int IN = TILE_N / (1024 * NWV);                // DMA instructions per wave: rows tile (2)
+    constexpr int RPI = 1024 / RBN, LPR = RBN / 16;          // rows per DMA instruction, lanes per row
     constexpr int NPP = PH * 3;                              // patch pieces: 3 per line (rows 0-7, 8-15, 16-23)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // wave w owns all 64 `rows` channels x source channels 16w..16w+15 of every tap: the four A (rows) fragments are
+    // wave (wn, wk) owns 64 `rows` channels x source channels 16wk..16wk+15 of every tap: the four A (rows) fragments are
     // read once per K half and shared by the nine taps, a tap costs ONE B fragment (2 transposed reads) per 4 MFMAs —
     // the loop is LDS-read-bound (2 x 2 waves of 32 x 32 needed 160 KB of reads per stage and workgroup, this 104 KB)
-    const int wk = wave;
+    const int wn = wave >> 2, wk = wave & 3;
     const int tile = blockIdx.z;
     const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
-    const int n0 = tn * 64, k0 = tk * 64;
+    const int n0 = tn * 64 * NH, k0 = tk * 64;
     const int kd = blockIdx.y;
     const int64_t ntiles = (int64_t)p.B * p.Dr * p.tiles_y * p.tiles_x;
     const int64_t tbeg = (int64_t)blockIdx.x * p.tiles_per_chunk;
@@ -415,19 +428,19 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
     uint32_t r_dlt[IN], r_chunk[IN];
 #pragma unroll
     for (int i = 0; i < IN; ++i) {
-        const int r = (i * 4 + wave) * 8 + lane / 8;                         // site 0..63
-        const int c = (lane % 8) ^ chunk_swz<RB, false>(r);
+        const int r = (i * NWV + wave) * RPI + lane / LPR;                   // site 0..63
+        const int c = (lane % LPR) ^ chunk_swz<RBN, false>(r);
         r_py[i] = r >> 4; r_px[i] = r & 15;
         r_dlt[i] = (uint32_t)((((int64_t)(r >> 4)) * p.rH + (int64_t)(r & 15) * p.rW) * 2) + (uint32_t)c * 16u;
         r_chunk[i] = (n0 + c * 8) < p.N ? 1u : 0u;
     }
-    constexpr int IPP = (NPP + 3) / 4;
+    constexpr int IPP = (NPP + NWV - 1) / NWV;
     int s_qy[IPP], s_qx[IPP];
     int32_t s_dlt[IPP];
     uint32_t s_ok[IPP], s_lds[IPP];
 #pragma unroll
     for (int i = 0; i < IPP; ++i) {
-        const int piece = i * 4 + wave;
+        const int piece = i * NWV + wave;
         const int ql = piece / 3, cg = piece - ql * 3;
         const int qx = cg * 8 + lane / 8;                                    // column inside the line (0..23; 18.. unused)
         const int prow = ql * LP + qx;
@@ -456,12 +469,12 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
 #pragma unroll
         for (int i = 0; i < IN; ++i) {
             const bool ok = plane_ok && r_chunk[i] && y0 + r_py[i] < p.Hr && x0 + r_px[i] < p.Wr;
-            lds_dma16(rs_r, ln + i * 4096, ok ? rbase + r_dlt[i] : WG_OOB, r_col);
+            lds_dma16(rs_r, ln + i * (1024 * NWV), ok ? rbase + r_dlt[i] : WG_OOB, r_col);
         }
         char *lp = smem + buf * STAGE + TILE_N;
 #pragma unroll
         for (int i = 0; i < IPP; ++i) {
-            if (i * 4 + wave >= NPP) break;
+            if (i * NWV + wave >= NPP) break;
             const bool ok = plane_ok && s_ok[i] && (unsigned)(y0 + s_qy[i]) < (unsigned)p.Hs &&
                             (unsigned)(x0 + s_qx[i]) < (unsigned)p.Ws;
             lds_dma16(rs_s, lp + s_lds[i], ok ? sbase + (uint32_t)s_dlt[i] : WG_OOB, s_col);
@@ -485,14 +498,14 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
     // transposed-read lane geometry: lane = 16g + 4q + pp -> site (ks*32 + 8g + q [+4]), 8-B piece pp of a 16-column tile
     const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
     typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
-    // rows tile: sites r0 = ks*32 + 8g + q and r0 + 4 (ks*32 rows = ks*4096 B: an immediate)
+    // rows tile: sites r0 = ks*32 + 8g + q and r0 + 4 (ks*32 rows = ks*32*RBN B: an immediate)
     int aoff[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int col = i * 16 + pp * 4, c16 = col >> 3, half = (col >> 2) & 1;
+        const int col = (wn * 4 + i) * 16 + pp * 4, c16 = col >> 3, half = (col >> 2) & 1;
         const int r0 = g * 8 + q;
-        aoff[i][0] = r0 * RB + ((c16 ^ chunk_swz<RB, false>(r0)) << 4) + half * 8;
-        aoff[i][1] = (r0 + 4) * RB + ((c16 ^ chunk_swz<RB, false>(r0 + 4)) << 4) + half * 8;
+        aoff[i][0] = r0 * RBN + ((c16 ^ chunk_swz<RBN, false>(r0)) << 4) + half * 8;
+        aoff[i][1] = (r0 + 4) * RBN + ((c16 ^ chunk_swz<RBN, false>(r0 + 4)) << 4) + half * 8;
     }
     // patch: site (line ks*2 + (g>>1), column (g&1)*8 + q [+4]) shifted by tap (th, tw) -> patch row (line + th)*32 + col + tw
     int boff[3][2];
@@ -519,8 +532,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
             bf16x8_t a[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ln + ks * 32 * RB + aoff[i][0]));
-                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ln + ks * 32 * RB + aoff[i][1]));
+                const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ln + ks * 32 * RBN + aoff[i][0]));
+                const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(ln + ks * 32 * RBN + aoff[i][1]));
                 a[i] = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
             }
 #pragma unroll
@@ -531,22 +544,23 @@ __global__ void __launch_bounds__(256, 2) k_wgrad_patch(const WPParams p) {
                 const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)(lt + boff[tw][1]));
                 const bf16x8_t bq = __builtin_bit_cast(bf16x8_t, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], bq, acc[t][i], 0, 0, 0);
+                // operands swapped (source-channel fragment first): the accumulator is the TRANSPOSED tile D[k][n], so a lane
+                // holds four consecutive source channels k of one rows channel n — the epilogue stores 16 B per lane
+                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bq, a[i], acc[t][i], 0, 0, 0);
             }
         }
     }
-    // D[n][k]: n = (lane>>4)*4 + e, k = lane&15 ; tap index kd*9 + t
+    // D[k][n]: k = (lane>>4)*4 + e, n = lane&15 ; tap index kd*9 + t.  One float4 per accumulator (36 store instructions per
+    // wave instead of 144 dword ones: the store tail of a workgroup's 147 / 295 KB is issue-bound, cdna_hip_programming.md T21)
     float *dst = p.part + (int64_t)blockIdx.x * p.part_stride;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int k = k0 + wk * 16 + (lane & 15);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int n = n0 + i * 16 + (lane >> 4) * 4 + e;
-                if (n < p.N && k < p.C) dst[((int64_t)(kd * 9 + t) * p.N + n) * p.C + k] = acc[t][i][e];
-            }
+            const int k = k0 + wk * 16 + (lane >> 4) * 4;
+            const int n = n0 + (wn * 4 + i) * 16 + (lane & 15);
+            if (n < p.N && k < p.C)     // (C is a multiple of 8: k .. k + 3 are in range together)
+                *reinterpret_cast<f32x4_t *>(dst + ((int64_t)(kd * 9 + t) * p.N + n) * p.C + k) = acc[t][i];
         }
 }
 
@@ -606,10 +620,15 @@ static WGPlan wgrad_plan(const vnConv *g, int32_t split, int64_t M) {
 // ---- patch form (k_wgrad_patch): eligibility and chunking
 struct WPPlan {
     bool ok;
+    int nh;               // 64-channel halves of the `rows` tile (k_wgrad_patch<NH>)
     int tiles_x, tiles_y, tiles_n, tiles_k;
     int64_t ntiles, chunks;
 };
-static int wgrad_patch_enabled() {   // tuning aid: VN_WGRAD_PATCH=0 keeps the row form, 2 = also small images
+static int wgrad_patch_enabled() {   // tuning aid: VN_WGRAD_PATCH=0 keeps the row form everywhere, 1 (default) = the patch form on
+    // the 64-channel Conv3d layers, 3 = + the 128 x 64 nine-tap tile (k_wgrad_patch<2>) on the wider stride-1 2-D layers:
+    // measured in round 4 — alone 626 / 802 TFLOP/s on block1.1 / deconv1 at 246 workgroups (the single-tap row form: 427 /
+    // 465), but its partial-sum traffic is 4.5x per workgroup: in the step 554 (96-128 workgroups) ... 541 (256) against
+    // 559-562 point-clouds/s for the row form (DESIGN_HISTORY.md, round 4)
     static const int v = vn_knob("VN_WGRAD_PATCH", 1);
     return v;
 }
@@ -620,19 +639,29 @@ static WPPlan wgrad_patch_plan(const vnConv *g, int32_t split, bool list) {
         g->padW != 1 || g->tmulD != 1 || g->divD != 1 || g->divH != 1 || g->divW != 1)
         return w;
     if (g->Hs != g->Hr || g->Ws != g->Wr) return w;
-    // measured: a win for the 64-channel Conv3d layers (1.3-1.4x); on the 128-channel 200 x 176 layers the four 64 x 64
-    // channel tiles need 2.4x the row chunks (partial-sum traffic) and only tie with the 128 x 128 row form
-    if (wgrad_patch_enabled() < 2 && (g->Hr < 128 || g->Wr < 128 || g->Cr > 64 || g->Cs > 64)) return w;
+    const bool wide = g->Cr > 64;      // 128 x 64 nine-tap tile on eight waves (round 4); else the 64 x 64 four-wave tile
+    if (wide) {
+        if (!(wgrad_patch_enabled() & 2)) return w;
+    } else {
+        // measured (round 2): a win for the 64-channel Conv3d layers (1.3-1.4x) at 400 x 352
+        if (g->Hr < 128 || g->Wr < 128 || g->Cs > 64) return w;
+    }
+    w.nh = wide ? 2 : 1;
     w.tiles_x = (int)vn_ceil_div(g->Wr, 16);
     w.tiles_y = (int)vn_ceil_div(g->Hr, 4);
-    w.tiles_n = (int)vn_ceil_div(g->Cr, 64);
+    w.tiles_n = (int)vn_ceil_div(g->Cr, 64 * w.nh);
     w.tiles_k = (int)vn_ceil_div(g->Cs, 64);
     w.ntiles = (int64_t)g->B * g->Dr * w.tiles_y * w.tiles_x;
     // (one workgroup per CU: in the step these launches run on the side stream beside the data gradients;
     //  128 ... 512 workgroups measure within 1 %, 768 is 3 % slower)
     static const int ptarget = vn_knob("VN_WGP_BLOCKS", 256);   // tuning aid
-    int64_t chunks = ptarget / ((int64_t)g->kD * w.tiles_n * w.tiles_k);
-    if (chunks > w.ntiles / 8) chunks = w.ntiles / 8;
+    // wide tile: the partial-sum traffic (chunks x the whole weight gradient, written here and read back by the unpack)
+    // is what more workgroups cost; VN_WGP2_BLOCKS workgroups and at least VN_WGP2_STAGES stages of 64 sites each
+    static const int ptarget2 = vn_knob("VN_WGP2_BLOCKS", 64);
+    static const int pstages2 = vn_knob("VN_WGP2_STAGES", 10);
+    int64_t chunks = (wide ? ptarget2 : ptarget) / ((int64_t)g->kD * w.tiles_n * w.tiles_k);
+    const int64_t min_stages = wide ? pstages2 : 8;
+    if (chunks > w.ntiles / min_stages) chunks = w.ntiles / min_stages;
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
     w.chunks = chunks;
@@ -651,12 +680,13 @@ extern "C" size_t vn_conv_wgrad_workspace_bytes(const vnConv *g, int32_t split, 
     return (size_t)chunks * (size_t)w.dw_elems * sizeof(float);   // (>= one chunk: vn_conv_wgrad_partials always uses it)
 }
 
-// Which kernel vn_conv_wgrad / vn_conv_wgrad_partials pick for a geometry: 200 = k_wgrad_patch; else
+// Which kernel vn_conv_wgrad / vn_conv_wgrad_partials pick for a geometry: 200 = k_wgrad_patch<1>, 202 = k_wgrad_patch<2>; else
 // 1000 * (three-tap mode) + 10 * TN + TK of k_wgrad<TN, TK, ., .> (tile = 32 TN x 32 TK channels).
 extern "C" int32_t vn_conv_wgrad_plan_id(const vnConv *g, int32_t split, int64_t n_rows) {
     if (!g || g->B <= 0 || g->Dr <= 0 || g->Hr <= 0 || g->Wr <= 0 || g->Cs <= 0 || g->Cr <= 0) return -1;
     const int64_t M = n_rows > 0 ? n_rows : (int64_t)g->B * g->Dr * g->Hr * g->Wr;
-    if (wgrad_patch_plan(g, split, n_rows > 0).ok) return 200;
+    const WPPlan wp = wgrad_patch_plan(g, split, n_rows > 0);
+    if (wp.ok) return wp.nh == 2 ? 202 : 200;
     const WGPlan w = wgrad_plan(g, split, M);
     if (w.tri) return 1000 + 10 * 2 + (w.k128 ? 4 : 2);
     return 10 * (w.n128 ? 4 : 2) + (w.k128 ? 4 : 2);
@@ -768,13 +798,21 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
         q.tiles_per_chunk = (int32_t)vn_ceil_div(wp.ntiles, pchunks);
         pchunks = vn_ceil_div(wp.ntiles, q.tiles_per_chunk);
         q.src_bytes = p.src_bytes; q.rows_bytes = p.rows_bytes;
-        constexpr size_t lds = 2 * (64 * 128 + 6 * 32 * 128);
-        static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_patch),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (attr != hipSuccess) return (int)attr;
         hipStream_t pst = vn_stream(stream);
         const dim3 pgrid((unsigned)pchunks, (unsigned)g->kD, (unsigned)(wp.tiles_n * wp.tiles_k));
-        k_wgrad_patch<<<pgrid, 256, lds, pst>>>(q);
+        if (wp.nh == 2) {
+            constexpr size_t lds = 2 * (64 * 256 + 6 * 32 * 128);
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_patch<2>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (attr != hipSuccess) return (int)attr;
+            k_wgrad_patch<2><<<pgrid, 512, lds, pst>>>(q);
+        } else {
+            constexpr size_t lds = 2 * (64 * 128 + 6 * 32 * 128);
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_patch<1>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (attr != hipSuccess) return (int)attr;
+            k_wgrad_patch<1><<<pgrid, 256, lds, pst>>>(q);
+        }
         VN_LAUNCH_STATUS();
         if (partial_only) {
             *chunks_out = (int32_t)pchunks;
