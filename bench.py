@@ -83,6 +83,23 @@ def cpu_model_string():
     return "unknown"
 
 
+def pin_rank_to_cores(local_rank, local_world):
+    """contiguous slice `local_rank` of the cores this process may run on (contiguous ids share a socket / NUMA node on
+    the usual enumeration) -> the list it was pinned to, or None when there is nothing to split / it is switched off"""
+    if os.environ.get("VN_BENCH_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity") or local_world < 2:
+        return None
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+        per = len(cores) // local_world
+        if per < 1:
+            return None
+        mine = cores[local_rank * per:(local_rank + 1) * per]
+        os.sched_setaffinity(0, mine)
+        return mine
+    except OSError:
+        return None
+
+
 def cpu_baseline(frames_np, cls, T, threads):
     """oracle (kind 'port') on the host cores: B=2 fwd+bwd after one warm step (the metric's shape) and B=1 forward only
     (BASELINE configs[0]); C voxelizer + PyTorch-CPU restatement of the reference's op sequence."""
@@ -152,6 +169,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # N > 1: each rank's host threads on a slice of the cores of their own, set in-process BEFORE the first GPU call (no
+    # taskset / numactl wrapper: a process that has touched the GPU must not exec).  One step costs ~2 ms of one core's
+    # time per rank against ~3.6 ms on the GPU; eight ranks migrating over the same cores is the first thing that would
+    # show in the per-rank enqueue times below.  VN_BENCH_NO_AFFINITY=1 leaves the scheduler alone.
+    affinity = pin_rank_to_cores(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU path)"
     # rehearsal aid (NOT a benchmark configuration): VN_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and uses gloo, so
     # the N>1 code path (broadcast, bucketed all-reduce overlapped with the backward, MAX over ranks) can be
@@ -168,6 +190,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.direct_rccl and world > 1 and not share and os.environ.get("VN_DIRECT_RCCL_UNSAFE") != "1":
+        # the library's own RCCL entry (vn_allreduce_bucket) has only ever run on a ONE-rank communicator (this pool hands
+        # out one GPU per call): it must not be what an 8-GPU measurement silently runs through
+        raise SystemExit("--direct-rccl with N > 1 has never run on two devices: set VN_DIRECT_RCCL_UNSAFE=1 to try it "
+                         "(the default path is torch.distributed over the same RCCL)")
 
     from voxelnet_amd import _lib
     from voxelnet_amd import engine as E
@@ -367,7 +394,16 @@ def main():
               file=sys.stderr)
     assert torch.isfinite(loss).item(), "non-finite loss"
     ranks_in_sync, grad_checksums_equal = None, None
+    per_rank = None
     if world > 1:
+        # what each rank saw, before the MAX: the slowest rank sets `value`; the spread says whether one rank (host-bound,
+        # a slow device) holds the others in the collectives
+        mine = torch.tensor([1e3 * dt / args.steps, 1e3 * t_enq / args.steps], dtype=torch.float64, device=dev)
+        lo_, hi_ = mine.clone(), mine.clone()
+        dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+        per_rank = {"ms_per_step_min": float(lo_[0]), "ms_per_step_max": float(hi_[0]),
+                    "host_enqueue_in_loop_ms_per_step_min": float(lo_[1]), "host_enqueue_in_loop_ms_per_step_max": float(hi_[1])}
         t = torch.tensor([dt, dt_pre or 0.0] + window_dts, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
@@ -401,6 +437,13 @@ def main():
         samples.append(time.perf_counter() - th)
     torch.cuda.synchronize()
     host_free = 1e3 * sorted(samples)[len(samples) // 2]
+    if world > 1:           # the line carries the SLOWEST rank's host cost (and the fastest beside it)
+        hf_ = torch.tensor([host_free], dtype=torch.float64, device=dev)
+        hlo, hhi = hf_.clone(), hf_.clone()
+        dist.all_reduce(hlo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hhi, op=dist.ReduceOp.MAX)
+        per_rank["host_enqueue_ms_per_step_min"], per_rank["host_enqueue_ms_per_step_max"] = float(hlo.item()), float(hhi.item())
+        host_free = float(hhi.item())
     sync_all()
 
     # ---- N > 1: how long the main stream waits for the gradient exchange at the end of a step (the part of the bucketed
@@ -510,6 +553,9 @@ def main():
             "model_flops_fraction_of_peak": value / world * FLOP_PER_PC[args.config] / (peak * 1e12),
         }
         res["library"] = _lib.load().vn_build_info().decode()       # build + every VN_* tuning override in effect
+        if per_rank is not None:
+            per_rank["cpu_affinity_rank0"] = affinity if affinity is None else "%d cores: %d-%d" % (len(affinity), affinity[0], affinity[-1])
+            res["per_rank"] = per_rank          # host_enqueue_ms_per_step above is the MAX over ranks
         if dt_pre is not None:
             res["value_precomputed_targets"] = world * B * args.steps / dt_pre
         if model.grad_reducer is not None:
@@ -566,15 +612,21 @@ def main():
                 ach = f / (t * 1e-3) / 1e12
                 # HBM-side bytes per launch of that family: PMC counters cannot be read in-process; taken from the committed
                 # rocprofv3 --pmc passes of this same command (profiles/, tools/pmc_family.py), car / bf16 / batch 2 only
-                traffic = None
-                pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-                if args.config == "car" and args.precision == "bf16" and B == 2 and os.path.exists(pmc):
-                    with open(pmc) as fh:
-                        traffic = json.load(fh).get("traffic_bytes_per_launch")
+                traffic, traffic_wgrad, traffic_source = None, None, None
+                pmcs = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_traffic.json")) \
+                    if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+                if args.config == "car" and args.precision == "bf16" and B == 2 and pmcs:
+                    with open(os.path.join(ROOT, "profiles", pmcs[-1])) as fh:         # the latest round's passes
+                        pj = json.load(fh)
+                    traffic = pj.get("traffic_bytes_per_launch")
+                    traffic_wgrad = (pj.get("wgrad") or {}).get("traffic_bytes_per_launch")
+                    traffic_source = ("committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of this command, "
+                                      "tools/final_run.sh + tools/pmc_family.py): counters cannot be collected inside this process, "
+                                      "so the figure is NOT measured in this run" % pmcs[-1])
                 res["roofline"] = {
                     "kernel": "k_conv_patch + k_gather_gemm (implicit-GEMM convolutions: forward + data gradient)",
                     "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
-                    "traffic": traffic, "avg_launch_us": 1e3 * t / n, "launches_per_step": n / ns,
+                    "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": 1e3 * t / n, "launches_per_step": n / ns,
                     "gflop_per_step": f / ns / 1e9, "ms_per_step": t / ns,
                     "note": "algorithmic FLOPs (SURVEY.md 8d; the launches that skip constant data — the rulebook first layer, "
                             "the row-list data gradients at its active sites — with the FLOPs they execute) / summed "
@@ -585,7 +637,8 @@ def main():
                     nw, tw_, fw_, _ = fam[2]
                     res["roofline_wgrad"] = {"kernel": "k_wgrad / k_wgrad_patch (weight gradients)", "bound": "mfma",
                                              "achieved": fw_ / (tw_ * 1e-3) / 1e12, "peak": peak, "unit": "TFLOP/s",
-                                             "frac": fw_ / (tw_ * 1e-3) / 1e12 / peak, "launches_per_step": nw / ns, "ms_per_step": tw_ / ns}
+                                             "frac": fw_ / (tw_ * 1e-3) / 1e12 / peak, "launches_per_step": nw / ns, "ms_per_step": tw_ / ns,
+                                             "traffic": traffic_wgrad, "traffic_source": traffic_source}
                 # FLOPs the MFMA pipes actually execute in a step (first layer: rulebook, not dense-equivalent)
                 fx = sum(fam.get(k, (0, 0, 0, 0))[2] for k in (0, 1, 2)) / ns
                 res["executed_mfma_flops_fraction_of_peak"] = fx / (1e-3 * res["ms_per_step"]) / (peak * 1e12)

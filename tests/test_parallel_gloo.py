@@ -87,3 +87,38 @@ def test_bucket_plan_covers_every_parameter_in_backward_order():
     assert abs(sum(sizes) - 27.24) < 0.01
     assert sizes[0] > sizes[1] > sizes[2] > sizes[3]          # heads+deconv3+block3 first and largest
     assert all(parallel.group_of(k) for k, _ in named)
+
+
+def test_bench_pins_each_rank_to_its_own_slice_of_the_cores():
+    """bench.py (N > 1): every rank restricts itself to a contiguous slice of the cores before its first GPU call
+    (eight ranks on one host is the first multi-GPU run this code will see)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    before = sorted(os.sched_getaffinity(0))
+    if len(before) < 2:
+        pytest.skip("one core")
+    try:
+        a = bench.pin_rank_to_cores(0, 2)
+        assert a == before[:len(before) // 2] and sorted(os.sched_getaffinity(0)) == a
+        os.sched_setaffinity(0, before)
+        b = bench.pin_rank_to_cores(1, 2)
+        assert b == before[len(before) // 2:2 * (len(before) // 2)] and not set(a) & set(b)
+        os.sched_setaffinity(0, before)
+        assert bench.pin_rank_to_cores(0, 1) is None and sorted(os.sched_getaffinity(0)) == before     # one rank: untouched
+        assert bench.pin_rank_to_cores(0, 10 * len(before)) is None                                      # fewer cores than ranks
+    finally:
+        os.sched_setaffinity(0, before)
+
+
+def test_direct_rccl_is_refused_for_more_than_one_rank(monkeypatch):
+    """the library's own RCCL wrapper has only ever run on a one-rank communicator: GradAllReducer(direct_rccl=True) must not
+    become the path of a multi-GPU run silently (bench.py --direct-rccl raises the same way before any GPU work)"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "voxelnet-pytorch_amd", "voxelnet_amd", "parallel.py")).read()
+    assert re.search(r"self\.world > 1 and os\.environ\.get\(\"VN_DIRECT_RCCL_UNSAFE\"\) != \"1\"", src)
+    bsrc = open(os.path.join(root, "bench.py")).read()
+    assert "VN_DIRECT_RCCL_UNSAFE" in bsrc and "raise SystemExit" in bsrc

@@ -1,12 +1,16 @@
 # round-end measurement set (run on the GPU box through gpurun): tests, smoke, bench (three configs), rocprofv3 kernel
 # stats of the SAME command, the two HBM-traffic PMC passes and the MFMA-busy PMC pass (each --pmc pass on its own, never
 # combined with tracing).  Summaries are copied to profiles/ by hand afterwards (gpurun_out/ is scratch).
-R=${R:-r03}
+R=${R:-r04}
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 set -e
 cd $GRAFT_REPO_ROOT
 python -m pytest tests/ -m gpu -x -q > gpurun_out/final_tests.log 2>&1
 tail -3 gpurun_out/final_tests.log
+# the alternative weight-gradient tile (k_wgrad_patch<2>, not the default: DESIGN_HISTORY.md round 4) keeps its half-ulp
+# coverage: the knobs are read once per process, so the parity file runs a second time under it
+VN_WGRAD_PATCH=3 VN_NO_DDP_REHEARSAL=1 python -m pytest tests/test_gpu_bf16_parity.py -m gpu -x -q -k layer_stages > gpurun_out/final_tests_wgp3.log 2>&1
+tail -1 gpurun_out/final_tests_wgp3.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1
 tail -1 gpurun_out/final_smoke.log
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
@@ -27,6 +31,9 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU 
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY -d $O/fpmc_vfe_b -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_vfe_b.log 2>&1
 cd $GRAFT_REPO_ROOT
 python tools/pmc_counters.py k_vfe 3 gpurun_out/fpmc_vfe_a gpurun_out/fpmc_vfe_b > gpurun_out/${R}_pmc_vfe.txt 2>&1 || true
+# (every post-processing script takes "the last 3 steps of the profiled run" and finds the step boundaries itself: the
+#  profiled command also runs warm-up / window / host-enqueue steps, 17 in all — round 3's per-step header divided all of
+#  them by 3)
 python tools/pmc_traffic.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 > gpurun_out/${R}_pmc_traffic_per_kernel.txt
 python tools/pmc_family.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 gpurun_out/${R}_pmc_traffic.json
 python tools/pmc_mfma.py gpurun_out/fpmc_mfma 3 gpurun_out/${R}_pmc_mfma_per_kernel.txt | head -40

@@ -76,6 +76,13 @@ class GradAllReducer:
         if direct_rccl is None:
             direct_rccl = os.environ.get("VN_DIRECT_RCCL") == "1"
         if direct_rccl and self.cuda:
+            if self.world > 1 and os.environ.get("VN_DIRECT_RCCL_UNSAFE") != "1":
+                # vn_allreduce_bucket has only ever run on a one-rank communicator (the build pool hands out one GPU per
+                # call): refuse to be the path of a multi-GPU run until someone asks for it by name
+                from . import _lib
+                raise _lib.VoxelnetHipError("GradAllReducer(direct_rccl=True) with world size %d: the library's own RCCL entry has "
+                                            "never run on two devices — set VN_DIRECT_RCCL_UNSAFE=1 to try it; the default "
+                                            "(torch.distributed, backend nccl = the same RCCL) needs nothing" % self.world)
             self._init_direct()
         self.reset()
 
