@@ -419,9 +419,12 @@ int vn_net_wait_bucket(vnNet *net, int32_t bucket, vnStream stream);
  * cfg->prepared for vn_net_forward.  The forward's stream need not wait for this one: vn_net_prepare records, on the
  * vnNet, one event behind what the first layer needs (issued first) and one behind the rest of the weight packing, and
  * vn_net_forward waits for the first at its start and for the second in front of the second layer.
- * Two-call form: heads_w == NULL issues only the first layer's needs (event 0) and returns; the next call, with heads_w,
- * issues only the rest (event 1) — for a caller whose heads_w is itself produced on that stream (a concatenation of the
- * two heads' parameters) and should not sit in front of the site list. */
+ * cfg->prepared names the PHASE of a vn_net_prepare call: 0 = everything in one call; 1 = only the first layer's needs
+ * (event 0; heads_w may be NULL) and return; 2 = only the rest (event 1), valid only right after a phase-1 call for the
+ * same workspace, coord, K and grid (else VN_EINVAL) — for a caller whose heads_w is itself produced on that stream (a
+ * concatenation of the two heads' parameters) and should not sit in front of the site list.  An error return clears the
+ * protocol state; vn_net_forward with cfg->prepared != 0 returns VN_EINVAL unless the prepare was issued for ITS
+ * workspace / coord / K / grid, and consumes it. */
 int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers, const float *heads_w,
                    const int64_t *coord, int64_t K, void *workspace, size_t workspace_bytes, vnStream stream);
 int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *layers /*[23]*/,

@@ -263,3 +263,63 @@ def test_rccl_wrapper_one_rank_and_reducer_direct_path(golden):
             m.grad_reducer.close()
     for k in res[0]:
         assert torch.allclose(res[0][k], res[1][k], rtol=1e-5, atol=1e-7), k
+
+
+def test_prepare_protocol_is_explicit_and_checked(golden):
+    """vn_net_prepare's phases are named by cfg->prepared (0 whole / 1 first layer's needs / 2 the rest) and checked: a
+    phase 2 without (or for another step than) its phase 1, and a vn_net_forward that claims `prepared` without a prepare
+    for ITS workspace / K, return VN_EINVAL instead of running on stale packed weights (round-3 advisor finding); an
+    error leaves no half-issued state behind, and the normal sequence still works afterwards."""
+    from voxelnet_amd import _lib
+    from voxelnet_amd import engine as E
+    from voxelnet_amd import model as M
+    feats, coords = tiny_batch(golden)
+    m = make_model("bf16").train()
+    lib = _lib.load()
+    mid = m.middle_rpn
+    arr, _ = M._native_layer_arrays(mid)
+    coord = torch.cat(coords).contiguous()
+    K = coord.shape[0]
+    cfg = _lib.VnNetConfig(2, 10, 16, 24, mid._block1_stride, 0, 1, 1, 0, 0)
+    nb = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    ws2 = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    net = m._net_handle(torch.device(DEV))
+    heads = M._heads_params([p.detach() for p in m._flat_params()[-4:]])
+    hw, hb = heads["weight"], heads["bias"]
+    side = torch.cuda.Stream()
+    st, sd = E.stream(), ctypes.c_void_p(side.cuda_stream)
+    EINVAL = -1
+
+    def prepare(phase, w=ws, k=K, heads_ptr=hw.data_ptr()):
+        cfg.prepared = phase
+        return lib.vn_net_prepare(net, ctypes.byref(cfg), arr, heads_ptr if phase != 1 else None, coord.data_ptr(), k, w.data_ptr(), nb, sd)
+
+    vw = torch.zeros((K, 128), dtype=torch.bfloat16, device=DEV)
+    prob = torch.empty((2, 2, 8, 12), device=DEV)
+    reg = torch.empty((2, 14, 8, 12), device=DEV)
+
+    def forward(w=ws, prepared=1):
+        cfg.prepared = prepared
+        return lib.vn_net_forward(net, ctypes.byref(cfg), arr, hw.data_ptr(), hb.data_ptr(), None, coord.data_ptr(), vw.data_ptr(), K,
+                                  w.data_ptr(), nb, prob.data_ptr(), reg.data_ptr(), st, sd)
+    torch.cuda.synchronize()
+    assert prepare(2) == EINVAL                                   # phase 2 without a phase 1
+    assert forward() == EINVAL                                    # "prepared" without any prepare
+    assert prepare(1) == 0 and prepare(2, w=ws2) == EINVAL        # phase 2 for another workspace
+    assert prepare(2) == EINVAL                                   # ... and the failed call cleared the first phase
+    assert prepare(1) == 0 and prepare(2, k=K - 1) == EINVAL      # phase 2 for another K
+    assert prepare(0, heads_ptr=None) == EINVAL                   # the one-call form needs the heads' weights
+    assert prepare(1) == 0 and prepare(2) == 0
+    assert forward(w=ws2) == EINVAL                               # prepared, but for another arena
+    assert forward() == EINVAL                                    # ... which also consumed / dropped the prepare
+    assert prepare(1) == 0 and prepare(2) == 0 and forward() == 0
+    assert forward() == EINVAL                                    # one forward per prepare
+    assert prepare(0) == 0 and forward() == 0                     # the one-call form
+    assert forward(prepared=0) == 0                               # and the forward that prepares for itself
+    torch.cuda.synchronize()
+    assert torch.isfinite(prob).all() and torch.isfinite(reg).all()
+    # the module path (two-phase prepare on its side stream) is unaffected
+    p1, r1 = m.detect(feats, coords)
+    torch.cuda.synchronize()
+    assert torch.isfinite(p1).all()

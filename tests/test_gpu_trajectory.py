@@ -73,3 +73,59 @@ def test_train_trajectory(golden, mode):
     floor, wm, mm = (1e-3, 2.0, 3.0) if mode == "fp32" else (3e-2, 2.0, 3.0)
     check_trajectory(g, losses, floor, 3.0, f"HIP {mode}")
     check_final_state(g, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, steps, f"HIP {mode}", wm, mm)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+def test_overfit_200_steps_with_positives(golden, mode):
+    """tests/golden/overfit_tiny.npz: 200 iterations over four frames whose labels give positive anchors in every batch
+    from the first step (regression loss and its quirk, loss.py:9, active throughout), against the imported reference's
+    fp32 loop — per iteration within max(floor, 3 x the reference's own fp32-vs-fp64 band), the last 20 iterations' mean
+    loss within 5 % (the band the reference itself stays in on these settings), and the loss falls below a third of its
+    start.  The targets come from the labels INSIDE RPN3D.forward on the target stream (no target_fn: the early-targets
+    path of the benchmarked step), with the fixture's 24 x 24 anchor grid installed as the module's generator."""
+    from trajectory_common import check_overfit, overfit_clouds, overfit_state_dict
+    from voxelnet_amd import model as M
+    from voxelnet_amd.optim import ClipSGD
+    from voxelnet_amd.targets import TargetGenerator
+    from voxelnet_amd.voxelize import voxelize_device
+    g = golden("overfit_tiny")
+    steps = int(g["steps"])
+    grid = traj_grid(g)
+    try:
+        M.set_precision(mode)
+        m = M.RPN3D("Car")
+        m.load_state_dict(overfit_state_dict(g, tr.make_state_dict))
+        m.feature_net._grid = replace(m.feature_net._grid, H=grid.H, W=grid.W)
+        m = m.to(DEV)
+        gen = TargetGenerator("Car", torch.device(DEV), anchors=g["anchors"])
+        m.__dict__["_targets"] = gen                      # what RPN3D._target_generator caches: forward() finds it and
+        m.anchors = gen.anchors                           # generates the targets itself, on its target stream
+        assert m.target_fn is None
+        batches = []
+        for j in range(2):
+            feats, coords, nums = [], [], []
+            for i, cloud in enumerate(overfit_clouds(g, j)):
+                f, c, n = voxelize_device(torch.from_numpy(cloud).to(DEV), grid, i, coord_cols=4)
+                feats.append(f); coords.append(c); nums.append(n)
+            assert [f.shape[0] for f in feats] == list(g[f"K{j}"])
+            labels = fixture_labels(g, j)
+            check_targets(g, j, *[t.cpu().numpy() for t in gen(labels)], tgt_rtol=1e-6)
+            batches.append(([f"b{j}s0", f"b{j}s1"], labels, feats, nums, coords, None, None))
+        opt = ClipSGD(m.parameters(), lr=float(g["lr"]), max_norm=float(g["clip"]))
+        losses = []
+        for it in range(steps):
+            m.train(True)
+            out = m(batches[int(g["order"][it])], DEV)
+            out[2].backward()
+            opt.step()
+            opt.zero_grad()
+            if it == 0:
+                np.testing.assert_allclose([float(v) for v in out[2:]], g["scalars"][0], rtol=1e-4 if mode == "fp32" else 2e-2, atol=1e-5)
+            losses.append(float(out[2]))
+        torch.cuda.synchronize()
+        assert m.__dict__.get("_tgt_stream") is not None          # the early-targets path ran
+        assert np.isfinite(losses).all()
+        check_overfit(g, losses, 1e-3 if mode == "fp32" else 3e-2, 3.0, f"HIP {mode}")
+        check_final_state(g, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, steps, f"HIP {mode}", 2.0, 3.0)
+    finally:
+        M.set_precision("bf16")

@@ -53,8 +53,10 @@ def check_trajectory(g, losses, floor, mult, what):
     ref = g["scalars"][:, 0]
     dev = np.abs(np.asarray(losses) - ref) / np.abs(ref)
     tol = np.maximum(floor, mult * band)
-    print(f"{what}: loss deviation per iteration   ", " ".join(f"{d:.1e}" for d in dev))
-    print(f"{what}: tolerance (floor {floor:g}, {mult:g} x band)", " ".join(f"{t:.1e}" for t in tol))
+    every = 1 if len(dev) <= 40 else 10
+    note = "" if every == 1 else f" (every {every}th; max {dev.max():.1e})"
+    print(f"{what}: loss deviation per iteration{note}   ", " ".join(f"{d:.1e}" for d in dev[::every]))
+    print(f"{what}: tolerance (floor {floor:g}, {mult:g} x band)", " ".join(f"{t:.1e}" for t in tol[::every]))
     bad = np.flatnonzero(dev > tol)
     assert bad.size == 0, (what, [(int(i), float(dev[i]), float(tol[i])) for i in bad])
     return dev
@@ -85,3 +87,40 @@ def check_final_state(g, state, steps, what, worst_mult=2.0, median_mult=3.0):
     print(f"{what}: final state vs the reference's fp32 run: worst rel-L2 {worst[0]:.2e} ({worst[1]}), median {med:.2e}; "
           f"reference fp32 vs fp64: worst {max(bands):.2e}, median {float(np.median(bands)):.2e}")
     assert worst[0] <= worst_mult * max(bands) and med <= max(1e-3, median_mult * float(np.median(bands))), (what, worst, med)
+
+
+# ---- tests/golden/overfit_tiny.npz: 200 iterations over four frames, positives from step 0 (tools/gen_golden.py overfit)
+def overfit_clouds(g, j):
+    """the two clouds of overfit batch j, rebuilt from the seeds of tools/gen_golden.py::ovf_cloud"""
+    grid = traj_grid(g)
+    out = []
+    for i in range(2):
+        cloud = synth.synth_cloud("Car", k0=400 + 30 * i + 12 * j, seed=700 + 10 * j + i, grid=grid, overflow_frac=0.03)
+        np.random.default_rng(90 + 10 * j + i).shuffle(cloud)
+        out.append(cloud)
+    return out
+
+
+def overfit_state_dict(g, make_state_dict):
+    """tools/gen_golden.py::ovf_state_dict: the closed-form initial state with the regression head scaled by g['reg_scale']"""
+    sd = make_state_dict("Car")
+    for k in ("middle_rpn.reg_conv.conv.weight", "middle_rpn.reg_conv.conv.bias"):
+        sd[k] = sd[k] * float(g["reg_scale"])
+    return sd
+
+
+def check_overfit(g, losses, floor, mult, what, tail=20, tail_floor=0.05):
+    """200-step overfit run: (1) every iteration within max(floor, mult x running maximum of the reference's own fp32-vs-fp64
+    band); (2) the mean loss of the last `tail` iterations within max(tail_floor, 2 x that band's tail value) of the
+    reference's fp32 run — tail_floor = 5 %, the band the verdict asked the reference itself to stay in; (3) the run DID
+    overfit: that mean is below a third of the first loss, as the reference's is."""
+    dev = check_trajectory(g, losses, floor, mult, what)
+    ref, ref64 = g["scalars"][:, 0], g["scalars64"][:, 0]
+    band_tail = abs(ref[-tail:].mean() - ref64[-tail:].mean()) / abs(ref64[-tail:].mean())
+    got = float(np.mean(losses[-tail:]))
+    rel = abs(got - ref[-tail:].mean()) / abs(ref[-tail:].mean())
+    print(f"{what}: mean loss of the last {tail} iterations {got:.4f} (reference fp32 {ref[-tail:].mean():.4f}, fp64 "
+          f"{ref64[-tail:].mean():.4f}: {band_tail:.2e} apart); deviation {rel:.2e}; first loss {losses[0]:.3f}")
+    assert rel <= max(tail_floor, 2.0 * band_tail), (what, rel, band_tail)
+    assert got < losses[0] / 3.0 and ref[-tail:].mean() < ref[0] / 3.0
+    return dev

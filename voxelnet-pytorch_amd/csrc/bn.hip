@@ -85,6 +85,7 @@ __device__ __forceinline__ void block_reduce_slab(const float s1[8], const float
 __global__ void __launch_bounds__(256) k_bn_stats(const void *__restrict__ y, int dtype, int64_t M, int C,
                                                   int64_t stride, int fold, const float *__restrict__ shift,
                                                   double *__restrict__ sums) {
+    VN_PRIO_MAIN();
     const int groups = C >> 3, rpb = 256 / groups;
     const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
     const int creal = C / fold;
@@ -112,6 +113,7 @@ __global__ void __launch_bounds__(256) k_bn_finalize(const double *__restrict__ 
                                                      const float *__restrict__ beta, float *running_mean,
                                                      float *running_var, int training, float momentum, float eps,
                                                      float *__restrict__ stats) {
+    VN_PRIO_MAIN();
     const int creal = C / fold;
     for (int c = threadIdx.x; c < creal; c += blockDim.x) {
         double mean, var;
@@ -151,6 +153,7 @@ __global__ void __launch_bounds__(256) k_bn_finalize_slab(const float *__restric
                                                           const float *__restrict__ beta, float *running_mean,
                                                           float *running_var, float momentum, float eps,
                                                           float *__restrict__ stats) {
+    VN_PRIO_MAIN();
     // This launch sits on the dependency chain 46 times per step and is pure latency: the per-channel parameters are
     // requested before the slab loop (not after the reduction: one memory round trip less), and the 256 partial sums
     // meet through wave shuffles + one barrier (fixed order: deterministic) instead of an 8-barrier LDS tree.
@@ -208,6 +211,7 @@ __global__ void __launch_bounds__(256) k_bn_apply(const void *__restrict__ y, in
                                                   int adt, int64_t astride, int64_t lo_off, int64_t fold,
                                                   const uint8_t *__restrict__ flags, const float *__restrict__ inactive,
                                                   int hoist) {
+    VN_PRIO_MAIN();
     const int groups = C >> 3;
     const int64_t total = M * groups;
     {
@@ -276,6 +280,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const void *__restrict__ 
                                                        int C, const float *__restrict__ stats, int relu,
                                                        double *__restrict__ sums, float *__restrict__ slab, int64_t fold,
                                                        const uint8_t *__restrict__ flags, const float *__restrict__ inactive) {
+    VN_PRIO_MAIN();
     const int groups = C >> 3, rpb = 256 / groups;
     const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
     float mean[8], invstd[8], S[8], be[8], yin[8];
@@ -347,6 +352,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize_slab(const float *__res
                                                               const float *__restrict__ gamma,
                                                               const float *__restrict__ stats, float *__restrict__ coef,
                                                               float *__restrict__ d_gamma, float *__restrict__ d_beta) {
+    VN_PRIO_MAIN();
     __shared__ double r1[4], r2[4];   // (same shape as k_bn_finalize_slab: parameters first, shuffles + one barrier)
     const int c = blockIdx.x;
     float invstd = 0.f, p_gamma = 0.f;
@@ -379,6 +385,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize(const double *__restric
                                                          const float *__restrict__ gamma,
                                                          const float *__restrict__ stats, float *__restrict__ coef,
                                                          float *__restrict__ d_gamma, float *__restrict__ d_beta) {
+    VN_PRIO_MAIN();
     const int creal = C / fold;
     for (int c = threadIdx.x; c < creal; c += blockDim.x) {
         double s1 = 0.0, s2 = 0.0;
@@ -406,6 +413,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const void *__restrict__ d
                                                       const float *__restrict__ coef, int relu, void *__restrict__ dy,
                                                       int dydt, int64_t dystride, int64_t lo_off,
                                                       const uint8_t *__restrict__ flags, int64_t fold) {
+    VN_PRIO_MAIN();
     // flags != NULL: rows with flag 0 are skipped (their dy is never read by the caller's consumers)
     const int groups = C >> 3;
     if (256 % groups == 0) {
@@ -460,6 +468,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_list(const void *__restric
                                                            int relu, void *__restrict__ dy, int dydt,
                                                            const int64_t *__restrict__ list, const int32_t *__restrict__ count,
                                                            int64_t cap, int da_compact) {
+    VN_PRIO_MAIN();
     const int groups = C >> 3, rpb = 256 / groups;
     const int c = (threadIdx.x % groups) << 3, rr = threadIdx.x / groups;
     if (rr >= rpb) return;
@@ -504,6 +513,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_list(const void *__restri
                                                             const float *__restrict__ stats, int relu,
                                                             float *__restrict__ slab, const int64_t *__restrict__ list,
                                                             const int32_t *__restrict__ count, int64_t cap) {
+    VN_PRIO_MAIN();
     __shared__ float red[256 * 24];
     const int groups = C >> 3, rpb = 256 / groups;
     const int g = threadIdx.x % groups, c = g << 3, rr = threadIdx.x / groups;
@@ -553,6 +563,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize_list(const float *__res
                                                               const float *__restrict__ total, const float *__restrict__ inactive,
                                                               int ydt, int relu, float *__restrict__ coef,
                                                               float *__restrict__ d_gamma, float *__restrict__ d_beta) {
+    VN_PRIO_MAIN();
     __shared__ double r1[256], r2[256], r3[256];
     const int c = blockIdx.x;
     double a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -591,6 +602,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_finalize_list(const float *__res
 constexpr int BOX_EB = 16;
 __global__ void __launch_bounds__(256) k_box_partials(const void *__restrict__ x, int dt, int B, int D, int H, int W, int C,
                                                       int nb, float *__restrict__ slab) {
+    VN_PRIO_MAIN();
     __shared__ float red[256 * 8];
     const int groups = C >> 3, rpb = 256 / groups;
     const int g = threadIdx.x % groups, c = g << 3, rr = threadIdx.x / groups;
@@ -648,6 +660,7 @@ __global__ void __launch_bounds__(256) k_box_partials(const void *__restrict__ x
 // depth tap in range: no padding in D).  One workgroup per input channel ci (every workgroup re-reduces the small slab).
 __global__ void __launch_bounds__(256) k_box_total(const float *__restrict__ slab, int nb, int Co, int Ci, int kD,
                                                    const float *__restrict__ w, int w_bf16, float *__restrict__ total) {
+    VN_PRIO_MAIN();
     __shared__ double part[4][256];    // [row quarter][co]
     __shared__ double edge[8][256];
     __shared__ double box[9][256];     // [3*hc + wc][co]: hc / wc 0 = exclude first, 1 = all, 2 = exclude last
@@ -932,6 +945,7 @@ struct FinApply {
 
 template <bool BWD>
 __global__ void __launch_bounds__(256) k_bn_fin_apply(const FinApply p) {
+    VN_PRIO_MAIN();
     __shared__ double r1[4][8], r2[4][8];
     __shared__ float cst[6][8];
     const int split = blockIdx.x % p.splits, cg = blockIdx.x / p.splits;
@@ -1181,6 +1195,7 @@ __global__ void __launch_bounds__(256) k_act_delta_rows(const void *__restrict__
                                                         int ydt, int relu, const int64_t *__restrict__ list,
                                                         const int32_t *__restrict__ count, int64_t cap,
                                                         void *__restrict__ out, int odt) {
+    VN_PRIO_MAIN();
     const int groups = C >> 3, rpb = 256 / groups;
     const int c = (threadIdx.x % groups) << 3, rr = threadIdx.x / groups;
     if (rr >= rpb) return;
@@ -1206,6 +1221,7 @@ __global__ void __launch_bounds__(256) k_act_delta_rows(const void *__restrict__
 __global__ void __launch_bounds__(256) k_wgrad_const_add(float *__restrict__ dw, const float *__restrict__ slab, int nb, int Co,
                                                          int Ci, int kD, const float *__restrict__ stats,
                                                          const float *__restrict__ inactive, int ydt, int adt, int relu) {
+    VN_PRIO_MAIN();
     __shared__ double sums[9];         // Tot, then the eight edges
     __shared__ float box[9];
     const int co = blockIdx.x;

@@ -20,6 +20,17 @@ static inline hipStream_t vn_stream(vnStream s) { return reinterpret_cast<hipStr
 static inline int64_t vn_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline size_t vn_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 
+// Wave priority of the kernels on the step's dependency chain (convolutions, BatchNorm passes, VFE, loss): the weight
+// gradients of the side stream keep the default 0.  Two waves of different kernels on one SIMD are arbitrated by priority,
+// then AGE (MI355X_MICROARCH.md, "Two waves per SIMD"): the long-lived weight-gradient waves are always the older ones, so
+// at equal priority the chain's short kernels lose every issue slot they contend for.  -DVN_MAIN_PRIO=n builds set
+// s_setprio n at the top of those kernels (round 4 A/B; 0 / undefined = no instruction).
+#if defined(VN_MAIN_PRIO) && VN_MAIN_PRIO > 0
+#define VN_PRIO_MAIN() __builtin_amdgcn_s_setprio(VN_MAIN_PRIO)
+#else
+#define VN_PRIO_MAIN() ((void)0)
+#endif
+
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;

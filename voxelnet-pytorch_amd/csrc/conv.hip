@@ -210,6 +210,7 @@ __device__ __forceinline__ void gg_store(const GGParams &p, f32x4_t (&acc)[SM][4
 // the small late layers — 4400 rows x 2304 K — are latency-bound, not bandwidth-bound, and want a deep pipeline)
 template <int WM, int WN, int SM, int NS, bool F32>
 __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
+    VN_PRIO_MAIN();
     static_assert(WM * WN == 4 && NS >= 2 && SM >= 1 && SM <= 8, "4 waves");
     constexpr int ESZ = F32 ? 4 : 2;          // a K step is always 128 B of every row: 64 bf16 or 32 fp32
     constexpr int BM = 16 * SM * WM, BN = 64 * WN;
@@ -516,6 +517,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
 // A pieces per tap step: (TH+2)(TW+2)/(8*9*4) per wave (~0.8) instead of BM/32 (5-8).
 template <int WM, int WN, int SM, int TW, bool F32>
 __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
+    VN_PRIO_MAIN();
     constexpr int ESZ = F32 ? 4 : 2;
     constexpr int BM = 16 * SM * WM, BN = 64 * WN, TH = BM / TW;
     static_assert(WM * WN == 4 && BM % TW == 0, "4 waves; whole patch lines");
@@ -715,6 +717,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
 // each SIMD, so that one wave's DMA issue runs beside the other's MFMAs (round 3).
 template <int WM, int WN, int SM, int TW, int NSB, bool F32>
 __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_patch2d(const GGParams p) {
+    VN_PRIO_MAIN();
     constexpr int ESZ = F32 ? 4 : 2;
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int BM = 16 * SM * WM, BN = 64 * WN, TH = BM / TW;

@@ -16,6 +16,7 @@ typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __global__ void __launch_bounds__(256) k_heads_fwd(const bf16_t *__restrict__ cat, int64_t cat_stride,
                                                    const bf16_t *__restrict__ w /* [16][768] */, const float *__restrict__ bias,
                                                    int B, int64_t S, float *__restrict__ prob, float *__restrict__ reg) {
+    VN_PRIO_MAIN();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     bf16x8_t Bf[24];
@@ -64,6 +65,7 @@ __global__ void __launch_bounds__(256) k_heads_fwd(const bf16_t *__restrict__ ca
 __global__ void __launch_bounds__(256) k_heads_dgrad(const bf16_t *__restrict__ drows /* [M][16] */, int64_t drows_stride,
                                                      const bf16_t *__restrict__ wd /* [768][16] */, bf16_t *__restrict__ dcat,
                                                      int64_t dcat_stride, int64_t M) {
+    VN_PRIO_MAIN();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     // MFMA row r = 4g + e of tile h of pair p <-> channel 32p + 8g + 4h + e: a lane (rows 4*fq .. +3 of both tiles) ends up
@@ -105,6 +107,7 @@ template <bool OUT_F32>
 __global__ void __launch_bounds__(192) k_heads_dgrad_f32(const float *__restrict__ drows, int64_t drows_stride,
                                                          const float *__restrict__ w /* [16][768] */, void *__restrict__ dcat,
                                                          int64_t dcat_stride, int64_t M) {
+    VN_PRIO_MAIN();
     const int cg = threadIdx.x % 96, rr = threadIdx.x / 96;      // channel group (8 channels), row slot 0/1
     float W[16][8];
 #pragma unroll

@@ -19,6 +19,7 @@ constexpr int NORM_CHUNKS = 64;   // workgroups per sample in the normaliser red
 // part[(b*NORM_CHUNKS + chunk)*2 + {0,1}] = partial sums of pos / neg ; combined in fixed order by k_loss_norm_final
 __global__ void __launch_bounds__(LOSS_THREADS) k_loss_norm(const float *__restrict__ pos, const float *__restrict__ neg,
                                                             int64_t per_b, float *__restrict__ part) {
+    VN_PRIO_MAIN();
     const int b = blockIdx.x / NORM_CHUNKS, chunk = blockIdx.x % NORM_CHUNKS;
     float sp = 0.f, sn = 0.f;
     for (int64_t i = (int64_t)chunk * LOSS_THREADS + threadIdx.x; i < per_b; i += (int64_t)NORM_CHUNKS * LOSS_THREADS) {
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss_norm(const float *__restr
 }
 
 __global__ void __launch_bounds__(64) k_loss_norm_final(const float *__restrict__ part, float *__restrict__ norm, int B) {
+    VN_PRIO_MAIN();
     const int b = blockIdx.x, lane = threadIdx.x;   // NORM_CHUNKS == 64 == one wave
     const float a = vn_wave_sum(part[((int64_t)b * NORM_CHUNKS + lane) * 2]);
     const float c = vn_wave_sum(part[((int64_t)b * NORM_CHUNKS + lane) * 2 + 1]);
@@ -76,6 +78,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
                                                        LossGeom g, float *__restrict__ slab /* fwd: [blocks][3] */,
                                                        LossGrads gout /* bwd: five device scalars, NULL = 0 */,
                                                        float *__restrict__ d_prob, float *__restrict__ d_reg) {
+    VN_PRIO_MAIN();
     const int64_t hw = (int64_t)g.H * g.W, sites = hw * g.B;
     const int64_t site = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x;
     float s_pos = 0.f, s_neg = 0.f, s_reg = 0.f;
@@ -133,6 +136,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
 
 __global__ void __launch_bounds__(LOSS_THREADS) k_loss_finalize(const float *__restrict__ slab, int nblocks, float alpha,
                                                                 float beta, float *__restrict__ out) {
+    VN_PRIO_MAIN();
     double s[3] = {0.0, 0.0, 0.0};
     for (int i = threadIdx.x; i < nblocks; i += LOSS_THREADS)
         for (int k = 0; k < 3; ++k) s[k] += (double)slab[(int64_t)i * 3 + k];

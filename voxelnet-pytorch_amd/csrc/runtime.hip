@@ -410,7 +410,12 @@ struct vnNet {
     // at its start and for [1] in front of the second layer, so the ~65 us of packing are off the start of the step
     hipEvent_t prep_ev[2];
     bool prep_recorded;
-    bool prep_first_done;   // vn_net_prepare was called with heads_w == NULL: the next call issues only the rest
+    bool prep_first_done;   // vn_net_prepare phase 1 (cfg->prepared == 1) has been issued: phase 2 issues only the rest
+    // what phase 1 was issued FOR: phase 2 and the vn_net_forward that follows must name the same step (round-3 advisor:
+    // hidden state without a check let a stale first phase stand in for a later step's)
+    const void *prep_ws, *prep_coord;
+    int64_t prep_K;
+    int32_t prep_dims[4];
     // the data-gradient orientation of the packed weights is first read by the BACKWARD: vn_net_prepare leaves those jobs
     // here and vn_net_forward issues them on the side stream behind deconv2, beside block3's small images (CUs to spare)
     // instead of beside the first layers (where the launch cost 0.03 ms of step time)
@@ -604,8 +609,17 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
         }
         return VN_OK;
     };
-    if (!own_stream && !heads_w) return VN_EINVAL;
-    const bool rest_only = own_stream && heads_w && net->prep_first_done;   // second call of the two-call protocol
+    // own_stream: cfg->prepared names the phase of this call — 0 everything in one call, 1 only the first layer's needs
+    // (event 0; heads_w unused), 2 only the rest (event 1; needs a phase 1 for the same workspace / coord / K / grid)
+    const int phase = own_stream ? cfg->prepared : 0;
+    if (phase < 0 || phase > 2 || (phase != 1 && !heads_w)) return VN_EINVAL;
+    const int32_t dims[4] = {cfg->B, cfg->D, cfg->H, cfg->W};
+    const bool rest_only = phase == 2;
+    if (rest_only && !(net->prep_first_done && net->prep_ws == P.wp_f[0] && net->prep_coord == coord && net->prep_K == K &&
+                       !memcmp(net->prep_dims, dims, sizeof(dims)))) {
+        net->prep_first_done = false;
+        return VN_EINVAL;      // no (or another step's) first phase
+    }
     net->prep_first_done = false;
     if (own_stream && !rest_only) {
         const Spec &sp = P.spec[0];
@@ -613,7 +627,9 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
         RTT(T_PACK, 0, 0.0, (double)j0.c_out * j0.c_in * j0.taps * (4 + P.esz), stream, vn_pack_weights_batch(&j0, 1, stream));
         RT(first_needs());
         VN_HIP(hipEventRecord(net->prep_ev[0], vn_stream(stream)));
-        if (!heads_w) {   // first call of the two-call protocol: the caller has more to queue (e.g. the heads' concatenation)
+        net->prep_ws = P.wp_f[0]; net->prep_coord = coord; net->prep_K = K;
+        memcpy(net->prep_dims, dims, sizeof(dims));
+        if (phase == 1) {   // the caller has more to queue on this stream (e.g. the heads' concatenation) before phase 2
             net->prep_first_done = true;
             return VN_OK;
         }
@@ -660,7 +676,13 @@ extern "C" int vn_net_prepare(vnNet *net, const vnNetConfig *cfg, const vnLayerP
     Plan P;
     if (!make_plan(cfg, K, static_cast<char *>(workspace), &P)) return VN_EUNSUPPORTED;
     if (workspace_bytes < P.bytes) return VN_EWORKSPACE;
-    return net_prepare(net, cfg, P, L, heads_w, coord, K, stream, true);
+    const int rc = net_prepare(net, cfg, P, L, heads_w, coord, K, stream, true);
+    if (rc != VN_OK) {     // no half-issued protocol state survives an error
+        net->prep_first_done = false;
+        net->prep_recorded = false;
+        net->n_deferred = 0;
+    }
+    return rc;
 }
 
 extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *L, const float *heads_w,
@@ -678,7 +700,18 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
     const int relu_fl = P.round_act ? 3 : 1;    // (bit 1: the activation is rounded to the nearest bf16 value — diagnostic)
     // (no memset: every statistics buffer of the forward is a per-workgroup slab written with plain stores)
     if (!cfg->prepared) RT(net_prepare(net, cfg, P, L, heads_w, coord, K, stream, false));
-    const bool prep_wait = cfg->prepared && net->prep_recorded;   // (a caller that joined the prepare stream itself loses nothing)
+    if (cfg->prepared && !net->prep_recorded) return VN_EINVAL;   // "prepared" without a vn_net_prepare on this context (or already consumed)
+    const bool prep_wait = cfg->prepared != 0;
+    if (prep_wait) {        // the prepared step must be THIS one: same arena, voxel coordinates, K and grid
+        const int32_t dims[4] = {cfg->B, cfg->D, cfg->H, cfg->W};
+        if (net->prep_ws != P.wp_f[0] || net->prep_K != K || (cfg->sparse_first && net->prep_coord != coord) ||
+            memcmp(net->prep_dims, dims, sizeof(dims))) {
+            net->prep_recorded = false;
+            net->n_deferred = 0;
+            return VN_EINVAL;
+        }
+    }
+    net->prep_recorded = false;     // consumed: a later forward needs its own vn_net_prepare
     if (prep_wait) VN_HIP(hipStreamWaitEvent(hs, net->prep_ev[0], 0));
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
     Rows x1{}, x2{};

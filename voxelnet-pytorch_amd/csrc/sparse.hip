@@ -21,6 +21,7 @@ struct ASGeom {
 
 __global__ void __launch_bounds__(256) k_mark(const int64_t *__restrict__ coord, int64_t K, ASGeom g,
                                               uint8_t *__restrict__ flags) {
+    VN_PRIO_MAIN();
     const int taps = g.kD * g.kH * g.kW;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K * taps) return;
@@ -61,6 +62,7 @@ __device__ int block_excl_scan_i32(int v, int *total) {
 
 __global__ void __launch_bounds__(AS_THREADS) k_as_count(const uint8_t *__restrict__ flags, int64_t n,
                                                          int32_t *__restrict__ blk) {
+    VN_PRIO_MAIN();
     const int64_t base = (int64_t)blockIdx.x * AS_TILE + (int64_t)threadIdx.x * AS_ITEMS;
     int s = 0;
 #pragma unroll
@@ -73,6 +75,7 @@ __global__ void __launch_bounds__(AS_THREADS) k_as_count(const uint8_t *__restri
 
 __global__ void __launch_bounds__(AS_THREADS) k_as_scan(int32_t *__restrict__ blk, int64_t nb, int64_t cap,
                                                         int32_t *__restrict__ count) {
+    VN_PRIO_MAIN();
     int carry = 0;
     for (int64_t base = 0; base < nb; base += AS_THREADS) {
         const int64_t i = base + threadIdx.x;
@@ -88,6 +91,7 @@ __global__ void __launch_bounds__(AS_THREADS) k_as_scan(int32_t *__restrict__ bl
 __global__ void __launch_bounds__(AS_THREADS) k_as_write(const uint8_t *__restrict__ flags, int64_t n,
                                                          const int32_t *__restrict__ blk, ASGeom g,
                                                          int64_t *__restrict__ list, int64_t cap) {
+    VN_PRIO_MAIN();
     const int64_t base = (int64_t)blockIdx.x * AS_TILE + (int64_t)threadIdx.x * AS_ITEMS;
     uint8_t f[AS_ITEMS];
     int s = 0;
@@ -116,6 +120,7 @@ __global__ void __launch_bounds__(AS_THREADS) k_as_write(const uint8_t *__restri
 
 __global__ void __launch_bounds__(256) k_fill_rows(void *__restrict__ y, int f32, int64_t M, int C, int64_t stride,
                                                    const float *__restrict__ bias) {
+    VN_PRIO_MAIN();
     const int groups = C >> 2;
     const int64_t total = M * groups;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -141,6 +146,7 @@ __global__ void __launch_bounds__(256) k_fill_rows(void *__restrict__ y, int f32
 // matching P rows in tap order (deterministic), writes y and the per-workgroup BatchNorm partial sums.
 __global__ void __launch_bounds__(256) k_index_scatter(const int64_t *__restrict__ coord, int64_t K, int B, int D, int H,
                                                        int W, int32_t *__restrict__ grid) {
+    VN_PRIO_MAIN();
     const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (v >= K) return;
     const int64_t *c = coord + v * 4;
@@ -157,6 +163,7 @@ __global__ void __launch_bounds__(256) k_rulebook_combine(const float *__restric
                                                           const int32_t *__restrict__ count, ASGeom g, int Di, int Hi,
                                                           int Wi, int C, const float *__restrict__ bias,
                                                           void *__restrict__ y, float *__restrict__ slab) {
+    VN_PRIO_MAIN();
     // workgroup = RB_ROWS list rows (= one slab row); wave w takes rows w, w+4, ...; lane = output channel (C == 64).
     // The per-site chain (coordinates -> 27 index lookups -> P rows) is latency-bound: many short workgroups.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -391,6 +391,7 @@ __device__ __forceinline__ void load_weights_lds(const VfeParams &P, float *wl, 
 // rows[v] = 1 + index of the last slot whose 7 values differ (bit-wise) from slot T-1; one wave per voxel
 __global__ void __launch_bounds__(256) k_vfe_rows(const float *__restrict__ feature, int64_t K, int T,
                                                   uint8_t *__restrict__ rows) {
+    VN_PRIO_MAIN();
     const int lane = threadIdx.x & 63;
     const int64_t v = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (v >= K) return;
@@ -423,6 +424,7 @@ __device__ __forceinline__ void classify16(const uint4 &q, int64_t v0, int64_t K
 
 __global__ void __launch_bounds__(256) k_vfe_partition(const uint8_t *__restrict__ rows, int64_t K, int32_t *__restrict__ list,
                                                        int32_t *__restrict__ counts) {
+    VN_PRIO_MAIN();
     __shared__ int red[4][9];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n16 = (K + 15) >> 4, mine = (int64_t)blockIdx.x * (PART_CHUNK / 16);   // in units of 16 voxels
@@ -491,6 +493,7 @@ __global__ void __launch_bounds__(256) k_vfe_partition(const uint8_t *__restrict
 // pass 1: weighted sums of h1 ; slab[b] = [sum(16) | sumsq(16) | 0(32)]
 __global__ void __launch_bounds__(NT) k_vfe_p1(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
                                                float *__restrict__ slabs) {
+    VN_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(-1)
@@ -540,6 +543,7 @@ __device__ __forceinline__ void p2_item(const float *__restrict__ feature, int T
 
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_vfe_p2(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
                                                const float *__restrict__ stats, float *__restrict__ slabs) {
+    VN_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(2)
@@ -594,6 +598,7 @@ __device__ __forceinline__ void p3_item(const float *__restrict__ feature, int T
 
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_vfe_p3(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
                                                const float *__restrict__ stats, float *__restrict__ voxelwise) {
+    VN_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(3)
@@ -636,6 +641,7 @@ __global__ void __launch_bounds__(256) k_vfe_finalize(const float *__restrict__ 
                                                       const float *__restrict__ gamma, const float *__restrict__ beta,
                                                       float *running_mean, float *running_var, int training,
                                                       float momentum, float eps, float *__restrict__ st) {
+    VN_PRIO_MAIN();
     const int c = blockIdx.x;
     double mean, var;
     float p_gamma = 0.f, p_beta = 0.f, p_rm = 0.f, p_rv = 0.f;   // requested before the slab loop, not behind the reduction
@@ -759,6 +765,7 @@ __device__ __forceinline__ void b1_item(const float *__restrict__ feature, int T
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_vfe_b1(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
                                                const float *__restrict__ stats, const float *__restrict__ dvw,
                                                float *__restrict__ slabs) {
+    VN_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(11)
@@ -786,6 +793,7 @@ __global__ void __launch_bounds__(256) k_vfe_bn_bwd_finalize(const float *__rest
                                                              const float *__restrict__ gamma,
                                                              const float *__restrict__ st, float *__restrict__ coef,
                                                              float *__restrict__ d_gamma, float *__restrict__ d_beta, int eval) {
+    VN_PRIO_MAIN();
     const int c = blockIdx.x;
     double s1, s2;
     slab_pair_sum(slabs, nslabs, slab_stride, slab_off, C, c, s1, s2);
@@ -943,6 +951,7 @@ __global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature
                                                const float *__restrict__ stats_g, const float *__restrict__ dvw,
                                                const float *__restrict__ coef2_g, float *__restrict__ dp1_ws,
                                                float *__restrict__ slabs) {
+    VN_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(12)
@@ -1006,6 +1015,7 @@ __global__ void __launch_bounds__(NT) k_vfe_b2(const float *__restrict__ feature
 __global__ void __launch_bounds__(NT) k_vfe_b3(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
                                                const float *__restrict__ stats, const float *__restrict__ coef1,
                                                const float *__restrict__ dp1_ws, float *__restrict__ slabs) {
+    VN_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     VFE_TR_KERNEL(-1)
@@ -1044,6 +1054,7 @@ __global__ void __launch_bounds__(NT) k_vfe_b3(const float *__restrict__ feature
 // out[i] = sum_b slabs[b*stride + off + i]  (double accumulation, fixed order); one wave per output element
 __global__ void __launch_bounds__(256) k_vfe_reduce(const float *__restrict__ slabs, int nslabs, int stride, int off,
                                                     int n, float *__restrict__ out) {
+    VN_PRIO_MAIN();
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= n) return;
@@ -1061,6 +1072,7 @@ struct ReduceJobs {
     int stride[4], off[4], n[4], first[5], nslabs[4];
 };
 __global__ void __launch_bounds__(256) k_vfe_reduce_multi(const ReduceJobs J) {
+    VN_PRIO_MAIN();
     int j = 0;
 #pragma unroll
     for (int q = 1; q < 4; ++q)

@@ -624,13 +624,16 @@ class _DetectorFn(torch.autograd.Function):
                     # weight packing reads — and the rest of the packing
                     side_t = rpn.__dict__["_side"]
                     side_t.wait_stream(torch.cuda.current_stream())
-                    if os.environ.get("VN_PREP_JOIN") != "1":      # ("1": the round-2 schedule, for A/B runs against older builds)
+                    two_phase = os.environ.get("VN_PREP_JOIN") != "1"      # ("1": the round-2 schedule, one call, for A/B runs)
+                    if two_phase:
+                        cfg.prepared = 1                       # phase 1: the first layer's needs only
                         _lib.call("vn_net_prepare", rpn._net_handle(dev_), ctypes.byref(cfg), arr, None, coord.data_ptr(), K,
                                   ws.data_ptr(), ws_bytes, side)
                     with torch.cuda.stream(side_t):
                         heads = _heads_params([f.detach() for f in flat[-4:]])
                     for t_ in heads.values():
                         t_.record_stream(torch.cuda.current_stream())
+                    cfg.prepared = 2 if two_phase else 0       # phase 2: the rest (0: everything in this one call)
                     _lib.call("vn_net_prepare", rpn._net_handle(dev_), ctypes.byref(cfg), arr, heads["weight"].data_ptr(), coord.data_ptr(), K,
                               ws.data_ptr(), ws_bytes, side)
                     cfg.prepared = 1
