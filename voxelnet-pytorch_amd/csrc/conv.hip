@@ -62,6 +62,7 @@ struct GGParams {
     int32_t mulD, mulH, mulW, omulD, omulH, omulW;
     int32_t Cs, src_wrap, N, out_f32, accumulate, nclasses, src_row_elems;
     int32_t esz;                // operand element size: 2 (bf16) or 4 (fp32, exact v_mfma_f32_16x16x4_f32 path)
+    int32_t kc_rot;             // k_conv_patch2d: workgroups start their K-chunk loop at chunk (tile mod nk) — tuning aid VN_P2D_ROT
     uint32_t w_bytes;
     int64_t src_batch_extent;   // elements spanned by one batch item (for num_records)
     // row-list mode (sparse first Conv3d): rows are an explicit list of (b,d,h,w) coordinates
@@ -832,11 +833,16 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
     const int sd = qd * p.mulD + cl.offD[0];
     const int total = ((unsigned)sd < (unsigned)p.Ds) ? nk * 9 : 0;
     const int wbase = wbase_of(0);
+    // (p.kc_rot: neighbouring workgroups walk the K chunks from different starting points, so the 140-280 workgroups of a
+    //  launch — which otherwise all request the SAME 16-KB weight tile at the same moment, 36 times — spread over nk tiles;
+    //  the accumulation order of a tile then depends on its position, still fixed run to run)
+    const int rot = p.kc_rot ? tile % nk : 0;
+    auto kc_of = [&](int kc) { const int k = kc + rot; return k >= nk ? k - nk : k; };
     auto stage_step = [&](int s) {
         const int kc = s / 9;
-        stage_b(wbase, s - kc * 9, kc, s % NSB);
+        stage_b(wbase, s - kc * 9, kc_of(kc), s % NSB);
     };
-    if (total > 0) stage_patch(sd, 0, smem);
+    if (total > 0) stage_patch(sd, kc_of(0), smem);
 #pragma unroll
     for (int s = 0; s < NSB - 1; ++s)
         if (s < total) stage_step(s);
@@ -856,7 +862,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             // (the other patch buffer was last read in the previous chunk: PT >= 1 barriers ago)
-            if (tap == PT && kc + 1 < nk) stage_patch(sd, kc + 1, smem + (pbuf ^ 1) * PATCH_BYTES);
+            if (tap == PT && kc + 1 < nk) stage_patch(sd, kc_of(kc + 1), smem + (pbuf ^ 1) * PATCH_BYTES);
             if (s + NSB - 1 < total) stage_step(s + NSB - 1);
             const int shift = cl.offH[ih] * PW + cl.offW[iw];
             const char *lb = bst + (s % NSB) * B_BYTES + wn * (64 * 128);
@@ -1049,12 +1055,15 @@ int patch2d_stages() {   // VN_PATCH2D=0: the two-stage kernel for the small ima
 }
 int launch_patch_cfg(const PatchCfg &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
     if (c.id == 2 && p.Ds == 1 && p.nclasses == 1 && p.cls[0].nD == 1 && patch2d_stages() >= 3) {
+        static const int rot = vn_knob("VN_P2D_ROT", 0);
+        GGParams q = p;
+        q.kc_rot = rot;
         // eight waves (4 x 2 of 16 x 64) for the bf16 kernels; tuning aid VN_PATCH2D_WAVES=4: the four-wave kernel of round 2
         static const int waves = vn_knob("VN_PATCH2D_WAVES", 8);
-        if (patch2d_stages() == 3 && waves == 8 && !f32) return launch_patch2d<4, 2, 1, 16, 3, false>(p, grid, st);
+        if (patch2d_stages() == 3 && waves == 8 && !f32) return launch_patch2d<4, 2, 1, 16, 3, false>(q, grid, st);
         if (patch2d_stages() == 3)
-            return f32 ? launch_patch2d<2, 2, 2, 16, 3, true>(p, grid, st) : launch_patch2d<2, 2, 2, 16, 3, false>(p, grid, st);
-        return f32 ? launch_patch2d<2, 2, 2, 16, 4, true>(p, grid, st) : launch_patch2d<2, 2, 2, 16, 4, false>(p, grid, st);
+            return f32 ? launch_patch2d<2, 2, 2, 16, 3, true>(q, grid, st) : launch_patch2d<2, 2, 2, 16, 3, false>(q, grid, st);
+        return f32 ? launch_patch2d<2, 2, 2, 16, 4, true>(q, grid, st) : launch_patch2d<2, 2, 2, 16, 4, false>(q, grid, st);
     }
     if (c.id == 1) return f32 ? launch_patch<4, 1, 4, 32, true>(p, grid, st) : launch_patch<4, 1, 4, 32, false>(p, grid, st);
     if (c.id == 4) return f32 ? launch_patch<2, 2, 3, 16, true>(p, grid, st) : launch_patch<2, 2, 3, 16, false>(p, grid, st);
