@@ -48,6 +48,10 @@ struct WGParams {
     // adds into dw itself (one writer per element: no atomics either way)
     float *part;
     int64_t part_stride;
+    // XCD-aware launch (1-D grid): nchunks > 0 — workgroup L of the grid is (chunk, tap group, tile) with the tap groups of
+    // ONE chunk on linear ids that are equal mod 8 (= one XCD under round-robin placement; speed only): the chunk's `rows`
+    // and source slabs are then fetched into one L2 instead of up to eight.  0: the plain 3-D grid (chunk, group, tile)
+    int32_t nchunks, ngroups, ntiles_xcd;
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -89,10 +93,23 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wn = wave / WKW, wk = wave % WKW;
-    const int tile = blockIdx.z;
+    int bx = blockIdx.x, by = blockIdx.y, tile = blockIdx.z, gx = gridDim.x;
+    if (p.nchunks > 0) {
+        // unit = (chunk, channel tile): its tap groups sit on linear ids L = batch * 8 * ngroups + group * 8 + (unit & 7),
+        // all equal mod 8; units go round-robin over the eight residues
+        const int ntiles = p.ntiles_xcd;
+        const int r = blockIdx.x;
+        const int batch = r / (8 * p.ngroups), w = r - batch * (8 * p.ngroups);
+        const int unit = batch * 8 + (w & 7);
+        by = w >> 3;
+        bx = unit / ntiles;
+        tile = unit - bx * ntiles;
+        gx = p.nchunks;
+        if (bx >= p.nchunks) return;           // (padding of the unit count to a multiple of 8)
+    }
     const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
     const int n0 = tn * DN, k0 = tk * DK;
-    const int tap0 = blockIdx.y * TPB;          // TPB == 3: the three kW taps of one (kd, kh)
+    const int tap0 = by * TPB;          // TPB == 3: the three kW taps of one (kd, kh)
     const int td = tap0 / (p.kH * p.kW), th = (tap0 / p.kW) % p.kH, tw0 = tap0 % p.kW;
     const bool list = p.row_list != nullptr;
     int64_t M = list ? p.n_rows : (int64_t)p.B * p.Dr * p.Hr * p.Wr;
@@ -103,7 +120,7 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
     // counted list: the slabs of ROWS rows are dealt round-robin to the chunks (the launch is sized for the list's capacity;
     // contiguous ranges would leave the chunks past the count without work)
     const bool dealt = list && p.row_count;
-    int64_t rbeg = (int64_t)blockIdx.x * p.rows_per_chunk;
+    int64_t rbeg = (int64_t)bx * p.rows_per_chunk;
     if (rbeg >= M && !dealt) return;   // (the host sizes the grid so that every chunk has rows)
     int64_t rend = rbeg + p.rows_per_chunk;
     if (rend > M) rend = M;
@@ -112,10 +129,10 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
     int64_t slab_stride = ROWS;        // rows between two consecutive slabs of this chunk
     if (dealt) {
         const int64_t nslabs = (M + ROWS - 1) / ROWS;
-        nsteps = (int)(nslabs > blockIdx.x ? (nslabs - blockIdx.x + gridDim.x - 1) / gridDim.x : 0);
-        rbeg = (int64_t)blockIdx.x * ROWS;
+        nsteps = (int)(nslabs > bx ? (nslabs - bx + gx - 1) / gx : 0);
+        rbeg = (int64_t)bx * ROWS;
         rend = M;
-        slab_stride = (int64_t)gridDim.x * ROWS;
+        slab_stride = (int64_t)gx * ROWS;
     }
     const int nv = p.split ? 3 : 1;
     const int nstages = nsteps * nv;
@@ -321,7 +338,7 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
     }
 
     // D[n][k]: n = (lane>>4)*4 + e, k = lane&15
-    float *dst = p.part ? p.part + (int64_t)blockIdx.x * p.part_stride : p.dw;
+    float *dst = p.part ? p.part + (int64_t)bx * p.part_stride : p.dw;
 #pragma unroll
     for (int t = 0; t < TPB; ++t)
 #pragma unroll
@@ -843,7 +860,14 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
         *chunks_out = (int32_t)chunks;
     }
     p.part_stride = w.dw_elems;
-    const dim3 grid((unsigned)chunks, (unsigned)groups, (unsigned)(tiles_n * tiles_k));
+    dim3 grid((unsigned)chunks, (unsigned)groups, (unsigned)(tiles_n * tiles_k));
+    static const int xcd_map = vn_knob("VN_WG_XCD", 0);   // tuning aid: the XCD-aware 1-D grid (WGParams::nchunks)
+    if (xcd_map && chunks > 1) {
+        p.nchunks = (int32_t)chunks;
+        p.ngroups = groups;
+        p.ntiles_xcd = tiles_n * tiles_k;
+        grid = dim3((unsigned)((((chunks * tiles_n * tiles_k) + 7) & ~7ll) * groups), 1, 1);
+    }
     hipStream_t st = vn_stream(stream);
     int rc;
     static const int tri_waves = vn_knob("VN_WG_TRI_WAVES", 8);   // waves per workgroup of the three-tap tiles (4: round 2)
