@@ -1252,6 +1252,17 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 RT(after_unpack(0, nu, wstream));
                 u_early = nu;
             }
+            // middle_layer.2's partial slabs (85 row chunks, 37.6 MB: most of what the LAST unpack reads) are final ~135 us
+            // before the side stream gets middle_layer.1's dy: unpacked here, in that gap, instead of in the step's tail
+            // (tuning aid VN_UNPACK_M2)
+            static const int unpack_m2_on = vn_knob("VN_UNPACK_M2", 0);   // (round 4: 557.5 vs 559.2 pc/s over four pairs: off)
+            if (l == L_M2 && tail_balance && early_unpack_on && unpack_m2_on && nu > u_early) {
+                RT(join_wg());
+                RTT(T_UNPACK, L_M2, 0.0, unpack_bytes(unpack + u_early, nu - u_early), wstream,
+                    vn_unpack_wgrads_batch(unpack + u_early, nu - u_early, wstream));
+                RT(after_unpack(u_early, nu, wstream));
+                u_early = nu;
+            }
         }
         if (bucket_ev) {   // group ends (backward order): ... block3.0 | ... deconv1 | ... block1.0 | ... middle_layer.0
             if (l == L_B3) RT(bucket_done(0));
