@@ -77,6 +77,15 @@ struct GGParams {
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+#ifdef VN_P2D_TRACE
+// -DVN_P2D_TRACE builds only (tools/trace_patch2d.py): shader-clock stamps of wave 0 of workgroup (1, 0) of every
+// k_conv_patch2d launch, per tap step: [0] before the wait, [1] after it, [2] after the barrier, [3] after the DMA issue,
+// [4] after the fragment reads + MFMAs (a wait for the accumulators)
+__device__ long long g_p2d_trace[64 * 8];
+#define P2D_STAMP(s, k) do { if (tr_on) g_p2d_trace[((s) & 63) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define P2D_STAMP(s, k) do {} while (0)
+#endif
 #ifndef GG_PIN_SCHEDULE
 #define GG_PIN_SCHEDULE 1
 #endif
@@ -830,6 +839,9 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
     // HBM / Infinity Cache — in the train step every layer's weights and input are cold — have NSB - 1 tap steps to arrive
     // instead of one, and a chunk boundary is an ordinary step (no drain)
     constexpr int PT = 3;
+#ifdef VN_P2D_TRACE
+    const bool tr_on = blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0;
+#endif
     const int sd = qd * p.mulD + cl.offD[0];
     const int total = ((unsigned)sd < (unsigned)p.Ds) ? nk * 9 : 0;
     const int wbase = wbase_of(0);
@@ -856,14 +868,18 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
             // the tile of step s (and, at tap 0, this chunk's patch: issued before that tile) has landed; the loads issued
             // after it — the tiles of steps s+1 .. s+NSB-2 — may still be in flight.  lgkmcnt(0): see k_gather_gemm
             const int after = total - 1 - s < NSB - 2 ? total - 1 - s : NSB - 2;
+            P2D_STAMP(s, 0);
             if (after >= 2 && NSB >= 4) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * RB) : "memory");
             else if (after == 1) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RB) : "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            P2D_STAMP(s, 1);
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            P2D_STAMP(s, 2);
             // (the other patch buffer was last read in the previous chunk: PT >= 1 barriers ago)
             if (tap == PT && kc + 1 < nk) stage_patch(sd, kc_of(kc + 1), smem + (pbuf ^ 1) * PATCH_BYTES);
             if (s + NSB - 1 < total) stage_step(s + NSB - 1);
+            P2D_STAMP(s, 3);
             const int shift = cl.offH[ih] * PW + cl.offW[iw];
             const char *lb = bst + (s % NSB) * B_BYTES + wn * (64 * 128);
 #pragma unroll
@@ -897,6 +913,12 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
                     }
                 }
             }
+#ifdef VN_P2D_TRACE
+            if (tr_on) {     // wait for this step's accumulators (adds a dependency the product build does not have)
+                asm volatile("s_nop 0" ::"v"(acc[0][0]), "v"(acc[SM - 1][3]));
+                P2D_STAMP(s, 4);
+            }
+#endif
         }
         pbuf ^= 1;
     }
@@ -1377,3 +1399,9 @@ static int gather_gemm_impl(const void *src, const void *w_packed, const float *
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
+
+#ifdef VN_P2D_TRACE
+extern "C" int vn_debug_p2d_trace(long long *out /* host, 64 x 8 */) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_p2d_trace), sizeof(long long) * 64 * 8);
+}
+#endif
