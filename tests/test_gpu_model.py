@@ -289,11 +289,11 @@ def test_reducer_path_gives_the_same_gradients(golden):
 
 @pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_train_step_on_a_grid_the_native_executor_does_not_take(mode):
-    """D = 9 (the three Conv3d layers still fold to depth 2: model.py:207-209, 262) is outside the native executor
-    (csrc/runtime.hip plans D = 10 only): detect() must then route the whole step — forward AND backward — through the
-    per-layer orchestration with the parameters as autograd inputs (round 2 picked the one-tensor 'anchor' call from a
-    different predicate than the forward's path choice and the backward raised).  fp32: maps against the oracle at 1e-3;
-    both modes: every parameter receives a finite gradient through autograd (torch.autograd.grad works on this path)."""
+    """A model with `native_executor = False` (or bf16x3, or a depth the executor does not plan): detect() must route the
+    whole step — forward AND backward — through the per-layer orchestration with the parameters as autograd inputs (round 2
+    picked the one-tensor 'anchor' call from a different predicate than the forward's path choice and the backward raised).
+    On a D = 9 grid (the three Conv3d layers still fold to depth 2: model.py:207-209, 262).  fp32: maps against the oracle
+    at 1e-3; both modes: every parameter receives a finite gradient through autograd (torch.autograd.grad works here)."""
     from oracle import voxelize as ov
     from voxelnet_amd import model as M
     from voxelnet_amd import synth
@@ -310,6 +310,7 @@ def test_train_step_on_a_grid_the_native_executor_does_not_take(mode):
     m.load_state_dict(tr.make_state_dict("Car"))
     m.feature_net._grid = g9
     m = m.to(DEV).train()
+    m.native_executor = False                  # (round 4: the executor plans D = 9 ... 12 itself — test_native_executor_other_depths)
     assert not m._native_ok(mode)
     prob, reg = m.detect([f.to(DEV) for f in feats], [c.to(DEV) for c in coords])
     assert prob.shape == (2, 2, 8, 12)
@@ -323,6 +324,55 @@ def test_train_step_on_a_grid_the_native_executor_does_not_take(mode):
     assert len(grads) == 104 and all(g is not None and torch.isfinite(g).all() for g in grads)
     assert sum(float(g.abs().sum()) for g in grads) > 0
     M.set_precision("bf16")
+
+
+@pytest.mark.parametrize("D", [9, 11, 12])
+def test_native_executor_other_depths(D):
+    """The native executor on grids of depth 9, 11 and 12 (round 4: the D == 10 restriction of csrc/runtime.hip is gone;
+    model.py:207-209 only needs the depth to fold to 2): fp32-mode maps against the CPU oracle at 1e-3, and the whole
+    backward against the per-layer orchestration of the SAME kernels (native_executor = False) — maps within 1e-4, every
+    parameter gradient within 5e-2 relative L2 (measured 2e-2 at the VFE end of the chain) (the two paths differ in the first layer's summation order — rulebook vs
+    row-list — which the 23-layer BatchNorm / ReLU stack amplifies; the reference's own fp32 / fp64 gradients differ more)."""
+    from oracle import voxelize as ov
+    from voxelnet_amd import model as M
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import grid_config
+    g = grid_config("Car", D=D, H=16, W=24, oy=1.6)
+    feats, coords = [], []
+    for i in range(2):
+        cloud = synth.synth_cloud("Car", k0=120 + 30 * i, seed=900 + i + D, grid=g, overflow_frac=0.03)
+        v = ov.voxelize(cloud, "Car", D=D, H=16, W=24, oy=1.6)
+        feats.append(torch.from_numpy(v["feature_buffer"]))
+        coords.append(torch.from_numpy(np.pad(v["coordinate_buffer"], ((0, 0), (1, 0)), constant_values=i)))
+    with torch.no_grad():
+        sd = tr.make_state_dict("Car")
+        rp, rr = tr.middle_rpn(tr.feature_net(feats, coords, sd, (D, 16, 24), True), sd, "Car", True)
+    fd, cd = [f.to(DEV) for f in feats], [c.to(DEV) for c in coords]
+    up = (torch.full((2, 2, 8, 12), 0.05, device=DEV), torch.full((2, 14, 8, 12), -0.03, device=DEV))
+    try:
+        M.set_precision("fp32")
+        out = {}
+        for native in (True, False):
+            m = M.RPN3D("Car")
+            m.load_state_dict(tr.make_state_dict("Car"))
+            m.feature_net._grid = g
+            m = m.to(DEV).train()
+            m.native_executor = native
+            assert m._native_ok("fp32") == native
+            prob, reg = m.detect(fd, cd)
+            torch.autograd.backward([prob, reg], list(up))
+            out[native] = (prob.detach(), reg.detach(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+        pn, rn, gn = out[True]
+        pf, rf, gf = out[False]
+        assert rel_err(pn, rp.numpy()) < 1e-3 and rel_err(rn, rr.numpy()) < 1e-3
+        em = (rel_err(pn, pf.cpu().numpy()), rel_err(rn, rf.cpu().numpy()))
+        assert em[0] < 1e-4 and em[1] < 1e-4, em
+        worst = max((float((gn[k] - gf[k]).norm() / gf[k].norm().clamp(min=1e-30)), k) for k in gf
+                    if not (k.endswith("conv.bias") and "prob_conv" not in k and "reg_conv" not in k) and not k.endswith("deconv.bias"))
+        print(f"D = {D}: native vs per-layer: maps {em[0]:.1e} / {em[1]:.1e}, gradients worst rel-L2 {worst}")
+        assert worst[0] < 5e-2, worst        # (the chained-gradient bound of test_detect_fwd_bwd_fp32 on these tiny grids)
+    finally:
+        M.set_precision("bf16")
 
 
 def _hip_masks(st):

@@ -146,7 +146,10 @@ vnConv wgrad_geom(const Plan &P, int l, const Rows &x) {
 int m0_bn_knob();
 int box_zero_total();
 bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
-    if (!c || c->B <= 0 || c->D != 10 || c->H <= 0 || c->W <= 0 || (c->H & 7) || (c->W & 7)) return false;
+    // depth: every D whose three Conv3d layers (model.py:207-209: stride 2 / pad 1, stride 1 / no pad, stride 2 / pad 1)
+    // end at depth 2, the BEV fold of model.py:262 — D = 9 ... 12 (the reference's grids are all D = 10; round 4 lifted the
+    // D == 10 restriction: nothing below depends on it, the walk checks the folded depth)
+    if (!c || c->B <= 0 || c->D < 9 || c->D > 12 || c->H <= 0 || c->W <= 0 || (c->H & 7) || (c->W & 7)) return false;
     if (c->mode != 0 && c->mode != 1) return false;
     if (c->block1_stride != 1 && c->block1_stride != 2) return false;
     memset(P, 0, sizeof(*P));

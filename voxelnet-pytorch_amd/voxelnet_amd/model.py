@@ -1081,10 +1081,11 @@ class RPN3D(nn.Module):
         return prob, reg
 
     def _native_ok(self, mode):
-        """ONE predicate for "this call runs on the native executor" (csrc/runtime.hip: D = 10 grids, bf16 / fp32 modes), used
-        by detect() to pick the one-tensor call and by _DetectorFn.forward to pick the path: every other configuration
-        (bf16x3, D != 10) trains through the per-layer orchestration with the 104 parameters as autograd inputs."""
-        return bool(self.native_executor) and not E.is_split(mode) and self.feature_net._grid.D == 10
+        """ONE predicate for "this call runs on the native executor" (csrc/runtime.hip: grids whose depth folds to 2 —
+        D = 9 ... 12 —, bf16 / fp32 modes), used by detect() to pick the one-tensor call and by _DetectorFn.forward to pick the
+        path: every other configuration (bf16x3, other depths, native_executor = False) trains through the per-layer
+        orchestration with the 104 parameters as autograd inputs."""
+        return bool(self.native_executor) and not E.is_split(mode) and 9 <= self.feature_net._grid.D <= 12
 
     def _all_need_grad(self, flat):
         return all(p.requires_grad for p in flat)
