@@ -147,7 +147,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="car", choices=sorted(CONFIGS),
                     help="car = BASELINE configs[1] (the metric's workload, default), ped = configs[2], dense = configs[4]")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp32x3"])
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: 2, 2, 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -465,7 +465,7 @@ def main():
     # ---- per-kernel durations: the native executor's own HIP events around every launch (same path as the timed region),
     #      torch events around the launch groups the Python side issues (voxelizer, VFE, loss, optimizer)
     recs, sect = None, None
-    native_timed = model.native_executor and args.precision in ("bf16", "fp32")
+    native_timed = model.native_executor and args.precision in ("bf16", "fp32", "fp32x3")
     if not args.no_kernel_timer and (rank == 0 or world > 1):
         sect = E.KernelTimer()
         E.SECTIONS = sect
@@ -498,6 +498,8 @@ def main():
         maps["bf16"] = maps_of(build_model("bf16"))
         parity = {}
         for prec, nsteps, note in (("fp32", 5, "fp32 operands on v_mfma_f32_16x16x4_f32: the mode of the <= 1e-3 parity tests"),
+                                   ("fp32x3", 5, "fp32 storage, every conv / weight-gradient product as three bf16 MFMAs on hi / lo splits made "
+                                                 "in registers (VN_F32X3), native executor: the fast mode INSIDE the 1e-3 map tolerance"),
                                    ("bf16x3", 3, "[hi|lo] bf16 operand pairs, three bf16 MFMA products per fp32 product; per-layer "
                                                  "orchestration from Python (not the native executor: host-bound)")):
             pm = build_model(prec)
@@ -517,7 +519,7 @@ def main():
             state.update(model=model, params=params, named=named, opt=opt)
             del pm
         M.set_precision(args.precision)
-        for prec in ("bf16", "bf16x3"):
+        for prec in ("bf16", "bf16x3", "fp32x3"):
             (pa, ra), (pb, rb) = maps[prec], maps["fp32"]
             err = {"prob_max_over_max": float((pa - pb).abs().max() / pb.abs().max()), "prob_rel_l2": float((pa - pb).norm() / pb.norm()),
                    "reg_max_over_max": float((ra - rb).abs().max() / rb.abs().max()), "reg_rel_l2": float((ra - rb).norm() / rb.norm())}
@@ -537,7 +539,7 @@ def main():
             # the spread over --windows timed regions of --steps steps in this run (the first one is `value`)
             "value_min": vals[0], "value_median": vals[len(vals) // 2], "value_max": vals[-1], "windows": len(vals),
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3", "fp32x3": "f32 storage / bf16x3 products"}[args.precision], "data": "synthetic",
             "config": {"workload": "%s, batch=%d per GPU, fwd+bwd train step (BASELINE configs[%d])" % (cfg_desc, B, cfg_index),
                        "global_batch": world * B, "points_per_frame": int(frames_np[0].shape[0]),
                        "parallelism": "dp%d" % world,

@@ -33,7 +33,13 @@ extern "C" {
 #define VN_EUNSUPPORTED (-2) /* shape outside what the kernels are built for */
 #define VN_EWORKSPACE (-3) /* workspace too small */
 
-typedef enum { VN_F32 = 0, VN_BF16 = 1 } vnDtype;
+typedef enum { VN_F32 = 0, VN_BF16 = 1,
+               /* OPERAND dtype of the conv / weight-gradient entry points only (vnConv.dtype): fp32 storage — sources, rows
+                * and packed weights exactly as VN_F32 — with every product evaluated as three bf16 MFMAs on hi / lo splits
+                * made in registers (a.b ~= ah.bh + al.bh + ah.bl, ~2^-16 per product): the "fp32x3" mode, ~1e-4 on the RPN
+                * maps at a fraction of the exact fp32 MFMA cost (round 4).  Tensor dtypes (outputs, BatchNorm, ...) never
+                * take this value. */
+               VN_F32X3 = 2 } vnDtype;
 
 typedef void *vnStream; /* hipStream_t */
 
@@ -358,7 +364,7 @@ int vn_fov_crop(const float *points, int64_t n, const float *P_3x4, const float 
 typedef struct {
     int32_t B, D, H, W;      /* dense voxel grid (D must be 10) */
     int32_t block1_stride;   /* 2: Car, 1: Pedestrian/Cyclist (model.py:212-227) */
-    int32_t mode;            /* 0 bf16, 1 fp32 */
+    int32_t mode;            /* 0 bf16, 1 fp32, 2 fp32x3 (fp32 storage, conv / weight-gradient products as three bf16 MFMAs: VN_F32X3) */
     int32_t training;        /* BatchNorm: batch statistics + running-stat update, or running statistics */
     int32_t sparse_first;
     int32_t prepared;        /* forward: vn_net_prepare has already been issued for this step on the same vnNet (weights packed,

@@ -118,6 +118,16 @@ def test_car_full_size_batch2_fp32_maps():
         # per sample too: a batch-index mix-up would survive a whole-batch maximum only by luck, not a per-sample one
         for b in range(2):
             assert rel_err(prob[b], rp[b]) < 1e-3 and rel_err(reg[b], rr[b]) < 1e-3, b
+        # fp32x3 (round 4): fp32 storage, every conv product as three bf16 MFMAs — the fast mode INSIDE the parity tolerance
+        M.set_precision("fp32x3")
+        m = M.RPN3D("Car")
+        m.load_state_dict(tr.make_state_dict("Car"))
+        m = m.to(DEV).train()
+        with torch.no_grad():
+            prob, reg = m.detect(feats, coords)
+        e3 = rel_err(prob, rp), rel_err(reg, rr)
+        print(f"car full size batch 2, fp32x3 mode vs CPU oracle: prob {e3[0]:.2e}, reg {e3[1]:.2e}")
+        assert e3[0] < 1e-3 and e3[1] < 1e-3, e3
         M.set_precision("bf16")
         m = M.RPN3D("Car")
         m.load_state_dict(tr.make_state_dict("Car"))

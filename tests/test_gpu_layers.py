@@ -14,7 +14,7 @@ from layer_cases import LAYER_CASES, build_layer_state, layer_input, layer_upstr
 
 pytestmark = pytest.mark.gpu
 
-TOL = {"fp32": 2e-4, "bf16x3": 1e-3, "bf16": 8e-3}   # bf16: heads only (fp32 output, bf16 operands vs the fp32 reference)
+TOL = {"fp32": 2e-4, "bf16x3": 1e-3, "fp32x3": 1e-3, "bf16": 8e-3}   # bf16: heads only (fp32 output, bf16 operands vs the fp32 reference)
 
 
 def rel_err(a, b):
@@ -59,10 +59,19 @@ def _spec(case):
 PER_LAYER_CASES = [c for c in LAYER_CASES if not (c[1] == "head" and c[4] % 4)]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
-@pytest.mark.parametrize("case", PER_LAYER_CASES, ids=lambda c: c[0])
-def test_layer_fwd_bwd(golden, case, mode):
+@pytest.fixture
+def x3_flag():
+    """"fp32x3" is "fp32" storage plus the operand dtype VN_F32X3 in every conv geometry (engine.X3, set by set_precision)"""
     from voxelnet_amd import engine as E
+    yield E.X3
+    E.X3["on"] = False
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "fp32x3"])
+@pytest.mark.parametrize("case", PER_LAYER_CASES, ids=lambda c: c[0])
+def test_layer_fwd_bwd(golden, case, mode, x3_flag):
+    from voxelnet_amd import engine as E
+    x3_flag["on"] = mode == "fp32x3"
     g = golden("layers_tiny")
     name, kind, dim, cin, cout, k, s, p, sp = case
     idx = [c[0] for c in LAYER_CASES].index(name)

@@ -148,20 +148,23 @@ def test_middle_module_boundary(golden):
     assert m.feature_net.vfe_1.fcn[0].weight.grad is not None
 
 
-@pytest.mark.parametrize("mode,tol", [("bf16x3", 5e-3), ("bf16", 0.25)])
+@pytest.mark.parametrize("mode,tol", [("bf16x3", 5e-3), ("fp32x3", 1e-3), ("bf16", 0.25)])
 def test_detect_reduced_precision_modes(golden, mode, tol):
     g = golden("middle_tiny_car")
     feats, coords = split(g)
     m = make_model("Car", 16, 24, mode)
     m.train()
     prob, reg = m.detect([f.to(DEV) for f in feats], [c.to(DEV) for c in coords])
-    # stated tolerances relative to the map maximum (not the parity bar): bf16x3 5e-3, bf16 0.25
+    # stated tolerances relative to the map maximum: bf16x3 5e-3, bf16 0.25; fp32x3 (round 4: fp32 storage, three bf16 MFMAs
+    # per product, native executor) meets the PARITY bar of 1e-3
     print(mode, "prob err", rel_err(prob, g["prob"]), "reg err", rel_err(reg, g["reg"]))
     assert rel_err(prob, g["prob"]) < tol
     assert rel_err(reg, g["reg"]) < tol
     torch.autograd.backward([prob, reg], [torch.ones_like(prob) * 0.1, torch.ones_like(reg) * 0.1])
     for k, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    from voxelnet_amd import model as M
+    M.set_precision("bf16")
 
 
 def test_rpn3d_forward_loss(golden):

@@ -27,7 +27,7 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "bf16"])
 def test_train_trajectory(golden, mode):
     from voxelnet_amd import model as M
     from voxelnet_amd.optim import ClipSGD
@@ -63,19 +63,20 @@ def test_train_trajectory(golden, mode):
         opt.zero_grad()
         scal = [float(v) for v in out[2:]]
         if it == 0:
-            tol0 = 1e-4 if mode == "fp32" else 2e-2
+            tol0 = {"fp32": 1e-4, "fp32x3": 5e-4}.get(mode, 2e-2)   # (fp32x3, round 4: three bf16 MFMAs per product, ~2^-16 each)
             np.testing.assert_allclose(scal, g["scalars"][0], rtol=tol0, atol=1e-6)
             # (the total gradient norm is a chained quantity: ReLU-mask flips move it by ~1e-3 in fp32, tests/test_gpu_model.py)
-            assert abs(float(total) - g["grad_norm"][0]) <= (5e-3 if mode == "fp32" else 0.2) * g["grad_norm"][0]
+            assert abs(float(total) - g["grad_norm"][0]) <= (0.2 if mode == "bf16" else 5e-3) * g["grad_norm"][0]
         losses.append(scal[0])
     torch.cuda.synchronize()
     assert np.isfinite(losses).all()
-    floor, wm, mm = (1e-3, 2.0, 3.0) if mode == "fp32" else (3e-2, 2.0, 3.0)
+    floor, wm, mm = (3e-2, 2.0, 3.0) if mode == "bf16" else (1e-3, 2.0, 3.0)
     check_trajectory(g, losses, floor, 3.0, f"HIP {mode}")
     check_final_state(g, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, steps, f"HIP {mode}", wm, mm)
+    M.set_precision("bf16")
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3", "bf16"])
 def test_overfit_200_steps_with_positives(golden, mode):
     """tests/golden/overfit_tiny.npz: 200 iterations over four frames whose labels give positive anchors in every batch
     from the first step (regression loss and its quirk, loss.py:9, active throughout), against the imported reference's
@@ -120,12 +121,12 @@ def test_overfit_200_steps_with_positives(golden, mode):
             opt.step()
             opt.zero_grad()
             if it == 0:
-                np.testing.assert_allclose([float(v) for v in out[2:]], g["scalars"][0], rtol=1e-4 if mode == "fp32" else 2e-2, atol=1e-5)
+                np.testing.assert_allclose([float(v) for v in out[2:]], g["scalars"][0], rtol={"fp32": 1e-4, "fp32x3": 5e-4}.get(mode, 2e-2), atol=1e-5)
             losses.append(float(out[2]))
         torch.cuda.synchronize()
         assert m.__dict__.get("_tgt_stream") is not None          # the early-targets path ran
         assert np.isfinite(losses).all()
-        check_overfit(g, losses, 1e-3 if mode == "fp32" else 3e-2, 3.0, f"HIP {mode}")
+        check_overfit(g, losses, 3e-2 if mode == "bf16" else 1e-3, 3.0, f"HIP {mode}")
         check_final_state(g, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, steps, f"HIP {mode}", 2.0, 3.0)
     finally:
         M.set_precision("bf16")

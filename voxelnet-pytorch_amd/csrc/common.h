@@ -48,6 +48,26 @@ __device__ __forceinline__ void vn_split_bf16(float x, bf16_t &hi, bf16_t &lo) {
     lo = (bf16_t)(x - (float)hi);
 }
 
+// "fp32x3" products (vnDtype VN_F32X3: fp32 storage, every product as three bf16 MFMAs): eight fp32 operands of a lane ->
+// hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32); a.b ~= ah.bh + al.bh + ah.bl, error ~2^-16 per product
+__device__ __forceinline__ void vn_split8(const float (&v)[8], bf16x8_t &hi, bf16x8_t &lo) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const bf16_t h = (bf16_t)v[e];
+        hi[e] = h;
+        lo[e] = (bf16_t)(v[e] - (float)h);
+    }
+}
+__device__ __forceinline__ void vn_split8(const f32x4_t &a0, const f32x4_t &a1, bf16x8_t &hi, bf16x8_t &lo) {
+    const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    vn_split8(v, hi, lo);
+}
+__device__ __forceinline__ f32x4_t vn_mfma_x3(const bf16x8_t &ah, const bf16x8_t &al, const bf16x8_t &bh, const bf16x8_t &bl, f32x4_t c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+
 __device__ __forceinline__ float vn_wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -62,6 +62,7 @@ struct GGParams {
     int32_t mulD, mulH, mulW, omulD, omulH, omulW;
     int32_t Cs, src_wrap, N, out_f32, accumulate, nclasses, src_row_elems;
     int32_t esz;                // operand element size: 2 (bf16) or 4 (fp32, exact v_mfma_f32_16x16x4_f32 path)
+    int32_t x3;                 // fp32 storage, products as three bf16 MFMAs (VN_F32X3): the F32 kernels' alternative inner loop
     int32_t kc_rot;             // k_conv_patch2d: workgroups start their K-chunk loop at chunk (tile mod nk) — tuning aid VN_P2D_ROT
     uint32_t w_bytes;
     int64_t src_batch_extent;   // elements spanned by one batch item (for num_records)
@@ -439,6 +440,28 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         if (live) advance();
         const char *la = smem + buf * STAGE + wm * (16 * SM * 128);
         const char *lb = smem + buf * STAGE + A_BYTES + wn * (64 * 128);
+        bool x3_done = false;
+        if constexpr (F32) {
+            if (p.x3) {      // both 16-B halves of the 32-channel chunk at once: the lane's eight k values, split hi / lo
+                bf16x8_t ah[SM], al[SM], bh[4], bl[4];
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+                    vn_split8(*reinterpret_cast<const f32x4_t *>(la + i * 2048 + frag_off0),
+                              *reinterpret_cast<const f32x4_t *>(la + i * 2048 + frag_off1), ah[i], al[i]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    vn_split8(*reinterpret_cast<const f32x4_t *>(lb + j * 2048 + frag_off0),
+                              *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + frag_off1), bh[j], bl[j]);
+#pragma unroll
+                for (int q = 0; q < LPS; ++q) piece(c, q);
+#pragma unroll
+                for (int i = 0; i < SM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = vn_mfma_x3(ah[i], al[i], bh[j], bl[j], acc[i][j]);
+                x3_done = true;
+            }
+        }
+        if (!x3_done) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int fo = ks ? frag_off1 : frag_off0;
@@ -478,6 +501,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
                     GG_PIN();
                 }
             }
+        }
         }
         buf = buf + 1 == NS ? 0 : buf + 1;
         nbuf = nbuf + 1 == NS ? 0 : nbuf + 1;
@@ -665,6 +689,27 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
                 }
                 const int shift = cl.offH[ih] * PW + cl.offW[iw];
                 const char *lb = bst + bbuf * B_BYTES + wn * (64 * 128);
+                bool x3_done = false;
+                if constexpr (F32) {
+                    if (p.x3) {
+                        bf16x8_t bh[4], bl[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            vn_split8(*reinterpret_cast<const f32x4_t *>(lb + j * 2048 + bfrag0),
+                                      *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + bfrag1), bh[j], bl[j]);
+#pragma unroll
+                        for (int i = 0; i < SM; ++i) {
+                            const int q = q0[i] + shift;
+                            bf16x8_t ah, al;
+                            vn_split8(*reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((0 + fq) ^ ((q >> 1) & 7)) << 4)),
+                                      *reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((4 + fq) ^ ((q >> 1) & 7)) << 4)), ah, al);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[i][j] = vn_mfma_x3(ah, al, bh[j], bl[j], acc[i][j]);
+                        }
+                        x3_done = true;
+                    }
+                }
+                if (!x3_done) {
 #pragma unroll
                 for (int ks = 0; ks < 2; ++ks) {
                     const int fo = ks ? bfrag1 : bfrag0;
@@ -695,6 +740,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[j], acc[i][j], 0, 0, 0);
                         }
                     }
+                }
                 }
                 bbuf ^= 1;
             }
@@ -882,6 +928,27 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
             P2D_STAMP(s, 3);
             const int shift = cl.offH[ih] * PW + cl.offW[iw];
             const char *lb = bst + (s % NSB) * B_BYTES + wn * (64 * 128);
+            bool x3_done = false;
+            if constexpr (F32) {
+                if (p.x3) {
+                    bf16x8_t bh[4], bl[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        vn_split8(*reinterpret_cast<const f32x4_t *>(lb + j * 2048 + bfrag0),
+                                  *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + bfrag1), bh[j], bl[j]);
+#pragma unroll
+                    for (int i = 0; i < SM; ++i) {
+                        const int q = q0[i] + shift;
+                        bf16x8_t ah, al;
+                        vn_split8(*reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((0 + fq) ^ ((q >> 1) & 7)) << 4)),
+                                  *reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((4 + fq) ^ ((q >> 1) & 7)) << 4)), ah, al);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = vn_mfma_x3(ah, al, bh[j], bl[j], acc[i][j]);
+                    }
+                    x3_done = true;
+                }
+            }
+            if (!x3_done) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int fo = ks ? bfrag1 : bfrag0;
@@ -912,6 +979,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[j], acc[i][j], 0, 0, 0);
                     }
                 }
+            }
             }
 #ifdef VN_P2D_TRACE
             if (tr_on) {     // wait for this step's accumulators (adds a dependency the product build does not have)
@@ -1137,8 +1205,8 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
     VN_CHECK_ARG(g->divD >= 1 && g->divH >= 1 && g->divW >= 1);
     VN_CHECK_ARG((g->divD == 1 || g->mulD == 1) && (g->divH == 1 || g->mulH == 1) && (g->divW == 1 || g->mulW == 1));
     VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
-    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32);
-    const bool f32 = g->dtype == VN_F32;
+    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32 || g->dtype == VN_F32X3);
+    const bool f32 = g->dtype != VN_BF16;      // VN_F32X3: the fp32 kernels (fp32 storage) with the three-bf16-product inner loop
     const int esz = f32 ? 4 : 2, align_e = 16 / esz;
     if (g->Cs <= 0 || (g->Cs % align_e) || g->Cr <= 0 || (g->Cr & 3) || g->src_wrap != 0) return VN_EUNSUPPORTED;
     if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & (align_e - 1)) != 0) return VN_EUNSUPPORTED;
@@ -1157,6 +1225,7 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
     p.out_f32 = out_dtype == VN_F32;
     p.src_row_elems = g->Cs;
     p.esz = esz;
+    p.x3 = g->dtype == VN_F32X3;
     const int taps_total = g->kD * g->kH * g->kW;
     const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * esz;
     if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;
@@ -1282,8 +1351,8 @@ static int gather_gemm_impl(const void *src, const void *w_packed, const float *
     VN_CHECK_ARG(g->divW == 1 || g->mulW == 1);
     VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
     VN_CHECK_ARG(!stats_slab || g->divD * g->divH * g->divW <= GG_MAX_CLASSES);
-    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32);
-    const bool f32 = g->dtype == VN_F32;
+    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32 || g->dtype == VN_F32X3);
+    const bool f32 = g->dtype != VN_BF16;      // VN_F32X3: the fp32 kernels (fp32 storage) with the three-bf16-product inner loop
     const int esz = f32 ? 4 : 2, bke = 128 / esz, align_e = 16 / esz;
     (void)bke;
     if (g->Cs <= 0 || (g->Cs % align_e) || g->Cr <= 0 || (g->Cr & 3)) return VN_EUNSUPPORTED;
@@ -1313,6 +1382,7 @@ static int gather_gemm_impl(const void *src, const void *w_packed, const float *
     p.accumulate = accumulate;
     p.src_row_elems = g->src_wrap > 0 ? g->src_wrap : g->Cs;
     p.esz = esz;
+    p.x3 = g->dtype == VN_F32X3;
     const int taps_total = g->kD * g->kH * g->kW;
     const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * esz;
     if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;

@@ -89,6 +89,7 @@ struct Plan {
     Rows dy[NL], dx[NL];
     float *dwp[NL]; size_t dwp_bytes[NL];   // row-chunk partials of the weight gradient (vn_conv_wgrad_partials)
     // heads
+    bool x3;          // cfg->mode == 2 ("fp32x3"): fp32 storage, the convolutions' and weight gradients' products as three bf16 MFMAs
     bool round_act;   // fp32 mode diagnostic (grad_storage & 16): activations rounded to bf16 VALUES, everything else exact fp32
     bool exact_heads; Rows d_rows32;   // grad_storage & 8: the fp32 logit gradient beside the bf16 one
     void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes; void *hcs_ws; size_t hcs_ws_bytes;
@@ -121,6 +122,8 @@ vnConv geom(const Rows &src, const int row_dims[3], int Cs, int Cr, const int k[
     return g;
 }
 const int ONE[3] = {1, 1, 1}, NEG[3] = {-1, -1, -1};
+struct Plan;
+const vnConv *cx(const Plan &P, vnConv &g);   // the geometry as the conv / weight-gradient entry points get it (fp32x3 mode: VN_F32X3)
 
 vnConv fwd_geom(const Spec &sp, const Rows &x, const int od[3], const Rows &out) {
     const int64_t os[4] = {out.sB, out.sD, out.sH, out.sW};
@@ -143,6 +146,10 @@ vnConv wgrad_geom(const Plan &P, int l, const Rows &x) {
     return geom(x, P.odims[l], sp.cin, sp.cout, sp.k, sp.s, ONE, sp.p, ONE, rs);
 }
 
+const vnConv *cx(const Plan &P, vnConv &g) {
+    if (P.x3 && g.dtype == VN_F32) g.dtype = VN_F32X3;
+    return &g;
+}
 int m0_bn_knob();
 int box_zero_total();
 bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
@@ -150,11 +157,12 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     // end at depth 2, the BEV fold of model.py:262 — D = 9 ... 12 (the reference's grids are all D = 10; round 4 lifted the
     // D == 10 restriction: nothing below depends on it, the walk checks the folded depth)
     if (!c || c->B <= 0 || c->D < 9 || c->D > 12 || c->H <= 0 || c->W <= 0 || (c->H & 7) || (c->W & 7)) return false;
-    if (c->mode != 0 && c->mode != 1) return false;
+    if (c->mode < 0 || c->mode > 2) return false;
     if (c->block1_stride != 1 && c->block1_stride != 2) return false;
     memset(P, 0, sizeof(*P));
     layer_table(c->block1_stride, P->spec);
-    const bool f32 = c->mode == 1;
+    const bool f32 = c->mode != 0;      // modes 1 (fp32) and 2 (fp32x3) store everything in fp32
+    P->x3 = c->mode == 2;
     P->esz = f32 ? 4 : 2;
     P->adt = f32 ? VN_F32 : VN_BF16;
     if (c->grad_storage & ~31) return false;
@@ -754,14 +762,14 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
                 q.src_sB = q.src_sD = q.src_sH = K * sp.cin; q.src_sW = sp.cin;
                 q.out_sB = q.out_sD = q.out_sH = K * q.Cr; q.out_sW = q.Cr;
                 RTT(T_CONV_FWD, l, 2.0 * K * sp.cin * 27.0 * sp.cout, (double)K * (sp.cin * P.esz + 27.0 * sp.cout * 4), stream,
-                    vn_conv_gather_gemm(vw_rows, P.wp_f[l], nullptr, P.rbP, VN_F32, &q, 0, nullptr, stream));
+                    vn_conv_gather_gemm(vw_rows, P.wp_f[l], nullptr, P.rbP, VN_F32, cx(P, q), 0, nullptr, stream));
             }
             RTT(T_FIRST, l, 0.0, 0.0, stream,
                 vn_rulebook_combine(P.rbP, P.igrid, P.alist, P.acap, P.acount, &g, L[l].bias, y.ptr, (vnDtype)y.dtype, slab,
                                     stream));
         } else {
             RTT(T_CONV_FWD, l, layer_flops(sp, P.in_dims[l], P.odims[l], cfg->B), rows_bytes(x) + rows_bytes(y), stream,
-                vn_conv_gather_gemm(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, &g, 0, slab, stream));
+                vn_conv_gather_gemm(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, cx(P, g), 0, slab, stream));
         }
         const Rows &a = P.a[l];
         const bool fuse_fin = slab && M <= bn_fuse_rows() && l != L_M2 && !(l == 0 && cfg->sparse_first);
@@ -822,7 +830,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
                 vn_heads_fwd(P.cat.ptr, P.cat.sW, P.hwp_f, heads_b, cfg->B, S, prob, reg, stream));
         } else {
         RTT(T_CONV_FWD, NL, 2.0 * cfg->B * S * 768 * 16, rows_bytes(P.cat) + rows_bytes(P.hy), stream,
-            vn_conv_gather_gemm(P.cat.ptr, P.hwp_f, heads_b, P.hy.ptr, VN_F32, &g, 0, nullptr, stream));
+            vn_conv_gather_gemm(P.cat.ptr, P.hwp_f, heads_b, P.hy.ptr, VN_F32, cx(P, g), 0, nullptr, stream));
         RTT(T_MISC, NL, 0.0, 2.0 * rows_bytes(P.hy), stream,
             vn_heads_to_nchw(reinterpret_cast<const float *>(P.hy.ptr), cfg->B, S, prob, reg, stream));
         }
@@ -928,11 +936,11 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 vn_heads_dgrad(P.d_rows.ptr, P.d_rows.sW, P.hwp_d, P.d_cat.ptr, P.d_cat.sW, (int64_t)B * S, stream));
         else
         RTT(T_CONV_DGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.d_cat), stream,
-            vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.cdt, &gd, 0, nullptr, stream));
+            vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.cdt, cx(P, gd), 0, nullptr, stream));
         RT(fork());
         heads_forked = true;
         RTT(T_WGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.cat), wstream,
-            vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, &gw, 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
+            vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, cx(P, gw), 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
         unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
     }
     auto cat_slice = [&](int off) {
@@ -967,7 +975,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
             RTT(T_WGRAD, l, 2.0 * K * sp.cin * 27.0 * C, 0.0, wstream,
-                vn_conv_wgrad_partials(dy.ptr, vw_rows, &gw, 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+                vn_conv_wgrad_partials(dy.ptr, vw_rows, cx(P, gw), 0, coord, K, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
             return VN_OK;
         }
@@ -982,21 +990,21 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             const int64_t rs[4] = {0, 0, 0, sp.cin};
             vnConv gl = geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
             RTT(T_WGRAD, l, 2.0 * active_rows * taps * sp.cin * C, rows_bytes(dy) + 2.0 * active_rows * sp.cin * P.esz, wstream,
-                vn_conv_wgrad_partials_counted(dy.ptr, P.drows, &gl, P.alist, P.acap, P.acount, P.dwp[l], P.dwp_bytes[l], &wch,
+                vn_conv_wgrad_partials_counted(dy.ptr, P.drows, cx(P, gl), P.alist, P.acap, P.acount, P.dwp[l], P.dwp_bytes[l], &wch,
                                                wstream));
             rank1_job = nu;
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 2, 1, wch, dw_elems};
             return VN_OK;
         }
         const Rows x = input_of(l);
-        const vnConv gw = wgrad_geom(P, l, x);
+        vnConv gw = wgrad_geom(P, l, x);
         if (sp.transposed) {
             RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(x) + rows_bytes(dy), wstream,
-                vn_conv_wgrad_partials(dy.ptr, x.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+                vn_conv_wgrad_partials(dy.ptr, x.ptr, cx(P, gw), 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, sp.cin, C, taps, 0, 1, wch, dw_elems};
         } else {
             RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(x) + rows_bytes(dy), wstream,
-                vn_conv_wgrad_partials(x.ptr, dy.ptr, &gw, 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
+                vn_conv_wgrad_partials(x.ptr, dy.ptr, cx(P, gw), 0, nullptr, 0, P.dwp[l], P.dwp_bytes[l], &wch, wstream));
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, wch, dw_elems};
         }
         return VN_OK;
@@ -1139,7 +1147,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
             RTT(T_CONV_DGRAD, l, 2.0 * K * sp.cin * 27.0 * C, 0.0, ls,
-                vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, &gw, coord, K, nullptr, 1, nullptr, ls));
+                vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, d_input, VN_F32, cx(P, gw), coord, K, nullptr, 1, nullptr, ls));
             return VN_OK;
         }
         if (l == 1 && P.list_bwd) {
@@ -1163,7 +1171,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             const int64_t rs[4] = {0, 0, 0, sp.cin};
             vnConv gl = geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
             RTT(T_CONV_DGRAD, l, 2.0 * active_rows * taps * sp.cin * C, rows_bytes(dy) + 2.0 * active_rows * sp.cin * P.esz, ls,
-                vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, P.dx[l].ptr, (vnDtype)P.dx[l].dtype, &gl, P.alist, P.acap,
+                vn_conv_gather_gemm_rows(dy.ptr, P.wp_d[l], nullptr, P.dx[l].ptr, (vnDtype)P.dx[l].dtype, cx(P, gl), P.alist, P.acap,
                                          P.acount, 1, nullptr, ls));
             return VN_OK;
         }
@@ -1180,17 +1188,17 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         // own reduce launch — 4-8 us plus the gap between two dependent launches — is skipped in do_layer(l - 1))
         const bool below_plain = l >= 2 && l - 1 != L_M2 && l - 1 != L_D1 && l - 1 != L_D2 && l - 1 != L_D3 && l != L_D1 &&
                                  l != L_D2 && l != L_D3 && !P.spec[l - 1].transposed;
-        if (fuse_bwd_reduce_on() && single_call && !accumulate && !on_side && below_plain && vn_conv_plan_id(&gd) == 123 &&
+        if (fuse_bwd_reduce_on() && single_call && !accumulate && !on_side && below_plain && vn_conv_plan_id(cx(P, gd)) == 123 &&
             P.y[l - 1].sB == dx.sB && P.y[l - 1].sD == dx.sD && P.y[l - 1].sH == dx.sH && P.y[l - 1].sW == dx.sW &&
-            vn_conv_stats_slab_rows(&gd) <= P.bslab_rows[l - 1]) {
+            vn_conv_stats_slab_rows(cx(P, gd)) <= P.bslab_rows[l - 1]) {
             RTT(T_CONV_DGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(dy) + 2.0 * rows_bytes(dx), ls,
-                vn_conv_dgrad_bn_bwd(dy.ptr, P.wp_d[l], dx.ptr, (vnDtype)dx.dtype, &gd, P.y[l - 1].ptr, (vnDtype)P.y[l - 1].dtype,
+                vn_conv_dgrad_bn_bwd(dy.ptr, P.wp_d[l], dx.ptr, (vnDtype)dx.dtype, cx(P, gd), P.y[l - 1].ptr, (vnDtype)P.y[l - 1].dtype,
                                      P.stats[l - 1], P.bslab[l - 1], ls));
-            fused_rows[l - 1] = vn_conv_stats_slab_rows(&gd);
+            fused_rows[l - 1] = vn_conv_stats_slab_rows(cx(P, gd));
             return VN_OK;
         }
         RTT(T_CONV_DGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(dy) + rows_bytes(dx), ls,
-            vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, &gd, accumulate ? 1 : 0, nullptr, ls));
+            vn_conv_gather_gemm(dy.ptr, P.wp_d[l], nullptr, dx.ptr, (vnDtype)dx.dtype, cx(P, gd), accumulate ? 1 : 0, nullptr, ls));
         return VN_OK;
     };
     // Single-call backward with a side stream: deconv2 / deconv1 only depend on the heads' data gradient, so their

@@ -35,6 +35,7 @@ struct WGParams {
     int32_t kD, kH, kW;
     int32_t C, N;             // real source / row channels
     int32_t split;
+    int32_t x3;               // VN_F32X3: fp32 tiles, products as three bf16 MFMAs
     int32_t rows_per_chunk;   // multiple of 64
     int32_t tiles_k;          // number of DK tiles
     uint32_t src_bytes, rows_bytes;
@@ -271,6 +272,39 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
         if constexpr (F32) {
             // v_mfma_f32_16x16x4_f32: lane (c = lane&15, kq = lane>>4) supplies element [site 4s+kq][col c]
             const int fc = lane & 15, kq = lane >> 4;
+            if (p.x3) {
+                // fp32x3: the lane's eight sites 4 ss + kq (ss = 0..7) of a column are its eight k values of ONE
+                // v_mfma_f32_16x16x32_bf16 (same (ss, kq) <-> k assignment for both operands), split hi / lo in registers
+                static_assert(ROWS == 32, "eight sites per lane");
+                bf16x8_t ah[TN], al[TN];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int col = (wn * TN + i) * 16 + fc;
+                    float v[8];
+#pragma unroll
+                    for (int ss = 0; ss < 8; ++ss) {
+                        const int r = ss * 4 + kq;
+                        v[ss] = *reinterpret_cast<const float *>(ln + r * RBN + ((((col >> 2) ^ chunk_swz<RBN, true>(r))) << 4) + (col & 3) * 4);
+                    }
+                    vn_split8(v, ah[i], al[i]);
+                }
+#pragma unroll
+                for (int t = 0; t < TPB; ++t)
+#pragma unroll
+                    for (int j = 0; j < TK; ++j) {
+                        const int col = (wk * TK + j) * 16 + fc;
+                        float v[8];
+#pragma unroll
+                        for (int ss = 0; ss < 8; ++ss) {
+                            const int r = ss * 4 + kq;
+                            v[ss] = *reinterpret_cast<const float *>(lk0 + t * TILE_K + r * RBK + ((((col >> 2) ^ chunk_swz<RBK, true>(r))) << 4) + (col & 3) * 4);
+                        }
+                        bf16x8_t bh, bl;
+                        vn_split8(v, bh, bl);
+#pragma unroll
+                        for (int i = 0; i < TN; ++i) acc[t][i][j] = vn_mfma_x3(ah[i], al[i], bh, bl, acc[t][i][j]);
+                    }
+            } else
 #pragma unroll
             for (int ss = 0; ss < ROWS / 4; ++ss) {
                 const int r = ss * 4 + kq;
@@ -609,7 +643,7 @@ struct WGPlan {
 };
 static WGPlan wgrad_plan(const vnConv *g, int32_t split, int64_t M) {
     WGPlan w{};
-    const bool f32 = g->dtype == VN_F32;
+    const bool f32 = g->dtype != VN_BF16;   // (VN_F32X3: the fp32 kernels)
     const int taps = g->kD * g->kH * g->kW;
     // three-tap mode (bf16): one workgroup owns the three kW taps of a (kd,kh) pair, a 64-row `rows` slab is
     // staged and fragment-read once for all three -> 3x the MFMA work per barrier
@@ -757,8 +791,8 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     VN_CHECK_ARG(g->kD >= 1 && g->kH >= 1 && g->kW >= 1 && g->kD * g->kH * g->kW <= 65535);
     if (!row_list && (g->divD != 1 || g->divH != 1 || g->divW != 1)) return VN_EUNSUPPORTED;
     if (g->divD < 1 || g->divH < 1 || g->divW < 1) return VN_EINVAL;
-    VN_CHECK_ARG(g->dtype == VN_BF16 || (g->dtype == VN_F32 && !split));
-    const bool f32 = g->dtype == VN_F32;
+    VN_CHECK_ARG(g->dtype == VN_BF16 || ((g->dtype == VN_F32 || g->dtype == VN_F32X3) && !split));
+    const bool f32 = g->dtype != VN_BF16;
     const int esz = f32 ? 4 : 2, al = 16 / esz - 1;
     if (g->Cs <= 0 || (g->Cs & al) || g->Cr <= 0 || (g->Cr & al)) return VN_EUNSUPPORTED;
     if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & al) != 0) return VN_EUNSUPPORTED;
@@ -777,6 +811,7 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     p.padD = g->padD; p.padH = g->padH; p.padW = g->padW;
     p.kD = g->kD; p.kH = g->kH; p.kW = g->kW;
     p.C = g->Cs; p.N = g->Cr; p.split = split ? 1 : 0;
+    p.x3 = g->dtype == VN_F32X3;
     const int wmul = split ? 2 : 1;
     const int64_t sbytes = ((int64_t)(g->B - 1) * g->src_sB + (int64_t)(g->Ds - 1) * g->src_sD +
                             (int64_t)(g->Hs - 1) * g->src_sH + (int64_t)(g->Ws - 1) * g->src_sW + wmul * g->Cs) * esz;
@@ -873,7 +908,14 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     static const int tri_waves = vn_knob("VN_WG_TRI_WAVES", 8);   // waves per workgroup of the three-tap tiles (4: round 2)
     if (tri && tri_waves == 8) rc = k128 ? launch_wgrad<2, 2, false, 3, 4>(p, grid, st) : launch_wgrad<2, 1, false, 3, 4>(p, grid, st);
     else if (tri) rc = k128 ? launch_wgrad<2, 4, false, 3>(p, grid, st) : launch_wgrad<2, 2, false, 3>(p, grid, st);
-    else if (f32) {
+    else if (f32 && p.x3) {
+        // fp32x3: a stage is 48 bf16 MFMAs per 128 x 128 tile instead of 128 fp32 ones — the four-wave workgroup that the
+        // exact fp32 path can afford (its MFMAs hide everything) leaves the fragment gathers exposed: eight waves
+        if (n128 && k128) rc = launch_wgrad<4, 2, true, 1, 4>(p, grid, st);
+        else if (n128) rc = launch_wgrad<4, 1, true, 1, 4>(p, grid, st);
+        else if (k128) rc = launch_wgrad<2, 2, true, 1, 4>(p, grid, st);
+        else rc = launch_wgrad<2, 1, true, 1, 4>(p, grid, st);
+    } else if (f32) {
         if (n128 && k128) rc = launch_wgrad<4, 4, true, 1>(p, grid, st);
         else if (n128) rc = launch_wgrad<4, 2, true, 1>(p, grid, st);
         else if (k128) rc = launch_wgrad<2, 4, true, 1>(p, grid, st);

@@ -36,7 +36,16 @@ def _dt(t):
     return VN_F32 if t.dtype == torch.float32 else VN_BF16
 
 
-MODES = ("bf16", "fp32", "bf16x3")
+MODES = ("bf16", "fp32", "bf16x3", "fp32x3")
+# "fp32x3" (round 4): fp32 storage exactly like "fp32", but the convolutions / weight gradients evaluate every product as
+# three bf16 MFMAs on hi / lo splits made in registers (vnDtype VN_F32X3) — ~1e-4 on the RPN maps at a fraction of the
+# exact fp32 MFMA cost.  The per-launch geometry carries the operand dtype, so the flag below is all the per-layer path needs.
+X3 = {"on": False}
+VN_F32X3 = 2
+
+
+def is_f32_storage(mode):
+    return mode in ("fp32", "fp32x3")
 
 
 def is_split(mode):
@@ -44,7 +53,7 @@ def is_split(mode):
 
 
 def act_dtype_of(mode):
-    return torch.float32 if mode == "fp32" else torch.bfloat16
+    return torch.float32 if is_f32_storage(mode) else torch.bfloat16
 
 
 def plain_dtype_of(mode):
@@ -130,6 +139,8 @@ def new_rows(B, dims, C, dtype, split, device):
 def _geom(B, src, row_dims, Cs_eff, src_wrap, Cr, k, mul, tmul, pad, div, out_strides):
     g = VnConv()
     g.dtype = _dt(src.t)
+    if X3["on"] and g.dtype == VN_F32:
+        g.dtype = VN_F32X3
     g.B = B
     g.Ds, g.Hs, g.Ws = src.dims
     g.Dr, g.Hr, g.Wr = row_dims

@@ -32,10 +32,12 @@ _PRECISION = {"mode": "bf16"}
 
 def set_precision(mode):
     """'bf16' (bf16 storage + MFMA, BASELINE configs[1]), 'fp32' (exact fp32 MFMA, the parity
-    mode) or 'bf16x3' (see engine.py)."""
+    mode), 'fp32x3' (fp32 storage, every conv product as three bf16 MFMAs: ~1e-4 maps, the fast mode inside the 1e-3
+    tolerance) or 'bf16x3' (see engine.py)."""
     if mode not in E.MODES:
         raise ValueError(mode)
     _PRECISION["mode"] = mode
+    E.X3["on"] = mode == "fp32x3"
 
 
 def get_precision():
@@ -417,7 +419,7 @@ class _MiddleFn(torch.autograd.Function):
         with torch.cuda.device(x.device):
             B, D, H, W, C = x.shape
             xc = x.contiguous().float()
-            if mode == "fp32":
+            if E.is_f32_storage(mode):
                 dense = Rows(xc, 128)
             else:
                 dense = E.new_rows(B, (D, H, W), 128, torch.bfloat16, E.is_split(mode), x.device)
@@ -608,8 +610,8 @@ class _DetectorFn(torch.autograd.Function):
                 sparse = bool(rpn.sparse_first_layer)
                 D, H, W = fn._grid.dims
                 K = feature.shape[0]
-                cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, 1 if mode == "fp32" else 0, int(training), int(sparse), 0, 0)
-                cfg.grad_storage = int(rpn.grad_storage) & (16 if mode == "fp32" else 15)
+                cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, {"bf16": 0, "fp32": 1, "fp32x3": 2}[mode], int(training), int(sparse), 0, 0)
+                cfg.grad_storage = int(rpn.grad_storage) & (16 if E.is_f32_storage(mode) else 15)
                 side = rpn._side_stream(dev_) if rpn.overlap_wgrad else None
                 arr, _ = _native_layer_arrays(mid)
                 lib = _lib.load()
@@ -643,7 +645,7 @@ class _DetectorFn(torch.autograd.Function):
                 # With the sparse first Conv3d (rulebook evaluation: voxel rows x packed weights, then a gather-sum per
                 # active site) the dense (B,10,400,352,128) grid of model.py:102-106 is never built.
                 dense = None if sparse else scatter_rows(vw, coord, B, fn._grid.dims, mode)
-                if mode == "fp32":
+                if E.is_f32_storage(mode):
                     vw_rows = vw.bfloat16().float() if cfg.grad_storage & 16 else vw      # (diagnostic: see vnNetConfig)
                 else:
                     vw_rows = torch.empty((vw.shape[0], 128), dtype=torch.bfloat16, device=vw.device)
@@ -674,7 +676,7 @@ class _DetectorFn(torch.autograd.Function):
             dense = scatter_rows(vw, coord, B, fn._grid.dims, mode)
             sparse = None
             if rpn.sparse_first_layer and not E.is_split(mode):
-                if mode == "fp32":
+                if E.is_f32_storage(mode):
                     vw_rows = vw
                 else:
                     vw_rows = torch.empty((vw.shape[0], 128), dtype=torch.bfloat16, device=vw.device)
