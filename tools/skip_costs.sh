@@ -9,6 +9,6 @@ run() { VN_SKIP=$1 timeout -k 10 200 python bench.py --steps 60 --warmup 10 --no
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-22s %7.1f pc/s  %.3f ms/step' % ('$2', d['value'], d['ms_per_step']))"; }
 run 0 nothing_skipped
-for k in 2 3 4 5 6 7 8 10; do run $((1 << k)) "skip_${names[$k]}"; done
+for k in 0 1 2 3 4 5 6 7 8 10; do run $((1 << k)) "skip_${names[$k]}"; done
 run $(( (1<<2) | (1<<7) | (1<<8) )) skip_wgrad+unpack+pack
 run 0 nothing_skipped
