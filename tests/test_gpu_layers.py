@@ -658,3 +658,61 @@ def test_fused_batchnorm_finalize_apply_is_bit_identical_to_the_two_launches(dt,
         assert torch.equal(u.view(torch.int16 if u.dtype == torch.bfloat16 else torch.int32),
                            v.view(torch.int16 if v.dtype == torch.bfloat16 else torch.int32)), name
     assert torch.isfinite(b1[0]).all() and torch.isfinite(b1[3].float()).all()
+
+
+def test_fp32x3_conv3d_weight_gradient_through_hi_lo_copies():
+    """fp32x3 (vnNetConfig.mode 2), middle_layer.2's weight gradient (model.py:209 backward) as the executor computes it: both
+    operands cast once to [hi|lo] bf16 rows (vn_cast_rows with a residual offset), then THREE launches of the bf16 weight
+    gradient over them — hi.hi, lo(src).hi, hi(src).lo(rows) — into consecutive partial slabs that one unpack sums.  At the
+    production size (2 x 3 x 400 x 352 -> 2 x 2 x 400 x 352, 64 -> 64 channels, the patch kernel: plan 200) against the exact
+    fp32 weight gradient of the same operands: relative L2 <= 2e-5 (three bf16 products carry ~2^-16 each)."""
+    import ctypes
+    from voxelnet_amd import _lib
+    from voxelnet_amd import engine as E
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    B, din, dout, H, W, C = 2, 3, 2, 400, 352, 64
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((B, din, H, W, C), generator=g).to(dev)
+    dy = (torch.randn((B, dout, H, W, C), generator=g) * 1e-2).to(dev)
+    taps, k, s, p = 27, (3, 3, 3), (2, 1, 1), (1, 1, 1)
+    one = (1, 1, 1)
+
+    def partials(src, rows, src_view, row_view, out, out_bytes):
+        gq = E._geom(B, src_view, (dout, H, W), C, 0, C, k, s, one, p, one, row_view.strides)
+        ch = ctypes.c_int32(0)
+        _lib.call("vn_conv_wgrad_partials", src, rows, ctypes.byref(gq), 0, None, 0, out, out_bytes, ctypes.byref(ch), E.stream())
+        return ch.value, gq
+    # exact fp32 reference: the same entry point on the fp32 operands
+    xr, dr = E.Rows(x, C), E.Rows(dy, C)
+    g32 = E._geom(B, xr, (dout, H, W), C, 0, C, k, s, one, p, one, dr.strides)
+    ws32, wsb32 = E.wgrad_workspace(g32, 0, 0, dev)
+    ch32, _ = partials(xr.ptr(), dr.ptr(), xr, dr, ws32.data_ptr(), wsb32)
+    dw32 = torch.empty((C, C, 3, 3, 3), device=dev)
+    jobs = (_lib.VnUnpackJob * 1)()
+    jobs[0] = _lib.VnUnpackJob(ws32.data_ptr(), dw32.data_ptr(), C, C, taps, 0, 1, ch32, taps * C * C)
+    _lib.call("vn_unpack_wgrads_batch", jobs, 1, E.stream())
+    # the executor's route
+    xh = torch.empty((B, din, H, W, 2 * C), dtype=torch.bfloat16, device=dev)
+    dh = torch.empty((B, dout, H, W, 2 * C), dtype=torch.bfloat16, device=dev)
+    _lib.call("vn_cast_rows", x.data_ptr(), _lib.VN_F32, C, x.numel() // C, C, xh.data_ptr(), _lib.VN_BF16, 2 * C, C, E.stream())
+    _lib.call("vn_cast_rows", dy.data_ptr(), _lib.VN_F32, C, dy.numel() // C, C, dh.data_ptr(), _lib.VN_BF16, 2 * C, C, E.stream())
+    hi = x.bfloat16().float()
+    assert torch.equal(xh[..., :C].float(), hi) and torch.equal(xh[..., C:].float(), (x - hi).bfloat16().float())
+    xv, dv = E.Rows(xh[..., :C], C), E.Rows(dh[..., :C], C)           # views: row width 2 C, C channels
+    gb = E._geom(B, xv, (dout, H, W), C, 0, C, k, s, one, p, one, dv.strides)
+    assert lib.vn_conv_wgrad_plan_id(ctypes.byref(gb), 0, 0) == 200           # the bf16 patch kernel
+    per = lib.vn_conv_wgrad_workspace_bytes(ctypes.byref(gb), 0, 0)
+    ws = torch.empty(3 * per, dtype=torch.uint8, device=dev)
+    total = 0
+    for src_lo, rows_lo in ((0, 0), (1, 0), (0, 1)):
+        ch, _ = partials(xh.data_ptr() + 2 * C * src_lo, dh.data_ptr() + 2 * C * rows_lo, xv, dv,
+                         ws.data_ptr() + total * taps * C * C * 4, per)
+        total += ch
+    dw = torch.empty_like(dw32)
+    jobs[0] = _lib.VnUnpackJob(ws.data_ptr(), dw.data_ptr(), C, C, taps, 0, 1, total, taps * C * C)
+    _lib.call("vn_unpack_wgrads_batch", jobs, 1, E.stream())
+    torch.cuda.synchronize()
+    l2 = float((dw.double() - dw32.double()).norm() / dw32.double().norm())
+    print(f"fp32x3 Conv3d weight gradient through [hi|lo] copies vs exact fp32: rel-L2 {l2:.2e} ({total} partial slabs)")
+    assert l2 < 2e-5, l2

@@ -89,6 +89,7 @@ struct Plan {
     Rows dy[NL], dx[NL];
     float *dwp[NL]; size_t dwp_bytes[NL];   // row-chunk partials of the weight gradient (vn_conv_wgrad_partials)
     // heads
+    void *x3_src, *x3_rows;   // fp32x3: [hi|lo] bf16 copies of middle_layer.2's input and dy (its weight gradient runs on the bf16 patch kernel)
     bool x3;          // cfg->mode == 2 ("fp32x3"): fp32 storage, the convolutions' and weight gradients' products as three bf16 MFMAs
     bool round_act;   // fp32 mode diagnostic (grad_storage & 16): activations rounded to bf16 VALUES, everything else exact fp32
     bool exact_heads; Rows d_rows32;   // grad_storage & 8: the fp32 logit gradient beside the bf16 one
@@ -149,6 +150,19 @@ vnConv wgrad_geom(const Plan &P, int l, const Rows &x) {
 const vnConv *cx(const Plan &P, vnConv &g) {
     if (P.x3 && g.dtype == VN_F32) g.dtype = VN_F32X3;
     return &g;
+}
+// fp32x3, middle_layer.2's weight gradient: in fp32 the row form re-stages both operands once per tap (27 x: 2.4 ms); the
+// operands are cast to [hi|lo] bf16 rows once (row width 2 C) and the bf16 patch kernel runs three times over them —
+// hi.hi, lo(src).hi, hi(src).lo(rows) — into consecutive partial slabs that the unpack sums like row chunks
+vnConv x3_wgrad_geom(const Plan &P, int l, void *src_hl, void *rows_hl, int src_lo, int rows_lo) {
+    const Spec &sp = P.spec[l];
+    const int B = P.dy[l].B;
+    Rows xs = dense_rows(src_hl, VN_BF16, B, P.in_dims[l][0], P.in_dims[l][1], P.in_dims[l][2], sp.cin, 2 * sp.cin);
+    Rows ds = dense_rows(rows_hl, VN_BF16, B, P.odims[l][0], P.odims[l][1], P.odims[l][2], sp.cout, 2 * sp.cout);
+    if (xs.ptr) xs.ptr += (size_t)(src_lo ? sp.cin : 0) * 2;
+    if (ds.ptr) ds.ptr += (size_t)(rows_lo ? sp.cout : 0) * 2;
+    const int64_t rs[4] = {ds.sB, ds.sD, ds.sH, ds.sW};
+    return geom(xs, P.odims[l], sp.cin, sp.cout, sp.k, sp.s, ONE, sp.p, ONE, rs);
 }
 int m0_bn_knob();
 int box_zero_total();
@@ -327,6 +341,11 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
                 b = ask(P->in_dims[0], sp.cout, sp.cin, sp.k, K > 0 ? K : 1);
             } else if (l == 1 && P->sparse_w1) {
                 b = ask(P->in_dims[1], sp.cout, sp.cin, sp.k, P->acap);
+            } else if (l == L_M2 && P->x3) {   // three passes of the bf16 kernel over [hi|lo] copies (x3_wgrad_geom)
+                const vnConv gb = x3_wgrad_geom(*P, l, nullptr, nullptr, 0, 0);
+                b = 3 * vn_conv_wgrad_workspace_bytes(&gb, 0, 0);
+                P->x3_src = A.take((size_t)B * P->in_dims[l][0] * P->in_dims[l][1] * P->in_dims[l][2] * 2 * sp.cin * 2);
+                P->x3_rows = A.take((size_t)B * P->odims[l][0] * P->odims[l][1] * P->odims[l][2] * 2 * sp.cout * 2);
             } else {   // the real launch geometry: the kernel variant (and its chunking) is chosen from it
                 const Rows xin = dense_rows(nullptr, P->adt, B, P->in_dims[l][0], P->in_dims[l][1], P->in_dims[l][2], sp.cin);
                 const vnConv gw = wgrad_geom(*P, l, xin);
@@ -997,6 +1016,27 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             return VN_OK;
         }
         const Rows x = input_of(l);
+        if (l == L_M2 && P.x3) {
+            RTT(T_MISC, l, 0.0, 2.0 * rows_bytes(x), wstream,
+                vn_cast_rows(x.ptr, VN_F32, x.sW, x.M(), sp.cin, P.x3_src, VN_BF16, 2 * sp.cin, sp.cin, wstream));
+            RTT(T_MISC, l, 0.0, 2.0 * rows_bytes(dy), wstream,
+                vn_cast_rows(dy.ptr, VN_F32, dy.sW, dy.M(), C, P.x3_rows, VN_BF16, 2 * C, C, wstream));
+            const size_t pass_bytes = P.dwp_bytes[l] / 3;
+            int32_t total = 0;
+            for (int pass = 0; pass < 3; ++pass) {
+                vnConv gb = x3_wgrad_geom(P, l, P.x3_src, P.x3_rows, pass == 1, pass == 2);
+                const Rows xs = dense_rows(P.x3_src, VN_BF16, B, P.in_dims[l][0], P.in_dims[l][1], P.in_dims[l][2], sp.cin, 2 * sp.cin);
+                const Rows ds = dense_rows(P.x3_rows, VN_BF16, B, P.odims[l][0], P.odims[l][1], P.odims[l][2], C, 2 * C);
+                int32_t ch = 1;
+                float *slabs = P.dwp[l] + (size_t)total * dw_elems;
+                RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B) / 3.0, (rows_bytes(x) + rows_bytes(dy)) / 3.0, wstream,
+                    vn_conv_wgrad_partials(xs.ptr + (size_t)(pass == 1 ? sp.cin : 0) * 2, ds.ptr + (size_t)(pass == 2 ? C : 0) * 2, &gb, 0,
+                                           nullptr, 0, slabs, pass_bytes, &ch, wstream));
+                total += ch;
+            }
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, total, dw_elems};
+            return VN_OK;
+        }
         vnConv gw = wgrad_geom(P, l, x);
         if (sp.transposed) {
             RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B), rows_bytes(x) + rows_bytes(dy), wstream,
