@@ -487,7 +487,6 @@ extern "C" int vn_net_create(vnNet **out) {
         for (int w = 0; w < 2 && err == hipSuccess; ++w) err = hipEventCreateWithFlags(&n->bucket_ev[b][w], hipEventDisableTiming);
     for (int i = 0; i < 64 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&n->ring[i], hipEventDisableTiming);
     for (int i = 0; i < 2 && err == hipSuccess; ++i) err = hipEventCreateWithFlags(&n->prep_ev[i], hipEventDisableTiming);
-    for (int i = 0; i < 3 && err == hipSuccess; ++i) err = hipStreamCreateWithFlags(&n->wg_stream[i], hipStreamNonBlocking);
     if (err != hipSuccess) {
         vn_net_destroy(n);
         return (int)err;
@@ -917,6 +916,8 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // there reads a partial slab (the unpacks)
     static const int wg_streams_knob = vn_knob("VN_WG_STREAMS", 1);
     const int n_wg = ws == hs ? 1 : (wg_streams_knob < 1 ? 1 : (wg_streams_knob > 4 ? 4 : wg_streams_knob));
+    for (int i = 0; i + 1 < n_wg; ++i)      // (created on first use: the default, one stream, never needs them)
+        if (!net->wg_stream[i]) VN_HIP(hipStreamCreateWithFlags(&net->wg_stream[i], hipStreamNonBlocking));
     unsigned wg_rr = 0;
     bool wg_used[3] = {false, false, false};
     auto join_wg = [&]() -> int {
