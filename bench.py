@@ -202,7 +202,7 @@ def main():
     from voxelnet_amd import parallel, synth
     from voxelnet_amd.config import GRADIENT_CLIP, LR, grid_config
     from voxelnet_amd.optim import ClipSGD
-    from voxelnet_amd.voxelize import VoxelBatch, VoxelBuffers, voxelize_device_async
+    from voxelnet_amd.voxelize import VoxelBatch, VoxelBuffers, pipeline_stream, voxelize_device_async
 
     cfg_index, workload_id, cls, T, default_batch, cfg_desc = CONFIGS[args.config]
     B = args.batch or default_batch
@@ -252,7 +252,7 @@ def main():
     # queue (capacity-sized outputs, K read by the gather kernel from device memory, asynchronous K copy to pinned memory:
     # voxelize_device_async).  Every timed step still runs one voxelization of its B frames (for the next step) and one
     # train step (on the buffers voxelized during the previous one).
-    vox_stream = torch.cuda.Stream()
+    vox_stream = pipeline_stream(dev)      # (the input pipeline's stream, shared with the target generator: 4 streams in all with a reducer)
     pending = {}
     slots = [[VoxelBuffers(pts.shape[0], grid, 4, dev) for pts in frames] for _ in range(3)]   # 3-deep ring
     ring = {"i": 0, "use": 0}

@@ -18,7 +18,7 @@ import torch
 
 from . import _lib
 from .config import grid_config
-from .voxelize import VoxelBatch, voxelize_device_async
+from .voxelize import VoxelBatch, pipeline_stream, voxelize_device_async
 
 
 def _read_image(path):
@@ -76,7 +76,7 @@ class DeviceCollate:
         self.grid = grid_config("Car" if target == "Car" else "Pedestrian")    # utils.py:24-33 ('Car' else ped/cyc)
         self.shuffle_points = shuffle_points
         self.fov_calib_dir, self.image_shape = fov_calib_dir, tuple(image_shape)
-        self.stream = torch.cuda.Stream(device=self.device)
+        self.stream = pipeline_stream(self.device)      # (shared with the target generator: see voxelize.pipeline_stream)
 
     def launch(self, parts):
         """enqueue the copies and the voxelization of one batch on the pipeline's stream; returns a handle"""

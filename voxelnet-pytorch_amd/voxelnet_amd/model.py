@@ -911,6 +911,18 @@ class _LossFn(torch.autograd.Function):
         return d_prob, d_delta, None, None, None, None, None, None
 
 
+_STREAMS = {}
+
+
+def _shared_stream(device, role):
+    """process-wide stream of a role ('side', 'targets') on a device (see RPN3D._side_stream)"""
+    key = (torch.device(device), role)
+    st = _STREAMS.get(key)
+    if st is None:
+        st = _STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 class RPN3D(nn.Module):
     """model.py:284-362.  forward(x: 7-tuple batch, device) -> 7-tuple like the reference.
     Targets (model.py:309): generated on the device from the batch's label lines x[1] (voxelnet_amd/targets.py,
@@ -969,10 +981,13 @@ class RPN3D(nn.Module):
                 pass
 
     def _side_stream(self, device):
-        """HIP stream handle (ctypes) of the module-owned side stream for the native backward"""
+        """HIP stream handle (ctypes) of the side stream for the native executor.  ONE stream per device and role for all
+        modules of the process (round 4): the HIP runtime spreads streams over a handful of hardware queues (4 by default)
+        in creation order, so a second model's own side stream could share a queue with the training stream and serialise
+        against it — measured with the third model of bench.py's parity block: 193 instead of 231 point-clouds/s."""
         st = self.__dict__.get("_side")
         if st is None or st.device != torch.device(device):
-            st = torch.cuda.Stream(device=device)
+            st = _shared_stream(device, "side")
             self.__dict__["_side"] = st
         return ctypes.c_void_p(st.cuda_stream)
 
@@ -1115,7 +1130,8 @@ class RPN3D(nn.Module):
             dev_ = voxel_features[0].device
             ts = self.__dict__.get("_tgt_stream")
             if ts is None or ts.device != dev_:
-                ts = self.__dict__["_tgt_stream"] = torch.cuda.Stream(device=dev_)
+                from .voxelize import pipeline_stream
+                ts = self.__dict__["_tgt_stream"] = pipeline_stream(dev_)     # (the input pipeline's stream: one queue for both)
             with torch.cuda.stream(ts):
                 early = self._target_generator(dev_)(label)
         prob_out, delta_out = self.detect(voxel_features, voxel_coordinates)

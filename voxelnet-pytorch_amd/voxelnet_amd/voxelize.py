@@ -128,6 +128,25 @@ def voxelize_device_async(points, grid, batch_index=0, coord_cols=4, buffers=Non
     return AsyncVoxels(feature, coord, number, k_host, ev)
 
 
+_PIPELINE_STREAMS = {}
+
+
+def pipeline_stream(device):
+    """THE input-pipeline stream of a device: raw-cloud copies, field-of-view crop, voxelization, the batch concatenations and
+    (RPN3D.forward) the target generation all queue here.  One stream for all of them, process-wide: the HIP runtime maps
+    streams onto 4 hardware queues; with the training stream, the executor's side stream and (data-parallel runs) the
+    reducer's communication stream that makes four — a fifth stream shares a queue with one of them and serialises against
+    it (round 4: 540 instead of 556 point-clouds/s with the reducer attached), and MORE hardware queues are no way out
+    (GPU_MAX_HW_QUEUES=8 with five busy streams: 248 point-clouds/s — the queues are time-sliced)."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    st = _PIPELINE_STREAMS.get(dev)
+    if st is None:
+        st = _PIPELINE_STREAMS[dev] = torch.cuda.Stream(device=dev)
+    return st
+
+
 class VoxelBatch(list):
     """The per-sample tensors of one batch — what collate_fn (dataset.py:80-96) puts into x[2] / x[4] — plus their
     concatenation, made AHEAD of the train step on the input pipeline's stream (`cat`, `cat_event`).  The model
