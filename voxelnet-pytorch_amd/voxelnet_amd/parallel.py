@@ -70,7 +70,16 @@ class GradAllReducer:
         missing = [n for n, _ in named_params if n not in self.where]
         assert not missing, f"parameters without a bucket: {missing[:3]}"
         self.cuda = self.buckets[0]["flat"].is_cuda
-        self.comm_stream = torch.cuda.Stream() if (self.cuda and use_side_stream) else None
+        # The collectives are issued from the input pipeline's stream (voxelnet_amd.voxelize.pipeline_stream), not from a
+        # stream of their own: torch.distributed runs an NCCL collective on ITS internal stream, ordered behind the stream it
+        # is called from — with a private communication stream the process had five busy streams (training, executor side,
+        # pipeline, this one, torch's) on the HIP runtime's four hardware queues, i.e. two of them serialised against each
+        # other.  The pipeline stream is idle while the backward runs (the next batch was voxelized at
+        # the start of the step), so waiting for the bucket events there delays nothing.
+        self.comm_stream = None
+        if self.cuda and use_side_stream:
+            from .voxelize import pipeline_stream
+            self.comm_stream = pipeline_stream(self.buckets[0]["flat"].device)
         self.defer_allreduce = False   # True: grad_ready only fills the buckets (HIP-graph capture); allreduce_all() later
         self.comm = None               # ncclComm_t of the direct path
         if direct_rccl is None:
