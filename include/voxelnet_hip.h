@@ -34,11 +34,13 @@ extern "C" {
 #define VN_EWORKSPACE (-3) /* workspace too small */
 
 typedef enum { VN_F32 = 0, VN_BF16 = 1,
-               /* OPERAND dtype of the conv / weight-gradient entry points only (vnConv.dtype): fp32 storage — sources, rows
-                * and packed weights exactly as VN_F32 — with every product evaluated as three bf16 MFMAs on hi / lo splits
-                * made in registers (a.b ~= ah.bh + al.bh + ah.bl, ~2^-16 per product): the "fp32x3" mode, ~1e-4 on the RPN
-                * maps at a fraction of the exact fp32 MFMA cost (round 4).  Tensor dtypes (outputs, BatchNorm, ...) never
-                * take this value. */
+               /* OPERAND dtype of the conv / weight-gradient entry points only (vnConv.dtype): fp32 storage — sources and
+                * rows exactly as VN_F32 — with every product evaluated as three bf16 MFMAs on hi / lo splits (a.b ~=
+                * ah.bh + al.bh + ah.bl, ~2^-16 per product): the "fp32x3" mode, ~1e-4 on the RPN maps at a fraction of the
+                * exact fp32 MFMA cost (round 4).  Sources / rows are split in registers; PACKED WEIGHTS of a convolution
+                * launched with this dtype must come from vn_pack_weight(s_batch) with packed_dtype VN_F32X3, which splits
+                * them once (same bytes as fp32; the layout is described there).  Tensor dtypes (outputs, BatchNorm, ...)
+                * never take this value. */
                VN_F32X3 = 2 } vnDtype;
 
 typedef void *vnStream; /* hipStream_t */
@@ -301,6 +303,11 @@ int vn_fill_rows(void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stride, c
  * mode 2: ConvTranspose weight (Cin,Cout,kh,kw) -> forward operand [tap][Cout][Cin]
  * mode 3: ConvTranspose weight        -> data-grad operand [tap][Cin][Cout]
  * split3: emit the bf16x3 expansion [hi;hi;lo] along K (3x wide rows).
+ * packed_dtype VN_F32X3 (operand of a convolution launched with vnConv.dtype VN_F32X3): rows of K fp32-sized slots
+ * whose every aligned 128-B chunk (32 input channels k0..k0+31) holds the bf16 hi / lo parts of its weights in the order
+ * the kernels' lanes read them — 16-B granule q (0..3): hi of channels k0+4q..+3 then k0+16+4q..+3; granule 4+q: their
+ * lo parts (hi = bf16(w), lo = bf16(w - hi)).  Needs K % 32 == 0; for other K the packed operand is plain fp32 and the
+ * kernels split it in registers (the same values either way).
  * cin_fold f: the packed Cin index p stands for torch channel (p % (Cin/f))*f + p/(Cin/f)
  * (f = 2 implements the BEV reshape of model.py:262, channel = c*2 + d; else 1). */
 int vn_pack_weight(const float *w, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode,

@@ -716,3 +716,66 @@ def test_fp32x3_conv3d_weight_gradient_through_hi_lo_copies():
     l2 = float((dw.double() - dw32.double()).norm() / dw32.double().norm())
     print(f"fp32x3 Conv3d weight gradient through [hi|lo] copies vs exact fp32: rel-L2 {l2:.2e} ({total} partial slabs)")
     assert l2 < 2e-5, l2
+
+
+def test_fp32x3_weights_are_split_once_by_the_pack(x3_flag):
+    """fp32x3 (round 4): a convolution launched with VN_F32X3 reads its weights as hi / lo bf16 granules that
+    vn_pack_weight(packed_dtype VN_F32X3) wrote — include/voxelnet_hip.h documents the order: in every 32-channel chunk,
+    16-B granule q (0..3) = hi of channels 4q..4q+3 then 16+4q..16+4q+3, granule 4+q = their lo parts.  (a) the packed
+    bytes against that description, bit for bit, all four packing modes and the BEV fold; K = 16: plain fp32 (split in
+    registers).  (b) conv outputs and data gradients of one layer per kernel family in fp32x3 against the exact fp32 mode:
+    rel-L2 < 2e-5 (three bf16 products: ~2^-16 each) — a misplaced hi / lo value would cost ~1e-3."""
+    from voxelnet_amd import _lib, engine as E
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(5)
+    for (co, ci, taps, mode, fold) in [(64, 128, 27, 0, 1), (64, 128, 27, 1, 1), (256, 128, 4, 2, 1), (256, 128, 4, 3, 1),
+                                       (128, 128, 9, 0, 2), (16, 768, 1, 0, 1), (16, 768, 1, 1, 1)]:
+        w = torch.from_numpy(rng.standard_normal((co, ci, taps) if mode < 2 else (ci, co, taps)).astype(np.float32)).to(dev)
+        N, K = (co, ci) if mode in (0, 2) else (ci, co)
+        plain = torch.empty((taps, N, K), dtype=torch.float32, device=dev)
+        split = torch.empty((taps, N, K), dtype=torch.float32, device=dev)
+        _lib.call("vn_pack_weight", w.data_ptr(), co, ci, taps, mode, 0, fold, plain.data_ptr(), _lib.VN_F32, E.stream())
+        _lib.call("vn_pack_weight", w.data_ptr(), co, ci, taps, mode, 0, fold, split.data_ptr(), E.VN_F32X3, E.stream())
+        jobs = (_lib.VnPackJob * 1)()
+        batch = torch.empty_like(split)
+        jobs[0] = _lib.VnPackJob(w.data_ptr(), batch.data_ptr(), co, ci, taps, mode, 0, fold, E.VN_F32X3, 0)
+        _lib.call("vn_pack_weights_batch", jobs, 1, E.stream())
+        torch.cuda.synchronize()
+        assert torch.equal(split.view(torch.int32), batch.view(torch.int32))
+        if K % 32:
+            assert torch.equal(split, plain)
+            continue
+        c = plain.view(taps, N, K // 32, 2, 4, 4)                      # [chunk][half][q][e]: channel = half*16 + 4q + e
+        lane = c.permute(0, 1, 2, 4, 3, 5).reshape(taps, N, K // 32, 4, 8)   # [q][half*4 + e]: a lane's eight values
+        hi = lane.to(torch.bfloat16)
+        lo = (lane - hi.float()).to(torch.bfloat16)
+        want = torch.stack([hi, lo], dim=3).reshape(taps, N, K * 2)    # granules 0..3 = hi(q), 4..7 = lo(q)
+        assert torch.equal(split.view(torch.bfloat16).view(taps, N, K * 2).view(torch.int16), want.view(torch.int16))
+    cases = {c[0]: c for c in LAYER_CASES}
+    for name in ("c3_s111_p011", "c3_s211_p111", "c2_s1", "c2_s2", "c2_s1_256", "d_k2s2", "d_k3s1"):
+        case = cases[name]
+        idx = [c[0] for c in LAYER_CASES].index(name)
+        kind, dim = case[1], case[2]
+        spec = _spec(case)
+        sd = build_layer_state(idx, case)
+        wkey = "deconv" if kind == "deconv" else "conv"
+        res = {}
+        for mode in ("fp32", "fp32x3"):
+            x3_flag["on"] = mode == "fp32x3"
+            P = {"weight": sd[f"L.{wkey}.weight"].to(dev), "bias": sd[f"L.{wkey}.bias"].to(dev),
+                 "gamma": sd["L.batch_norm.weight"].to(dev), "beta": sd["L.batch_norm.bias"].to(dev)}
+            Bf = {"running_mean": sd["L.batch_norm.running_mean"].to(dev).clone(),
+                  "running_var": sd["L.batch_norm.running_var"].to(dev).clone()}
+            xr = E.nchw_to_rows(layer_input(idx, case).to(dev), "fp32")
+            a, st = E.layer_forward(spec, xr, P, Bf, True, "fp32")
+            up = layer_upstream(idx, case, tuple(E.rows_to_nchw(a, dim).shape)).to(dev)
+            grads, dx = E.layer_backward(st, E.nchw_to_plain_rows(up, torch.float32), P, "fp32")
+            res[mode] = (st.y.t.float().clone(), dx.t.float().clone())
+        x3_flag["on"] = False
+        (y32, dx32), (y3, dx3) = res["fp32"], res["fp32x3"]
+        l2 = float((y3 - y32).norm() / y32.norm())
+        assert 0.0 < l2 < 2e-5, (name, "y", l2)
+        # (dx passes the ReLU mask of BN(y): a pre-activation within 1e-5 of zero flips between the two modes and moves a few
+        #  dx values by a whole term — robust_err looks at the 95th percentile, which a misplaced weight part would still move)
+        e95 = robust_err(dx3, dx32.cpu().numpy())
+        assert 0.0 < e95 < 5e-5, (name, "dx", e95)

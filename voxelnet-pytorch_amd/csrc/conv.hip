@@ -62,7 +62,8 @@ struct GGParams {
     int32_t mulD, mulH, mulW, omulD, omulH, omulW;
     int32_t Cs, src_wrap, N, out_f32, accumulate, nclasses, src_row_elems;
     int32_t esz;                // operand element size: 2 (bf16) or 4 (fp32, exact v_mfma_f32_16x16x4_f32 path)
-    int32_t x3;                 // fp32 storage, products as three bf16 MFMAs (VN_F32X3): the F32 kernels' alternative inner loop
+    int32_t x3;                 // fp32 storage, products as three bf16 MFMAs (VN_F32X3): the F32 kernels' alternative inner loop;
+                                // 2 = the packed weights hold hi / lo bf16 granules (Cs % 32 == 0), 1 = fp32 weights split in registers
     int32_t kc_rot;             // k_conv_patch2d: workgroups start their K-chunk loop at chunk (tile mod nk) — tuning aid VN_P2D_ROT
     uint32_t w_bytes;
     int64_t src_batch_extent;   // elements spanned by one batch item (for num_records)
@@ -99,6 +100,17 @@ __device__ long long g_p2d_trace[64 * 8];
 __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds_wave_base, uint32_t voffset,
                                           uint32_t soffset) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)lds_wave_base, 16, voffset, soffset, 0, 0);
+}
+
+// fp32x3: a lane's eight weight values of a 32-channel chunk as hi / lo bf16 — from the two granules vn_pack_weight(VN_F32X3)
+// wrote (presplit) or split here from the two fp32 granules
+__device__ __forceinline__ void x3_weights(bool presplit, const char *g0, const char *g1, bf16x8_t &hi, bf16x8_t &lo) {
+    if (presplit) {
+        hi = *reinterpret_cast<const bf16x8_t *>(g0);
+        lo = *reinterpret_cast<const bf16x8_t *>(g1);
+    } else {
+        vn_split8(*reinterpret_cast<const f32x4_t *>(g0), *reinterpret_cast<const f32x4_t *>(g1), hi, lo);
+    }
 }
 
 // Store one workgroup's accumulators (+bias, optional accumulate) through the per-row offset table otab (LDS, -1 =
@@ -449,9 +461,7 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
                     vn_split8(*reinterpret_cast<const f32x4_t *>(la + i * 2048 + frag_off0),
                               *reinterpret_cast<const f32x4_t *>(la + i * 2048 + frag_off1), ah[i], al[i]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    vn_split8(*reinterpret_cast<const f32x4_t *>(lb + j * 2048 + frag_off0),
-                              *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + frag_off1), bh[j], bl[j]);
+                for (int j = 0; j < 4; ++j) x3_weights(p.x3 == 2, lb + j * 2048 + frag_off0, lb + j * 2048 + frag_off1, bh[j], bl[j]);
 #pragma unroll
                 for (int q = 0; q < LPS; ++q) piece(c, q);
 #pragma unroll
@@ -694,9 +704,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
                     if (p.x3) {
                         bf16x8_t bh[4], bl[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            vn_split8(*reinterpret_cast<const f32x4_t *>(lb + j * 2048 + bfrag0),
-                                      *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + bfrag1), bh[j], bl[j]);
+                        for (int j = 0; j < 4; ++j) x3_weights(p.x3 == 2, lb + j * 2048 + bfrag0, lb + j * 2048 + bfrag1, bh[j], bl[j]);
 #pragma unroll
                         for (int i = 0; i < SM; ++i) {
                             const int q = q0[i] + shift;
@@ -933,9 +941,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
                 if (p.x3) {
                     bf16x8_t bh[4], bl[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        vn_split8(*reinterpret_cast<const f32x4_t *>(lb + j * 2048 + bfrag0),
-                                  *reinterpret_cast<const f32x4_t *>(lb + j * 2048 + bfrag1), bh[j], bl[j]);
+                    for (int j = 0; j < 4; ++j) x3_weights(p.x3 == 2, lb + j * 2048 + bfrag0, lb + j * 2048 + bfrag1, bh[j], bl[j]);
 #pragma unroll
                     for (int i = 0; i < SM; ++i) {
                         const int q = q0[i] + shift;
@@ -1225,7 +1231,7 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
     p.out_f32 = out_dtype == VN_F32;
     p.src_row_elems = g->Cs;
     p.esz = esz;
-    p.x3 = g->dtype == VN_F32X3;
+    p.x3 = g->dtype == VN_F32X3 ? (vn_x3_presplit(g->Cs) ? 2 : 1) : 0;   // 2: weights split by vn_pack_weight (VN_F32X3 operand)
     const int taps_total = g->kD * g->kH * g->kW;
     const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * esz;
     if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;
@@ -1382,7 +1388,7 @@ static int gather_gemm_impl(const void *src, const void *w_packed, const float *
     p.accumulate = accumulate;
     p.src_row_elems = g->src_wrap > 0 ? g->src_wrap : g->Cs;
     p.esz = esz;
-    p.x3 = g->dtype == VN_F32X3;
+    p.x3 = g->dtype == VN_F32X3 ? (vn_x3_presplit(g->Cs) ? 2 : 1) : 0;   // 2: weights split by vn_pack_weight (VN_F32X3 operand)
     const int taps_total = g->kD * g->kH * g->kW;
     const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * esz;
     if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;

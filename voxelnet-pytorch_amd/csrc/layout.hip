@@ -23,6 +23,21 @@ __device__ __forceinline__ int64_t torch_index(int mode, int c_out, int c_in, in
     return ((int64_t)ci * c_out + co) * taps + tap;
 }
 
+// packed_dtype VN_F32X3 (include/voxelnet_hip.h, vn_pack_weight): element (row, k) of a [rows][K] fp32-sized operand, K % 32
+// == 0 -> its hi / lo bf16 parts where the lanes of the fp32x3 convolution kernels read them: a lane (fq = lane >> 4)
+// reads the 16-B granules fq and 4 + fq of every 128-B chunk and takes them as eight hi and eight lo values of the
+// channels 4 fq .. 4 fq + 3 and 16 + 4 fq .. 16 + 4 fq + 3 (the order vn_split8 produces from the two fp32 granules)
+__device__ __forceinline__ void store_x3_weight(void *packed, int64_t i, int K, float v) {
+    const int k = (int)(i % K);
+    const int kk = k & 31, g = kk >> 2, e = kk & 3;
+    const int q = g & 3, pos = (g >> 2) * 4 + e;
+    bf16_t *chunk = static_cast<bf16_t *>(packed) + (i - kk) * 2;      // 64 bf16 slots per 32-channel chunk
+    bf16_t hi, lo;
+    vn_split_bf16(v, hi, lo);
+    chunk[q * 8 + pos] = hi;
+    chunk[(4 + q) * 8 + pos] = lo;
+}
+
 __global__ void __launch_bounds__(256) k_pack_weight(const float *__restrict__ w, int c_out, int c_in, int taps,
                                                      int mode, int split3, int cin_fold, void *__restrict__ packed, int f32) {
     const int N = (mode == 0 || mode == 2) ? c_out : c_in;
@@ -35,7 +50,9 @@ __global__ void __launch_bounds__(256) k_pack_weight(const float *__restrict__ w
         const int tap = (int)(i / ((int64_t)Ke * N));
         const int k = ke % K, part = ke / K;   // part 0: hi, 1: hi, 2: lo
         const float v = w[torch_index(mode, c_out, c_in, taps, tap, n, k, cin_fold)];
-        if (f32) {
+        if (f32 == 2) {
+            store_x3_weight(packed, i, K, v);
+        } else if (f32) {
             static_cast<float *>(packed)[i] = v;
         } else {
             bf16_t hi, lo;
@@ -62,6 +79,7 @@ constexpr int UNPACK_LDS_FLOATS = 8192;   // 32 KB: the LDS tile of the batched 
 constexpr int PACK_MAX_JOBS = 56;
 struct PackJobs {
     int32_t n;
+    int32_t x3_presplit;                // VN_F32X3 jobs with K % 32 == 0: hi / lo granules (vn_x3_presplit)
     int32_t block_begin[PACK_MAX_JOBS + 1];
     int32_t tiled[PACK_MAX_JOBS];       // 0: one thread per element; 1: row tiles (modes 0, 3); 2: 32 x 8 tiles (modes 1, 2)
     vnPackJob job[PACK_MAX_JOBS];
@@ -148,7 +166,9 @@ __global__ void __launch_bounds__(256) k_pack_weights_batch(const PackJobs t) {
         const int tap = (int)(i / ((int64_t)Ke * N));
         const int k = ke % K, part = ke / K;
         const float v = q.w[torch_index(q.mode, q.c_out, q.c_in, q.taps, tap, n, k, q.cin_fold)];
-        if (q.packed_dtype == VN_F32) {
+        if (q.packed_dtype == VN_F32X3 && t.x3_presplit && (K & 31) == 0) {
+            store_x3_weight(q.packed, i, K, v);
+        } else if (q.packed_dtype != VN_BF16) {
             static_cast<float *>(q.packed)[i] = v;
         } else {
             bf16_t hi, lo;
@@ -416,11 +436,12 @@ inline unsigned gs_blocks(int64_t total, int per_block = 256, int cap = 8192) {
 extern "C" int vn_pack_weight(const float *w, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode, int32_t split3,
                               int32_t cin_fold, void *packed, vnDtype packed_dtype, vnStream stream) {
     VN_CHECK_ARG(w && packed && c_out > 0 && c_in > 0 && taps > 0 && mode >= 0 && mode <= 3);
-    VN_CHECK_ARG(packed_dtype == VN_BF16 || (packed_dtype == VN_F32 && !split3));
+    VN_CHECK_ARG(packed_dtype == VN_BF16 || ((packed_dtype == VN_F32 || packed_dtype == VN_F32X3) && !split3));
     VN_CHECK_ARG(cin_fold >= 1 && c_in % cin_fold == 0);
     const int64_t total = (int64_t)taps * c_out * c_in * (split3 ? 3 : 1);
+    const int K = (mode == 0 || mode == 2) ? c_in : c_out;
     k_pack_weight<<<gs_blocks(total), 256, 0, vn_stream(stream)>>>(w, c_out, c_in, taps, mode, split3, cin_fold, packed,
-                                                                   packed_dtype == VN_F32);
+                                                                   packed_dtype == VN_BF16 ? 0 : (packed_dtype == VN_F32X3 && vn_x3_presplit(K)) ? 2 : 1);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -440,11 +461,12 @@ extern "C" int vn_pack_weights_batch(const vnPackJob *jobs, int32_t n, vnStream 
     for (int32_t base = 0; base < n; base += PACK_MAX_JOBS) {
         PackJobs t{};
         t.n = n - base < PACK_MAX_JOBS ? n - base : PACK_MAX_JOBS;
+        t.x3_presplit = vn_x3_presplit(32);
         int blocks = 0;
         for (int j = 0; j < t.n; ++j) {
             const vnPackJob &q = jobs[base + j];
             VN_CHECK_ARG(q.w && q.packed && q.c_out > 0 && q.c_in > 0 && q.taps > 0 && q.mode >= 0 && q.mode <= 3);
-            VN_CHECK_ARG(q.packed_dtype == VN_BF16 || (q.packed_dtype == VN_F32 && !q.split3));
+            VN_CHECK_ARG(q.packed_dtype == VN_BF16 || ((q.packed_dtype == VN_F32 || q.packed_dtype == VN_F32X3) && !q.split3));
             VN_CHECK_ARG(q.cin_fold >= 1 && q.c_in % q.cin_fold == 0);
             const int64_t total = (int64_t)q.taps * q.c_out * q.c_in * (q.split3 ? 3 : 1);
             int64_t nb = vn_ceil_div(total, 256 * 8);          // 8 elements per thread

@@ -124,6 +124,7 @@ vnConv geom(const Rows &src, const int row_dims[3], int Cs, int Cr, const int k[
 }
 const int ONE[3] = {1, 1, 1}, NEG[3] = {-1, -1, -1};
 struct Plan;
+int32_t wdt(const Plan &P);
 const vnConv *cx(const Plan &P, vnConv &g);   // the geometry as the conv / weight-gradient entry points get it (fp32x3 mode: VN_F32X3)
 
 vnConv fwd_geom(const Spec &sp, const Rows &x, const int od[3], const Rows &out) {
@@ -151,6 +152,8 @@ const vnConv *cx(const Plan &P, vnConv &g) {
     if (P.x3 && g.dtype == VN_F32) g.dtype = VN_F32X3;
     return &g;
 }
+// dtype the packed conv weights are made in: the storage dtype; fp32x3 mode: split once by the pack launch (VN_F32X3)
+int32_t wdt(const Plan &P) { return P.x3 ? (int32_t)VN_F32X3 : (int32_t)P.adt; }
 // fp32x3, middle_layer.2's weight gradient: in fp32 the row form re-stages both operands once per tap (27 x: 2.4 ms); the
 // operands are cast to [hi|lo] bf16 rows once (row width 2 C) and the bf16 patch kernel runs three times over them —
 // hi.hi, lo(src).hi, hi(src).lo(rows) — into consecutive partial slabs that the unpack sums like row chunks
@@ -652,7 +655,7 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
     net->prep_first_done = false;
     if (own_stream && !rest_only) {
         const Spec &sp = P.spec[0];
-        vnPackJob j0{L[0].weight, P.wp_f[0], sp.cout, sp.cin, sp.k[0] * sp.k[1] * sp.k[2], sp.transposed ? 2 : 0, 0, sp.cin_fold, P.adt, 0};
+        vnPackJob j0{L[0].weight, P.wp_f[0], sp.cout, sp.cin, sp.k[0] * sp.k[1] * sp.k[2], sp.transposed ? 2 : 0, 0, sp.cin_fold, wdt(P), 0};
         RTT(T_PACK, 0, 0.0, (double)j0.c_out * j0.c_in * j0.taps * (4 + P.esz), stream, vn_pack_weights_batch(&j0, 1, stream));
         RT(first_needs());
         VN_HIP(hipEventRecord(net->prep_ev[0], vn_stream(stream)));
@@ -671,18 +674,18 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
             const Spec &sp = P.spec[l];
             const int taps = sp.k[0] * sp.k[1] * sp.k[2];
             if (!(own_stream && l == 0))
-                jobs[nj++] = vnPackJob{L[l].weight, P.wp_f[l], sp.cout, sp.cin, taps, sp.transposed ? 2 : 0, 0, sp.cin_fold, P.adt, 0};
+                jobs[nj++] = vnPackJob{L[l].weight, P.wp_f[l], sp.cout, sp.cin, taps, sp.transposed ? 2 : 0, 0, sp.cin_fold, wdt(P), 0};
             if (training) {
                 const bool first_sparse = l == 0 && cfg->sparse_first;
                 const vnPackJob jd{L[l].weight, P.wp_d[l], sp.cout, sp.cin, taps, sp.transposed ? 3 : 1, 0,
-                                   first_sparse ? 1 : sp.cin_fold, P.adt, 0};
+                                   first_sparse ? 1 : sp.cin_fold, wdt(P), 0};
                 if (own_stream) net->deferred_pack[net->n_deferred++] = jd;
                 else jobs[nj++] = jd;
             }
         }
-        jobs[nj++] = vnPackJob{heads_w, P.hwp_f, 16, 768, 1, 0, 0, 1, P.adt, 0};
+        jobs[nj++] = vnPackJob{heads_w, P.hwp_f, 16, 768, 1, 0, 0, 1, wdt(P), 0};
         if (training) {
-            const vnPackJob jd{heads_w, P.hwp_d, 16, 768, 1, 1, 0, 1, P.adt, 0};
+            const vnPackJob jd{heads_w, P.hwp_d, 16, 768, 1, 1, 0, 1, wdt(P), 0};
             if (own_stream) net->deferred_pack[net->n_deferred++] = jd;
             else jobs[nj++] = jd;
         }

@@ -162,8 +162,9 @@ def pack_weight(w, spec, orient, mode):
     split = is_split(mode)
     dt = act_dtype_of(mode)
     packed = torch.empty((spec.taps, N, K * (3 if split else 1)), dtype=dt, device=w.device)
+    # (fp32x3: the convolutions launched with VN_F32X3 expect their weights split once by the pack, include/voxelnet_hip.h)
     _lib.call("vn_pack_weight", w.data_ptr(), c_out, c_in, spec.taps, orient, int(split), spec.cin_fold,
-              packed.data_ptr(), _dt(packed), stream())
+              packed.data_ptr(), VN_F32X3 if X3["on"] and dt == torch.float32 else _dt(packed), stream())
     return packed
 
 
