@@ -113,6 +113,23 @@ __device__ __forceinline__ void x3_weights(bool presplit, const char *g0, const 
     }
 }
 
+// fp32x3, patch kernels: the staged fp32 patch (rows of 128 B = 32 channels, 16-B granules XOR-swizzled by (row >> 1) & 7)
+// rewritten IN PLACE as hi / lo bf16 granules, once per (plane, chunk) by the whole workgroup — logical granule q (0..3)
+// becomes the hi parts of the eight values a lane with fq = q reads (granules q and 4 + q), granule 4 + q their lo parts:
+// exactly what x3_weights() reads of a pre-split weight row.  The nine taps (x WN waves) then read every A fragment ready
+// made instead of splitting it again: 24 VALU operations per fragment and use were what bounded these kernels (round 4).
+template <int NT>
+__device__ __forceinline__ void x3_split_patch(char *patch, int rows) {
+    for (int item = threadIdx.x; item < rows * 4; item += NT) {
+        const int q = item >> 2, f = item & 3, sw = (q >> 1) & 7;
+        char *g0 = patch + q * 128 + ((f ^ sw) << 4), *g1 = patch + q * 128 + (((4 + f) ^ sw) << 4);
+        bf16x8_t hi, lo;
+        vn_split8(*reinterpret_cast<const f32x4_t *>(g0), *reinterpret_cast<const f32x4_t *>(g1), hi, lo);
+        *reinterpret_cast<bf16x8_t *>(g0) = hi;
+        *reinterpret_cast<bf16x8_t *>(g1) = lo;
+    }
+}
+
 // Store one workgroup's accumulators (+bias, optional accumulate) through the per-row offset table otab (LDS, -1 =
 // row not stored) and, if asked, its per-channel sum / sum of squares into stats slab row `tile`.
 template <int WM, int WN, int SM, bool BNBWD = false>
@@ -702,15 +719,20 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
                 bool x3_done = false;
                 if constexpr (F32) {
                     if (p.x3) {
+                        if (tap == 0) {      // the patch has landed in every wave: split it once for all nine taps
+                            x3_split_patch<256>(patch, PA * 32);
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                        }
                         bf16x8_t bh[4], bl[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) x3_weights(p.x3 == 2, lb + j * 2048 + bfrag0, lb + j * 2048 + bfrag1, bh[j], bl[j]);
 #pragma unroll
                         for (int i = 0; i < SM; ++i) {
                             const int q = q0[i] + shift;
-                            bf16x8_t ah, al;
-                            vn_split8(*reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((0 + fq) ^ ((q >> 1) & 7)) << 4)),
-                                      *reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((4 + fq) ^ ((q >> 1) & 7)) << 4)), ah, al);
+                            const bf16x8_t ah = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((0 + fq) ^ ((q >> 1) & 7)) << 4));
+                            const bf16x8_t al = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((4 + fq) ^ ((q >> 1) & 7)) << 4));
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[i][j] = vn_mfma_x3(ah, al, bh[j], bl[j], acc[i][j]);
                         }
@@ -939,15 +961,20 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
             bool x3_done = false;
             if constexpr (F32) {
                 if (p.x3) {
+                    if (tap == 0) {      // this chunk's patch has landed in every wave: split it once for all nine taps
+                        x3_split_patch<NT>(smem + pbuf * PATCH_BYTES, PA * NW * 8);
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        __builtin_amdgcn_s_barrier();
+                        asm volatile("" ::: "memory");
+                    }
                     bf16x8_t bh[4], bl[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) x3_weights(p.x3 == 2, lb + j * 2048 + bfrag0, lb + j * 2048 + bfrag1, bh[j], bl[j]);
 #pragma unroll
                     for (int i = 0; i < SM; ++i) {
                         const int q = q0[i] + shift;
-                        bf16x8_t ah, al;
-                        vn_split8(*reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((0 + fq) ^ ((q >> 1) & 7)) << 4)),
-                                  *reinterpret_cast<const f32x4_t *>(patch + q * 128 + (((4 + fq) ^ ((q >> 1) & 7)) << 4)), ah, al);
+                        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((0 + fq) ^ ((q >> 1) & 7)) << 4));
+                        const bf16x8_t al = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((4 + fq) ^ ((q >> 1) & 7)) << 4));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[i][j] = vn_mfma_x3(ah, al, bh[j], bl[j], acc[i][j]);
                     }
