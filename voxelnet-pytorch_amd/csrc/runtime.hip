@@ -333,7 +333,8 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     {   // weight-gradient partials: one slab per layer, summed by the batched unpack at the end of a segment
         auto ask = [&](const int rd[3], int Cs, int Cr, const int k[3], int64_t n_rows) {
             vnConv q{};
-            q.dtype = P->adt; q.B = B; q.Dr = rd[0]; q.Hr = rd[1]; q.Wr = rd[2]; q.Cs = Cs; q.Cr = Cr;
+            q.dtype = wdt(*P);               // (the operand dtype of the launch: the chunk count depends on it)
+            q.B = B; q.Dr = rd[0]; q.Hr = rd[1]; q.Wr = rd[2]; q.Cs = Cs; q.Cr = Cr;
             q.kD = k[0]; q.kH = k[1]; q.kW = k[2];
             return vn_conv_wgrad_workspace_bytes(&q, 0, n_rows);
         };
@@ -351,8 +352,8 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
                 P->x3_rows = A.take((size_t)B * P->odims[l][0] * P->odims[l][1] * P->odims[l][2] * 2 * sp.cout * 2);
             } else {   // the real launch geometry: the kernel variant (and its chunking) is chosen from it
                 const Rows xin = dense_rows(nullptr, P->adt, B, P->in_dims[l][0], P->in_dims[l][1], P->in_dims[l][2], sp.cin);
-                const vnConv gw = wgrad_geom(*P, l, xin);
-                b = vn_conv_wgrad_workspace_bytes(&gw, 0, 0);
+                vnConv gw = wgrad_geom(*P, l, xin);
+                b = vn_conv_wgrad_workspace_bytes(cx(*P, gw), 0, 0);
             }
             P->dwp_bytes[l] = b;
             P->dwp[l] = (float *)A.take(b);

@@ -658,7 +658,10 @@ static WGPlan wgrad_plan(const vnConv *g, int32_t split, int64_t M) {
     // slabs of 64 sites per chunk: more chunks only add partial-tile traffic (each chunk stores DN x DK x taps fp32
     // and the batched unpack reads it back), fewer leave CUs idle.  Measured in the full step: 128 / 192 / 256 / 384 /
     // 512 / 768 workgroups -> 357 / 368 / 373 / 370 / 368 / 364 point-clouds/s.
-    static const int target = vn_knob("VN_WG_BLOCKS", 256);   // tuning aid
+    // fp32x3 (VALU / LDS-latency-bound stages, one workgroup does not fill a CU): 192 / 256 / 384 / 512 -> 246 / 259 / 265 /
+    // 262 point-clouds/s in that mode (round 4)
+    static const int knob = vn_knob("VN_WG_BLOCKS", 0);   // tuning aid; 0 = 256 (384 for fp32x3)
+    const int target = knob > 0 ? knob : (g->dtype == VN_F32X3 ? 384 : 256);
     int64_t chunks = target / ((int64_t)w.groups * w.tiles_n * w.tiles_k);
     const int64_t slabs = vn_ceil_div(M, 64);
     if (chunks > slabs / 10) chunks = slabs / 10;
