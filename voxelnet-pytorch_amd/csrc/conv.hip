@@ -1184,6 +1184,9 @@ int launch_patch_cfg(const PatchCfg &c, bool f32, const GGParams &p, dim3 grid, 
         // eight waves (4 x 2 of 16 x 64) for the bf16 kernels; tuning aid VN_PATCH2D_WAVES=4: the four-wave kernel of round 2
         static const int waves = vn_knob("VN_PATCH2D_WAVES", 8);
         if (patch2d_stages() == 3 && waves == 8 && !f32) return launch_patch2d<4, 2, 1, 16, 3, false>(q, grid, st);
+        // fp32x3: with the splits out of the tap loop its steps look like the bf16 kernel's (DMA issue, fragment reads, 24 bf16
+        // MFMAs per 16 x 64 sub-tile) — the same eight-wave arrangement; the exact fp32 path (128 fp32 MFMAs per step) keeps four
+        if (patch2d_stages() == 3 && waves == 8 && f32 && q.x3) return launch_patch2d<4, 2, 1, 16, 3, true>(q, grid, st);
         if (patch2d_stages() == 3)
             return f32 ? launch_patch2d<2, 2, 2, 16, 3, true>(q, grid, st) : launch_patch2d<2, 2, 2, 16, 3, false>(q, grid, st);
         return f32 ? launch_patch2d<2, 2, 2, 16, 4, true>(q, grid, st) : launch_patch2d<2, 2, 2, 16, 4, false>(q, grid, st);
