@@ -53,7 +53,7 @@ void layer_table(int block1_stride, Spec *t) {
     d2(256, 256, 4, 4, 0);                                                         // deconv3 (251)
 }
 // indices into the table
-constexpr int L_M0 = 0, L_M2 = 2, L_B1 = 3, L_D1 = 8, L_B2 = 9, L_D2 = 15, L_B3 = 16, L_D3 = 22;
+constexpr int L_M2 = 2, L_B1 = 3, L_D1 = 8, L_B2 = 9, L_D2 = 15, L_B3 = 16, L_D3 = 22;
 
 void out_dims(const Spec &sp, const int in[3], int out[3]) {
     for (int a = 0; a < 3; ++a)
