@@ -61,6 +61,29 @@ def test_ped_full_size_fp32_maps_and_bf16_step():
     ep, er = rel_err(prob, rp), rel_err(reg, rr)
     print(f"ped full size, fp32 mode vs CPU oracle: prob {ep:.2e}, reg {er:.2e}")
     assert ep < 1e-3 and er < 1e-3, (ep, er)
+    # --- fp32x3 (fp32 storage, three bf16 MFMAs per product; block1 at stride 1: the 200 x 240 patch kernels all the way): the
+    # same bar, and forward + backward twice: finite and bit-identical
+    M.set_precision("fp32x3")
+    m = M.RPN3D("Pedestrian")
+    m.load_state_dict(tr.make_state_dict("Pedestrian"))
+    m = m.to(DEV).train()
+    rng = np.random.default_rng(3300)
+    dp = torch.from_numpy((rng.standard_normal((2, 2, 200, 240)) * 1e-3).astype(np.float32)).to(DEV)
+    dr = torch.from_numpy((rng.standard_normal((2, 14, 200, 240)) * 1e-3).astype(np.float32)).to(DEV)
+    runs = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        prob, reg = m.detect(feats, coords)
+        torch.autograd.backward([prob, reg], [dp, dr])
+        torch.cuda.synchronize()
+        runs.append((prob.detach().clone(), reg.detach().clone(), [p.grad.detach().clone() for p in m.parameters()]))
+    e3 = rel_err(runs[0][0], rp), rel_err(runs[0][1], rr)
+    print(f"ped full size, fp32x3 mode vs CPU oracle: prob {e3[0]:.2e}, reg {e3[1]:.2e}")
+    assert e3[0] < 1e-3 and e3[1] < 1e-3, e3
+    assert all(torch.isfinite(g).all() for g in runs[0][2])
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    assert all(torch.equal(a, b) for a, b in zip(runs[0][2], runs[1][2]))
     # --- bf16: forward + backward of the whole net, twice: finite and bit-identical
     M.set_precision("bf16")
     m = M.RPN3D("Pedestrian")
