@@ -538,6 +538,19 @@ int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int64_t da_stride, const v
                     vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
                     const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
                     int64_t lo_off, vnStream stream);
+/* The same two passes for a deconv that feeds the heads (model.py:272-281 backward; /root/reference/voxelnet/model.py:251-281),
+ * with da formed in the pass itself: da[m][c] = sum_k d_rows[m][k] * W[c_base + c][k] (fp32 FMA chain over k = 0..15 of the
+ * bf16 operands) — d_rows (M,16) bf16 = the heads' conv-output gradient (vn_heads_bwd), w_packed_dgrad = the packed [768][16]
+ * bf16 data-gradient operand of the heads (vn_pack_weight mode 1), c_base = the deconv's first channel in the concat.  The
+ * (M,768) concat gradient (vn_heads_dgrad: 108 MB at the car size, read twice per deconv) is then never written.  Grids, slab
+ * rows (vn_bn_bwd_slab_rows) and summation order are those of vn_bn_bwd_reduce_slab / vn_bn_bwd_apply. */
+int vn_bn_bwd_reduce_slab_heads(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, int32_t c_base,
+                                const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C,
+                                const float *stats, int32_t relu, float *slab, vnStream stream);
+int vn_bn_bwd_apply_heads(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, int32_t c_base,
+                          const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                          const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
+                          vnStream stream);
 /* BEV-fold variants for the last Conv3d (model.py:262): y / dy are its plain (B*2*H*W, C=64) rows, a / da the
  * (B,1,H,W,2C) tensor block1 sees (row stride wide_stride, channel = d*C + c).  hw = H*W.  One launch each. */
 int vn_bn_apply_bev(const void *y, vnDtype y_dtype, int64_t M, int32_t C, int64_t hw, const float *stats,

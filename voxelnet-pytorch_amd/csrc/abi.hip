@@ -8,7 +8,7 @@ extern "C" int vn_abi_version(void) { return 3; }
 
 namespace {
 // every tuning aid of the library (vn_knob): kernel-selection overrides used for A/B measurements (tools/README.md)
-const char *const KNOBS[] = {"VN_BN_FUSE_ROWS", "VN_BN_HOIST", "VN_BOX_SIDE", "VN_BOX_ZERO", "VN_DUP", "VN_EARLY_DECONV", "VN_EARLY_UNPACK", "VN_FUSE_BWD_REDUCE", "VN_GG_CONFIG", "VN_GG_ROWS_CONFIG", "VN_HEADS_BLOCKS", "VN_HEADS_STREAM", "VN_M0_BN", "VN_M0_MAIN", "VN_P2D_ROT", "VN_PATCH", "VN_PATCH2D", "VN_PATCH2D_WAVES", "VN_PATCH_P0", "VN_PATCH_P1", "VN_SKIP", "VN_UNPACK_M2", "VN_WGP2_BLOCKS", "VN_WGP2_STAGES", "VN_WGP_BLOCKS", "VN_WGRAD_PATCH", "VN_WG_BLOCKS", "VN_WG_EARLY", "VN_WG_STREAMS", "VN_WG_TRI_WAVES", "VN_WG_WAVES", "VN_WG_XCD", "VN_X3_PRESPLIT"};
+const char *const KNOBS[] = {"VN_BN_FUSE_ROWS", "VN_BN_HOIST", "VN_BOX_SIDE", "VN_BOX_ZERO", "VN_DUP", "VN_EARLY_DECONV", "VN_EARLY_UNPACK", "VN_FUSE_BWD_REDUCE", "VN_GG_CONFIG", "VN_GG_ROWS_CONFIG", "VN_HEADS_BLOCKS", "VN_HEADS_NOCAT", "VN_HEADS_STREAM", "VN_M0_BN", "VN_M0_MAIN", "VN_P2D_ROT", "VN_PATCH", "VN_PATCH2D", "VN_PATCH2D_WAVES", "VN_PATCH_P0", "VN_PATCH_P1", "VN_SKIP", "VN_UNPACK_M2", "VN_WGP2_BLOCKS", "VN_WGP2_STAGES", "VN_WGP_BLOCKS", "VN_WGRAD_PATCH", "VN_WG_BLOCKS", "VN_WG_EARLY", "VN_WG_STREAMS", "VN_WG_TRI_WAVES", "VN_WG_WAVES", "VN_WG_XCD", "VN_X3_PRESPLIT"};
 constexpr int NKNOBS = sizeof(KNOBS) / sizeof(KNOBS[0]);
 }  // namespace
 

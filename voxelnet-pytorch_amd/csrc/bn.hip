@@ -460,6 +460,117 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const void *__restrict__ d
     }
 }
 
+// ---- BatchNorm backward of the three deconvs WITHOUT the 768-channel concat gradient (model.py:272-281 backward): the
+// gradient w.r.t. a deconv's activation is d_rows (M,16) . W_heads[:, c] — sixteen products per channel of values the
+// pass can form itself from 32 B of d_rows per row, instead of reading back the (M,768) tensor vn_heads_dgrad wrote (108 MB
+// at the car size, read twice).  d_rows = [d_prob p (1-p) | d_reg]: the fourteen regression columns are zero at every site
+// without a positive anchor, so all but a few rows cost two FMAs per channel (the test is wave-divergent only there).
+// da is the fp32 FMA chain over k = 0..15 of the bf16 operands (never rounded to bf16 as the stored tensor was).
+struct HeadsDa {
+    const bf16_t *drows;      // [M][dstride] bf16, 16 used
+    int64_t dstride;
+    const bf16_t *wd;         // packed data-gradient weights [768][16] bf16 (vn_pack_weight mode 1), row = concat channel
+};
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
+// the thread's eight channels c0 .. c0+7 of row m; w01[e][0/1] = W[c0+e][0/1]
+__device__ __forceinline__ void heads_da8(const HeadsDa &h, int64_t m, int c0, const float (&w01)[8][2], float (&dv)[8]) {
+    const uint4 g0 = *reinterpret_cast<const uint4 *>(h.drows + m * h.dstride);
+    const uint4 g1 = *reinterpret_cast<const uint4 *>(h.drows + m * h.dstride + 8);
+    const float k0 = bf_lo(g0.x), k1 = bf_hi(g0.x);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dv[e] = fmaf(k1, w01[e][1], k0 * w01[e][0]);
+    const uint32_t rest = (g0.y | g0.z | g0.w | g1.x | g1.y | g1.z | g1.w) & 0x7fff7fffu;
+    if (rest) {      // a site with regression gradients (positive anchors): the other fourteen terms
+        const uint32_t gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint4 wa = *reinterpret_cast<const uint4 *>(h.wd + (int64_t)(c0 + e) * 16);
+            const uint4 wb = *reinterpret_cast<const uint4 *>(h.wd + (int64_t)(c0 + e) * 16 + 8);
+            const uint32_t ww[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
+            float a = dv[e];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) {
+                a = fmaf(bf_lo(gw[q]), bf_lo(ww[q]), a);
+                a = fmaf(bf_hi(gw[q]), bf_hi(ww[q]), a);
+            }
+            dv[e] = a;
+        }
+    }
+}
+__device__ __forceinline__ void heads_w01(const HeadsDa &h, int c0, float (&w01)[8][2]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint32_t w = *reinterpret_cast<const uint32_t *>(h.wd + (int64_t)(c0 + e) * 16);
+        w01[e][0] = bf_lo(w); w01[e][1] = bf_hi(w);
+    }
+}
+
+// k_bn_bwd_reduce<false> with da from heads_da8 (one row per lane and iteration: the d_rows loads are L1 broadcasts)
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce_heads(const HeadsDa h, int c_base, const void *__restrict__ y, int ydt,
+                                                             int64_t ystride, int64_t M, int C, const float *__restrict__ stats,
+                                                             int relu, float *__restrict__ slab) {
+    VN_PRIO_MAIN();
+    const int groups = C >> 3, rpb = 256 / groups;
+    const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
+    float mean[8], invstd[8], S[8], be[8], w01[8][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = g * 8 + j;
+        mean[j] = stats[c]; invstd[j] = stats[C + c]; S[j] = stats[2 * C + c]; be[j] = stats[3 * C + c];
+    }
+    heads_w01(h, c_base + g * 8, w01);
+    float s1[8] = {0}, s2[8] = {0};
+    if (rr < rpb) {
+        const int64_t step = (int64_t)gridDim.x * rpb;
+        for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += step) {
+            float yv[8], dv[8];
+            load8(y, ydt, m * ystride + g * 8, yv);
+            heads_da8(h, m, c_base + g * 8, w01, dv);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float d0 = yv[j] - mean[j];
+                const float z = fmaf(S[j], d0, be[j]);
+                const float dz = (!relu || z > 0.f) ? dv[j] : 0.f;
+                s1[j] += dz;
+                s2[j] += dz * (d0 * invstd[j]);
+            }
+        }
+    }
+    block_reduce_slab(s1, s2, groups, rpb, C, slab + (size_t)blockIdx.x * 2 * C);
+}
+
+// k_bn_bwd_apply with da from heads_da8
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_heads(const HeadsDa h, int c_base, const void *__restrict__ y, int ydt,
+                                                            int64_t ystride, int64_t M, int C, const float *__restrict__ stats,
+                                                            const float *__restrict__ coef, int relu, void *__restrict__ dy,
+                                                            int dydt, int64_t dystride) {
+    VN_PRIO_MAIN();
+    const int groups = C >> 3, rpb = 256 / groups;
+    const int c = (threadIdx.x % groups) << 3, rr = threadIdx.x / groups;
+    if (rr >= rpb) return;
+    float mean[8], S[8], be[8], c0[8], c1[8], c2[8], w01[8][2];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mean[j] = stats[c + j]; S[j] = stats[2 * C + c + j]; be[j] = stats[3 * C + c + j];
+        c0[j] = coef[c + j]; c1[j] = coef[C + c + j]; c2[j] = coef[2 * C + c + j];
+    }
+    heads_w01(h, c_base + c, w01);
+    for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
+        float yv[8], dv[8], o[8];
+        load8(y, ydt, m * ystride + c, yv);
+        heads_da8(h, m, c_base + c, w01, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float d0 = yv[j] - mean[j];
+            const float z = fmaf(S[j], d0, be[j]);
+            const float dz = (!relu || z > 0.f) ? dv[j] : 0.f;
+            o[j] = fmaf(c0[j], dz, fmaf(c1[j], d0, c2[j]));
+        }
+        store8(dy, dydt, 0, m * dystride + c, o);
+    }
+}
+
 // dy = c0 dz + c1 (y - mean) + c2 at the rows of an explicit list only ((b,d,h,w) int64 coordinates of the dense
 // (B,D,H,W,C) tensors, *count valid entries): the first middle layer's gradient kernels read dy at its active sites only
 __global__ void __launch_bounds__(256) k_bn_bwd_apply_list(const void *__restrict__ da, int dadt, const void *__restrict__ y,
@@ -849,6 +960,37 @@ extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t d
     k_bn_bwd_reduce<false><<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, nullptr, slab, 0, nullptr, nullptr);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+// The two passes for a deconv under the heads (model.py:272-281 backward), da formed from d_rows and the heads' packed
+// data-gradient weights instead of read from the concat gradient: see HeadsDa.  c_base = the deconv's first concat channel.
+// Same grids, slab layout (vn_bn_bwd_slab_rows) and summation order as vn_bn_bwd_reduce_slab / vn_bn_bwd_apply.
+extern "C" int vn_bn_bwd_reduce_slab_heads(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, int32_t c_base,
+                                           const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C,
+                                           const float *stats, int32_t relu, float *slab, vnStream stream) {
+    VN_CHECK_ARG(slab && M > 0 && rows_ok(C, y_stride) && d_rows && w_packed_dgrad && y && stats && d_rows_stride >= 16 &&
+                 (d_rows_stride & 7) == 0 && c_base >= 0 && (c_base & 7) == 0 && c_base + C <= 768 && 256 % (C >> 3) == 0);
+    if ((reinterpret_cast<uintptr_t>(d_rows) & 15) || (reinterpret_cast<uintptr_t>(w_packed_dgrad) & 15)) return VN_EUNSUPPORTED;
+    const int rpb = 256 / (C >> 3);
+    const HeadsDa h{static_cast<const bf16_t *>(d_rows), d_rows_stride, static_cast<const bf16_t *>(w_packed_dgrad)};
+    k_bn_bwd_reduce_heads<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(h, c_base, y, (int)y_dtype, y_stride,
+                                                                                             M, C, stats, relu, slab);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+extern "C" int vn_bn_bwd_apply_heads(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, int32_t c_base,
+                                     const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
+                                     const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
+                                     vnStream stream) {
+    VN_CHECK_ARG(M > 0 && rows_ok(C, y_stride) && d_rows && w_packed_dgrad && y && stats && coef && dy && d_rows_stride >= 16 &&
+                 (d_rows_stride & 7) == 0 && (dy_stride & 7) == 0 && c_base >= 0 && (c_base & 7) == 0 && c_base + C <= 768 &&
+                 256 % (C >> 3) == 0);
+    if ((reinterpret_cast<uintptr_t>(d_rows) & 15) || (reinterpret_cast<uintptr_t>(w_packed_dgrad) & 15)) return VN_EUNSUPPORTED;
+    const HeadsDa h{static_cast<const bf16_t *>(d_rows), d_rows_stride, static_cast<const bf16_t *>(w_packed_dgrad)};
+    k_bn_bwd_apply_heads<<<gs_blocks(M * (C >> 3), 256 * apply_epl(M * (C >> 3)), 8192), 256, 0, vn_stream(stream)>>>(
+        h, c_base, y, (int)y_dtype, y_stride, M, C, stats, coef, relu, dy, (int)dy_dtype, dy_stride);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -149,6 +149,9 @@ SIGNATURES = {
     "vn_bn_bwd_slab_rows": (c_i64, [c_i64, c_i32]),
     "vn_bn_bwd_reduce_slab": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "vn_bn_bwd_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "vn_bn_bwd_reduce_slab_heads": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "vn_bn_bwd_apply_heads": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32,
+                                      c_i64, c_vp]),
     "vn_bn_bwd_apply": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp,
                                 c_i32, c_i64, c_i64, c_vp]),
     "vn_bn_apply_bev": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),
