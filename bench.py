@@ -309,7 +309,14 @@ def main():
 
     gap_events = [] if os.environ.get("VN_BENCH_GAPS") else None   # diagnostic: idle time of the training stream between steps
 
+    host_delay = float(os.environ.get("VN_BENCH_HOST_DELAY_US", "0")) * 1e-6   # diagnostic: a busy-wait per step on the host —
+    #                                    does the step time follow (the host is on the critical path) or not (the GPU is)?
+
     def step_eager():
+        if host_delay > 0:
+            t_end = time.perf_counter() + host_delay
+            while time.perf_counter() < t_end:
+                pass
         if gap_events is not None:
             g0 = torch.cuda.Event(enable_timing=True)
             g0.record()
