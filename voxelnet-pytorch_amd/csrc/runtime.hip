@@ -950,8 +950,6 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
         RTT(T_MISC, NL, 0.0, 0.0, stream, vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows.ptr, (vnDtype)P.adt, 16, 0, stream));
-        RTT(T_MISC, NL, 0.0, 0.0, stream,
-            vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, stream));
         const int od[3] = {1, P.hf, P.wf};
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
@@ -975,6 +973,10 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             vn_conv_gather_gemm(P.d_rows.ptr, P.hwp_d, nullptr, P.d_cat.ptr, (vnDtype)P.cdt, cx(P, gd), 0, nullptr, stream));
         RT(fork());
         heads_forked = true;
+        // the heads' bias gradients (column sums of d_rows: two small launches) are nobody's input: behind the fork, on the
+        // side stream (the main stream when there is none), not between the loss and the first data gradient
+        RTT(T_MISC, NL, 0.0, 0.0, wstream,
+            vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, wstream));
         RTT(T_WGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.cat), wstream,
             vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, cx(P, gw), 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
         unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
