@@ -125,18 +125,25 @@ def cpu_baseline(frames_np, cls, T, threads):
             with torch.no_grad():
                 tr.middle_rpn(tr.feature_net(feats, coords, sd, grid.dims, True), sd, cls, True)
 
+    def timed(nfr, backward, n):
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            step(nfr, backward)
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)
+
     step(nb, True)                       # warm (allocator, thread pool, oneDNN primitive caches)
-    t0 = time.perf_counter()
-    step(nb, True)
-    t_fb = time.perf_counter() - t0
+    fb = timed(nb, True, 3)              # three timed steps, the MEDIAN is reported
+    t_fb = fb[1]
     step(1, False)
-    t0 = time.perf_counter()
-    step(1, False)
-    t_f = time.perf_counter() - t0
+    f1 = timed(1, False, 3)
+    t_f = f1[1]
     return {"value": nb / t_fb, "unit": "point-clouds/s", "cores": threads, "kind": "port", "cpu": cpu_model_string(),
-            "sample": "1 warm + 1 timed step, batch=%d fwd+bwd (%.1f s): C voxelizer + PyTorch-CPU restatement of the reference "
-                      "op sequence; also batch=1 forward only (BASELINE configs[0]): %.2f point-clouds/s (%.1f s)"
-                      % (nb, t_fb, 1.0 / t_f, t_f),
+            "value_min": nb / fb[-1], "value_max": nb / fb[0],
+            "sample": "1 warm + 3 timed steps (median; %.1f / %.1f / %.1f s), batch=%d fwd+bwd: C voxelizer + PyTorch-CPU "
+                      "restatement of the reference op sequence; also batch=1 forward only (BASELINE configs[0]), median of 3: "
+                      "%.2f point-clouds/s (%.1f s)" % (fb[0], fb[1], fb[2], nb, 1.0 / t_f, t_f),
             "fwd_only_b1_value": 1.0 / t_f}
 
 
@@ -535,7 +542,10 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / dt
-        peak = PEAK_BF16_DENSE_TFLOPS if args.precision != "fp32" else PEAK_F32_MATRIX_TFLOPS
+        # fp32x3 / bf16x3 evaluate every algorithmic (fp32) product as THREE bf16 MFMA products: the roof for algorithmic FLOPs
+        # is a third of the dense bf16 MFMA peak
+        peak = {"fp32": PEAK_F32_MATRIX_TFLOPS, "fp32x3": PEAK_BF16_DENSE_TFLOPS / 3.0, "bf16x3": PEAK_BF16_DENSE_TFLOPS / 3.0}.get(
+            args.precision, PEAK_BF16_DENSE_TFLOPS)
         metric = "point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2"
         if args.config != "car":
             metric = "point-clouds/sec fwd+bwd, %s, batch=%d" % (cfg_desc, B)
@@ -627,16 +637,27 @@ def main():
                 if args.config == "car" and args.precision == "bf16" and B == 2 and pmcs:
                     with open(os.path.join(ROOT, "profiles", pmcs[-1])) as fh:         # the latest round's passes
                         pj = json.load(fh)
-                    traffic = pj.get("traffic_bytes_per_launch")
-                    traffic_wgrad = (pj.get("wgrad") or {}).get("traffic_bytes_per_launch")
-                    traffic_source = ("committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of this command, "
-                                      "tools/final_run.sh + tools/pmc_family.py): counters cannot be collected inside this process, "
-                                      "so the figure is NOT measured in this run" % pmcs[-1])
+                    # the counter passes name the library build they profiled (tools/pmc_family.py: vn_build_id); a figure
+                    # from another build is not this build's traffic: null, with the reason
+                    running = _lib.load().vn_build_id().decode()
+                    if pj.get("library_build_id") == running:
+                        traffic = pj.get("traffic_bytes_per_launch")
+                        traffic_wgrad = (pj.get("wgrad") or {}).get("traffic_bytes_per_launch")
+                        traffic_source = ("committed file profiles/%s (rocprofv3 --pmc FETCH_SIZE x2 / WRITE_SIZE passes of this command "
+                                          "on library build %s = the running one, tools/final_run.sh + tools/pmc_family.py): counters "
+                                          "cannot be collected inside this process, so the figure is NOT measured in this run"
+                                          % (pmcs[-1], running))
+                    else:
+                        traffic_source = ("null: profiles/%s was collected on library build %s, this run is build %s — re-run "
+                                          "tools/final_run.sh's PMC passes for this build" % (pmcs[-1], pj.get("library_build_id"), running))
                 res["roofline"] = {
                     "kernel": "k_conv_patch + k_gather_gemm (implicit-GEMM convolutions: forward + data gradient)",
                     "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                     "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": 1e3 * t / n, "launches_per_step": n / ns,
                     "gflop_per_step": f / ns / 1e9, "ms_per_step": t / ns,
+                    "peak_note": {"fp32x3": "2500 / 3 TFLOP/s: three bf16 MFMA products per algorithmic fp32 product",
+                                  "bf16x3": "2500 / 3 TFLOP/s: three bf16 MFMA products per algorithmic fp32 product",
+                                  "fp32": "v_mfma_f32_16x16x4_f32 dense peak"}.get(args.precision, "dense bf16 MFMA peak"),
                     "note": "algorithmic FLOPs (SURVEY.md 8d; the launches that skip constant data — the rulebook first layer, "
                             "the row-list data gradients at its active sites — with the FLOPs they execute) / summed "
                             "HIP-event time of every launch of the family, events on the launch's own stream inside the "

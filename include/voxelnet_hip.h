@@ -41,12 +41,21 @@ typedef enum { VN_F32 = 0, VN_BF16 = 1,
                 * launched with this dtype must come from vn_pack_weight(s_batch) with packed_dtype VN_F32X3, which splits
                 * them once (same bytes as fp32; the layout is described there).  Tensor dtypes (outputs, BatchNorm, ...)
                 * never take this value. */
-               VN_F32X3 = 2 } vnDtype;
+               VN_F32X3 = 2,
+               /* "split fp32" STORAGE (round 5): a tensor of C % 8 == 0 channels at 4 bytes per element, every aligned group of 8
+                * channels = 32 B holding the eight hi bf16 parts (hi = bf16(x)) followed by the eight lo parts (lo = bf16(x -
+                * hi)) — x to ~2^-17, the precision the VN_F32X3 products use of an fp32 operand anyway.  Written by the
+                * BatchNorm passes (vn_bn_apply / vn_bn_bwd_apply and their BEV forms: a_dtype / dy_dtype), read as vnConv.dtype
+                * by the conv entry points (source rows; the packed weights are the VN_F32X3 ones, same format) and the
+                * weight-gradient entry points (BOTH operands): the fp32x3 products without any split work in the kernels.
+                * Element strides count 4-byte elements and must be multiples of 8; Cs % 32 == 0 for a convolution source. */
+               VN_F32X3S = 3 } vnDtype;
 
 typedef void *vnStream; /* hipStream_t */
 
-int vn_abi_version(void); /* bumps when a signature changes */
+int vn_abi_version(void); /* bumps when a signature, a data layout or a call protocol changes (4: round 5) */
 const char *vn_build_info(void); /* "gfx950 <date> ..." static string */
+const char *vn_build_id(void);   /* 12 hex digits: SHA-256 over the library's sources (changes with ANY source change) */
 
 /* ------------------------------------------------------------------------
  * Voxelizer — utils.py:10-100 (pcl_to_voxels), minus the host-side shuffle
@@ -304,10 +313,10 @@ int vn_fill_rows(void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stride, c
  * mode 3: ConvTranspose weight        -> data-grad operand [tap][Cin][Cout]
  * split3: emit the bf16x3 expansion [hi;hi;lo] along K (3x wide rows).
  * packed_dtype VN_F32X3 (operand of a convolution launched with vnConv.dtype VN_F32X3): rows of K fp32-sized slots
- * whose every aligned 128-B chunk (32 input channels k0..k0+31) holds the bf16 hi / lo parts of its weights in the order
- * the kernels' lanes read them — 16-B granule q (0..3): hi of channels k0+4q..+3 then k0+16+4q..+3; granule 4+q: their
- * lo parts (hi = bf16(w), lo = bf16(w - hi)).  Needs K % 32 == 0; for other K the packed operand is plain fp32 and the
- * kernels split it in registers (the same values either way).
+ * in the "split fp32" format of VN_F32X3S: every aligned group of 8 input channels (32 B) = the eight hi bf16 parts, then
+ * the eight lo parts (hi = bf16(w), lo = bf16(w - hi)) — a lane of the kernels reads the group 8 fq .. 8 fq + 7 of each
+ * 128-B chunk as its eight k values.  Needs K % 32 == 0; for other K the packed operand is plain fp32 and the kernels split
+ * it in registers (the same values either way).
  * cin_fold f: the packed Cin index p stands for torch channel (p % (Cin/f))*f + p/(Cin/f)
  * (f = 2 implements the BEV reshape of model.py:262, channel = c*2 + d; else 1). */
 int vn_pack_weight(const float *w, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode,

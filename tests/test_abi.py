@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     # and the ctypes table mirrors the header one to one
     assert sorted(_lib.SIGNATURES) == names
     assert _lib.missing_symbols() == []
-    assert lib.vn_abi_version() == _lib.ABI_VERSION == 3      # round 3: vnNetConfig.grad_storage (round 2: caller-owned vnNet context)
+    assert lib.vn_abi_version() == _lib.ABI_VERSION == 4      # round 5: VN_F32X3S + the packed-weight layout it shares; the round-4 prepare protocol
     assert b"gfx950" in lib.vn_build_info()
 
 

@@ -718,11 +718,20 @@ def test_fp32x3_conv3d_weight_gradient_through_hi_lo_copies():
     assert l2 < 2e-5, l2
 
 
+def split_fp32_storage(t):
+    """fp32 tensor (..., C), C % 8 == 0 -> its VN_F32X3S bytes as bf16 (..., 2 C): per 8 channels eight hi parts, then eight
+    lo parts (hi = bf16(x), lo = bf16(x - hi))"""
+    g = t.reshape(t.shape[:-1] + (t.shape[-1] // 8, 8))
+    hi = g.to(torch.bfloat16)
+    lo = (g - hi.float()).to(torch.bfloat16)
+    return torch.cat([hi, lo], dim=-1).reshape(t.shape[:-1] + (t.shape[-1] * 2,))
+
+
 def test_fp32x3_weights_are_split_once_by_the_pack(x3_flag):
-    """fp32x3 (round 4): a convolution launched with VN_F32X3 reads its weights as hi / lo bf16 granules that
-    vn_pack_weight(packed_dtype VN_F32X3) wrote — include/voxelnet_hip.h documents the order: in every 32-channel chunk,
-    16-B granule q (0..3) = hi of channels 4q..4q+3 then 16+4q..16+4q+3, granule 4+q = their lo parts.  (a) the packed
-    bytes against that description, bit for bit, all four packing modes and the BEV fold; K = 16: plain fp32 (split in
+    """fp32x3: a convolution launched with VN_F32X3 reads its weights as hi / lo bf16 granules that
+    vn_pack_weight(packed_dtype VN_F32X3) wrote — include/voxelnet_hip.h documents the order (round 5: the "split fp32"
+    format of VN_F32X3S): every group of 8 input channels is 32 B = its eight hi parts, then its eight lo parts.  (a) the
+    packed bytes against that description, bit for bit, all four packing modes and the BEV fold; K = 16: plain fp32 (split in
     registers).  (b) conv outputs and data gradients of one layer per kernel family in fp32x3 against the exact fp32 mode:
     rel-L2 < 2e-5 (three bf16 products: ~2^-16 each) — a misplaced hi / lo value would cost ~1e-3."""
     from voxelnet_amd import _lib, engine as E
@@ -745,11 +754,7 @@ def test_fp32x3_weights_are_split_once_by_the_pack(x3_flag):
         if K % 32:
             assert torch.equal(split, plain)
             continue
-        c = plain.view(taps, N, K // 32, 2, 4, 4)                      # [chunk][half][q][e]: channel = half*16 + 4q + e
-        lane = c.permute(0, 1, 2, 4, 3, 5).reshape(taps, N, K // 32, 4, 8)   # [q][half*4 + e]: a lane's eight values
-        hi = lane.to(torch.bfloat16)
-        lo = (lane - hi.float()).to(torch.bfloat16)
-        want = torch.stack([hi, lo], dim=3).reshape(taps, N, K * 2)    # granules 0..3 = hi(q), 4..7 = lo(q)
+        want = split_fp32_storage(plain)
         assert torch.equal(split.view(torch.bfloat16).view(taps, N, K * 2).view(torch.int16), want.view(torch.int16))
     cases = {c[0]: c for c in LAYER_CASES}
     for name in ("c3_s111_p011", "c3_s211_p111", "c2_s1", "c2_s2", "c2_s1_256", "d_k2s2", "d_k3s1"):

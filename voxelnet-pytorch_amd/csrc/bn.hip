@@ -11,7 +11,12 @@
 namespace {
 
 __device__ __forceinline__ void load8(const void *base, int dtype, int64_t off, float v[8]) {
-    if (dtype == VN_F32) {
+    if (dtype == VN_F32X3S) {      // split fp32 storage: 32 B per 8 channels = eight hi bf16 parts, then eight lo parts
+        const bf16_t *g = reinterpret_cast<const bf16_t *>(static_cast<const float *>(base) + off);
+        const bf16x8_t hi = *reinterpret_cast<const bf16x8_t *>(g), lo = *reinterpret_cast<const bf16x8_t *>(g + 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)hi[j] + (float)lo[j];
+    } else if (dtype == VN_F32) {
         const float4 a = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off);
         const float4 b = *reinterpret_cast<const float4 *>(static_cast<const float *>(base) + off + 4);
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -30,7 +35,14 @@ __device__ __forceinline__ int64_t fold_off(int64_t m, int64_t fold, int64_t wid
 }
 
 __device__ __forceinline__ void store8(void *base, int dtype, int64_t lo_off, int64_t off, const float v[8]) {
-    if (dtype == VN_F32) {
+    if (dtype == VN_F32X3S) {      // split fp32 storage (the fp32x3 kernels' operand format: no split work left for them)
+        bf16x8_t hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { bf16_t h, l; vn_split_bf16(v[j], h, l); hi[j] = h; lo[j] = l; }
+        bf16_t *g = reinterpret_cast<bf16_t *>(static_cast<float *>(base) + off);
+        *reinterpret_cast<bf16x8_t *>(g) = hi;
+        *reinterpret_cast<bf16x8_t *>(g + 8) = lo;
+    } else if (dtype == VN_F32) {
         float *d = static_cast<float *>(base) + off;
         *reinterpret_cast<float4 *>(d) = make_float4(v[0], v[1], v[2], v[3]);
         *reinterpret_cast<float4 *>(d + 4) = make_float4(v[4], v[5], v[6], v[7]);

@@ -63,7 +63,8 @@ struct GGParams {
     int32_t Cs, src_wrap, N, out_f32, accumulate, nclasses, src_row_elems;
     int32_t esz;                // operand element size: 2 (bf16) or 4 (fp32, exact v_mfma_f32_16x16x4_f32 path)
     int32_t x3;                 // fp32 storage, products as three bf16 MFMAs (VN_F32X3): the F32 kernels' alternative inner loop;
-                                // 2 = the packed weights hold hi / lo bf16 granules (Cs % 32 == 0), 1 = fp32 weights split in registers
+                                // 2 = the packed weights hold hi / lo bf16 granules (Cs % 32 == 0), 1 = fp32 weights split in registers,
+                                // 3 = as 2 and the SOURCE rows are stored split as well (VN_F32X3S: no split pass at all)
     int32_t kc_rot;             // k_conv_patch2d: workgroups start their K-chunk loop at chunk (tile mod nk) — tuning aid VN_P2D_ROT
     uint32_t w_bytes;
     int64_t src_batch_extent;   // elements spanned by one batch item (for num_records)
@@ -102,8 +103,8 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t *)lds_wave_base, 16, voffset, soffset, 0, 0);
 }
 
-// fp32x3: a lane's eight weight values of a 32-channel chunk as hi / lo bf16 — from the two granules vn_pack_weight(VN_F32X3)
-// wrote (presplit) or split here from the two fp32 granules
+// fp32x3: a lane's eight weight values (channels 8 fq .. 8 fq + 7 of a 32-channel chunk: granules 2 fq and 2 fq + 1) as hi /
+// lo bf16 — the two granules vn_pack_weight(VN_F32X3) wrote (presplit) or split here from the two fp32 granules
 __device__ __forceinline__ void x3_weights(bool presplit, const char *g0, const char *g1, bf16x8_t &hi, bf16x8_t &lo) {
     if (presplit) {
         hi = *reinterpret_cast<const bf16x8_t *>(g0);
@@ -114,15 +115,17 @@ __device__ __forceinline__ void x3_weights(bool presplit, const char *g0, const 
 }
 
 // fp32x3, patch kernels: the staged fp32 patch (rows of 128 B = 32 channels, 16-B granules XOR-swizzled by (row >> 1) & 7)
-// rewritten IN PLACE as hi / lo bf16 granules, once per (plane, chunk) by the whole workgroup — logical granule q (0..3)
-// becomes the hi parts of the eight values a lane with fq = q reads (granules q and 4 + q), granule 4 + q their lo parts:
-// exactly what x3_weights() reads of a pre-split weight row.  The nine taps (x WN waves) then read every A fragment ready
-// made instead of splitting it again: 24 VALU operations per fragment and use were what bounded these kernels (round 4).
+// rewritten IN PLACE as hi / lo bf16 granules, once per (plane, chunk) by the whole workgroup — the granule pair (2 f, 2 f + 1)
+// = the eight fp32 values of channels 8 f .. 8 f + 7 becomes their eight hi parts (granule 2 f) and eight lo parts (granule
+// 2 f + 1): the "split fp32" format (VN_F32X3S) that x3_weights() reads of a pre-split weight row and that a pre-split
+// SOURCE (p.x3 == 3: the BatchNorm passes wrote it that way, round 5) arrives in — then this pass is skipped.  The nine taps
+// (x WN waves) read every A fragment ready made instead of splitting it again: 24 VALU operations per fragment and use were
+// what bounded these kernels (round 4).
 template <int NT>
 __device__ __forceinline__ void x3_split_patch(char *patch, int rows) {
     for (int item = threadIdx.x; item < rows * 4; item += NT) {
         const int q = item >> 2, f = item & 3, sw = (q >> 1) & 7;
-        char *g0 = patch + q * 128 + ((f ^ sw) << 4), *g1 = patch + q * 128 + (((4 + f) ^ sw) << 4);
+        char *g0 = patch + q * 128 + (((2 * f) ^ sw) << 4), *g1 = patch + q * 128 + (((2 * f + 1) ^ sw) << 4);
         bf16x8_t hi, lo;
         vn_split8(*reinterpret_cast<const f32x4_t *>(g0), *reinterpret_cast<const f32x4_t *>(g1), hi, lo);
         *reinterpret_cast<bf16x8_t *>(g0) = hi;
@@ -440,6 +443,9 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
     const int fr = lane & 15, fq = lane >> 4;
     const int frag_off0 = fr * 128 + (((0 + fq) ^ (fr >> 1)) << 4);
     const int frag_off1 = fr * 128 + (((4 + fq) ^ (fr >> 1)) << 4);
+    // fp32x3: the lane's eight k values are channels 8 fq .. 8 fq + 7 of the 32-channel chunk — granules 2 fq, 2 fq + 1
+    const int x3_off0 = fr * 128 + (((2 * fq) ^ (fr >> 1)) << 4);
+    const int x3_off1 = fr * 128 + (((2 * fq + 1) ^ (fr >> 1)) << 4);
 
     constexpr int LPS = RA + RB;                // pieces per stage and wave
     // every stage slot is always issued (past the last step as out-of-range pieces: zeros, no memory traffic), so
@@ -474,11 +480,10 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
             if (p.x3) {      // both 16-B halves of the 32-channel chunk at once: the lane's eight k values, split hi / lo
                 bf16x8_t ah[SM], al[SM], bh[4], bl[4];
 #pragma unroll
-                for (int i = 0; i < SM; ++i)
-                    vn_split8(*reinterpret_cast<const f32x4_t *>(la + i * 2048 + frag_off0),
-                              *reinterpret_cast<const f32x4_t *>(la + i * 2048 + frag_off1), ah[i], al[i]);
+                for (int i = 0; i < SM; ++i)      // (x3 == 3: the source rows are stored split — VN_F32X3S)
+                    x3_weights(p.x3 == 3, la + i * 2048 + x3_off0, la + i * 2048 + x3_off1, ah[i], al[i]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x3_weights(p.x3 == 2, lb + j * 2048 + frag_off0, lb + j * 2048 + frag_off1, bh[j], bl[j]);
+                for (int j = 0; j < 4; ++j) x3_weights(p.x3 >= 2, lb + j * 2048 + x3_off0, lb + j * 2048 + x3_off1, bh[j], bl[j]);
 #pragma unroll
                 for (int q = 0; q < LPS; ++q) piece(c, q);
 #pragma unroll
@@ -653,6 +658,8 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
     }
     const int bfrag0 = fr * 128 + (((0 + fq) ^ (fr >> 1)) << 4);
     const int bfrag1 = fr * 128 + (((4 + fq) ^ (fr >> 1)) << 4);
+    const int x3_b0 = fr * 128 + (((2 * fq) ^ (fr >> 1)) << 4);        // fp32x3: granules 2 fq (hi) / 2 fq + 1 (lo)
+    const int x3_b1 = fr * 128 + (((2 * fq + 1) ^ (fr >> 1)) << 4);
 
     f32x4_t acc[SM][4];
 #pragma unroll
@@ -719,7 +726,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
                 bool x3_done = false;
                 if constexpr (F32) {
                     if (p.x3) {
-                        if (tap == 0) {      // the patch has landed in every wave: split it once for all nine taps
+                        if (tap == 0 && p.x3 != 3) {      // the patch has landed in every wave: split it once for all nine taps
                             x3_split_patch<256>(patch, PA * 32);
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             __builtin_amdgcn_s_barrier();
@@ -727,12 +734,12 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
                         }
                         bf16x8_t bh[4], bl[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) x3_weights(p.x3 == 2, lb + j * 2048 + bfrag0, lb + j * 2048 + bfrag1, bh[j], bl[j]);
+                        for (int j = 0; j < 4; ++j) x3_weights(p.x3 >= 2, lb + j * 2048 + x3_b0, lb + j * 2048 + x3_b1, bh[j], bl[j]);
 #pragma unroll
                         for (int i = 0; i < SM; ++i) {
                             const int q = q0[i] + shift;
-                            const bf16x8_t ah = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((0 + fq) ^ ((q >> 1) & 7)) << 4));
-                            const bf16x8_t al = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((4 + fq) ^ ((q >> 1) & 7)) << 4));
+                            const bf16x8_t ah = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((2 * fq) ^ ((q >> 1) & 7)) << 4));
+                            const bf16x8_t al = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((2 * fq + 1) ^ ((q >> 1) & 7)) << 4));
 #pragma unroll
                             for (int j = 0; j < 4; ++j) acc[i][j] = vn_mfma_x3(ah, al, bh[j], bl[j], acc[i][j]);
                         }
@@ -879,6 +886,8 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
     }
     const int bfrag0 = fr * 128 + (((0 + fq) ^ (fr >> 1)) << 4);
     const int bfrag1 = fr * 128 + (((4 + fq) ^ (fr >> 1)) << 4);
+    const int x3_b0 = fr * 128 + (((2 * fq) ^ (fr >> 1)) << 4);        // fp32x3: granules 2 fq (hi) / 2 fq + 1 (lo)
+    const int x3_b1 = fr * 128 + (((2 * fq + 1) ^ (fr >> 1)) << 4);
 
     f32x4_t acc[SM][4];
 #pragma unroll
@@ -961,7 +970,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
             bool x3_done = false;
             if constexpr (F32) {
                 if (p.x3) {
-                    if (tap == 0) {      // this chunk's patch has landed in every wave: split it once for all nine taps
+                    if (tap == 0 && p.x3 != 3) {      // this chunk's patch has landed in every wave: split it once for all nine taps
                         x3_split_patch<NT>(smem + pbuf * PATCH_BYTES, PA * NW * 8);
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
@@ -969,12 +978,12 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
                     }
                     bf16x8_t bh[4], bl[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) x3_weights(p.x3 == 2, lb + j * 2048 + bfrag0, lb + j * 2048 + bfrag1, bh[j], bl[j]);
+                    for (int j = 0; j < 4; ++j) x3_weights(p.x3 >= 2, lb + j * 2048 + x3_b0, lb + j * 2048 + x3_b1, bh[j], bl[j]);
 #pragma unroll
                     for (int i = 0; i < SM; ++i) {
                         const int q = q0[i] + shift;
-                        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((0 + fq) ^ ((q >> 1) & 7)) << 4));
-                        const bf16x8_t al = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((4 + fq) ^ ((q >> 1) & 7)) << 4));
+                        const bf16x8_t ah = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((2 * fq) ^ ((q >> 1) & 7)) << 4));
+                        const bf16x8_t al = *reinterpret_cast<const bf16x8_t *>(patch + q * 128 + (((2 * fq + 1) ^ ((q >> 1) & 7)) << 4));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) acc[i][j] = vn_mfma_x3(ah, al, bh[j], bl[j], acc[i][j]);
                     }
@@ -1241,7 +1250,7 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
     VN_CHECK_ARG(g->divD >= 1 && g->divH >= 1 && g->divW >= 1);
     VN_CHECK_ARG((g->divD == 1 || g->mulD == 1) && (g->divH == 1 || g->mulH == 1) && (g->divW == 1 || g->mulW == 1));
     VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
-    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32 || g->dtype == VN_F32X3);
+    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32 || g->dtype == VN_F32X3 || g->dtype == VN_F32X3S);
     const bool f32 = g->dtype != VN_BF16;      // VN_F32X3: the fp32 kernels (fp32 storage) with the three-bf16-product inner loop
     const int esz = f32 ? 4 : 2, align_e = 16 / esz;
     if (g->Cs <= 0 || (g->Cs % align_e) || g->Cr <= 0 || (g->Cr & 3) || g->src_wrap != 0) return VN_EUNSUPPORTED;
@@ -1262,6 +1271,10 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
     p.src_row_elems = g->Cs;
     p.esz = esz;
     p.x3 = g->dtype == VN_F32X3 ? (vn_x3_presplit(g->Cs) ? 2 : 1) : 0;   // 2: weights split by vn_pack_weight (VN_F32X3 operand)
+    if (g->dtype == VN_F32X3S) {      // the source rows are stored split too (BatchNorm passes: VN_F32X3S tensors)
+        if (!vn_x3_presplit(g->Cs) || ((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & 7)) return VN_EUNSUPPORTED;
+        p.x3 = 3;
+    }
     const int taps_total = g->kD * g->kH * g->kW;
     const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * esz;
     if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;
@@ -1387,7 +1400,7 @@ static int gather_gemm_impl(const void *src, const void *w_packed, const float *
     VN_CHECK_ARG(g->divW == 1 || g->mulW == 1);
     VN_CHECK_ARG(out_dtype == VN_F32 || out_dtype == VN_BF16);
     VN_CHECK_ARG(!stats_slab || g->divD * g->divH * g->divW <= GG_MAX_CLASSES);
-    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32 || g->dtype == VN_F32X3);
+    VN_CHECK_ARG(g->dtype == VN_BF16 || g->dtype == VN_F32 || g->dtype == VN_F32X3 || g->dtype == VN_F32X3S);
     const bool f32 = g->dtype != VN_BF16;      // VN_F32X3: the fp32 kernels (fp32 storage) with the three-bf16-product inner loop
     const int esz = f32 ? 4 : 2, bke = 128 / esz, align_e = 16 / esz;
     (void)bke;
@@ -1419,6 +1432,10 @@ static int gather_gemm_impl(const void *src, const void *w_packed, const float *
     p.src_row_elems = g->src_wrap > 0 ? g->src_wrap : g->Cs;
     p.esz = esz;
     p.x3 = g->dtype == VN_F32X3 ? (vn_x3_presplit(g->Cs) ? 2 : 1) : 0;   // 2: weights split by vn_pack_weight (VN_F32X3 operand)
+    if (g->dtype == VN_F32X3S) {      // the source rows are stored split too (BatchNorm passes: VN_F32X3S tensors)
+        if (!vn_x3_presplit(g->Cs) || ((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & 7)) return VN_EUNSUPPORTED;
+        p.x3 = 3;
+    }
     const int taps_total = g->kD * g->kH * g->kW;
     const int64_t wb = (int64_t)taps_total * g->Cr * g->Cs * esz;
     if (wb > (int64_t)GG_MAX_WINDOW) return VN_EUNSUPPORTED;

@@ -24,18 +24,18 @@ __device__ __forceinline__ int64_t torch_index(int mode, int c_out, int c_in, in
 }
 
 // packed_dtype VN_F32X3 (include/voxelnet_hip.h, vn_pack_weight): element (row, k) of a [rows][K] fp32-sized operand, K % 32
-// == 0 -> its hi / lo bf16 parts where the lanes of the fp32x3 convolution kernels read them: a lane (fq = lane >> 4)
-// reads the 16-B granules fq and 4 + fq of every 128-B chunk and takes them as eight hi and eight lo values of the
-// channels 4 fq .. 4 fq + 3 and 16 + 4 fq .. 16 + 4 fq + 3 (the order vn_split8 produces from the two fp32 granules)
+// == 0 -> the "split fp32" storage format (vnDtype VN_F32X3S, round 5): every group of 8 channels is 32 B = its eight hi
+// bf16 parts, then its eight lo parts.  A lane (fq = lane >> 4) of the fp32x3 convolution kernels reads the two 16-B
+// granules 2 fq and 2 fq + 1 of every 128-B chunk: the hi and lo parts of channels 8 fq .. 8 fq + 7, its eight k values of
+// one v_mfma_f32_16x16x32_bf16 (the same channels vn_split8 takes from the two fp32 granules of an unsplit operand)
 __device__ __forceinline__ void store_x3_weight(void *packed, int64_t i, int K, float v) {
     const int k = (int)(i % K);
-    const int kk = k & 31, g = kk >> 2, e = kk & 3;
-    const int q = g & 3, pos = (g >> 2) * 4 + e;
-    bf16_t *chunk = static_cast<bf16_t *>(packed) + (i - kk) * 2;      // 64 bf16 slots per 32-channel chunk
+    const int pos = k & 7;
+    bf16_t *group = static_cast<bf16_t *>(packed) + (i - pos) * 2;      // 16 bf16 slots per 8-channel group
     bf16_t hi, lo;
     vn_split_bf16(v, hi, lo);
-    chunk[q * 8 + pos] = hi;
-    chunk[(4 + q) * 8 + pos] = lo;
+    group[pos] = hi;
+    group[8 + pos] = lo;
 }
 
 __global__ void __launch_bounds__(256) k_pack_weight(const float *__restrict__ w, int c_out, int c_in, int taps,
@@ -332,7 +332,18 @@ __global__ void __launch_bounds__(256) k_cast_rows(const void *__restrict__ src,
         const int64_t m = i / groups;
         const int c = (int)(i - m * groups) << 2;
         float v[4];
-        if (sdt == VN_F32) {
+        if (sdt == VN_F32X3S) {      // split fp32 storage (per 8 channels: eight hi bf16 parts, then eight lo parts)
+            const bf16_t *g = reinterpret_cast<const bf16_t *>(static_cast<const float *>(src) + m * sstride + (c & ~7)) + (c & 7);
+            const bf16x4_t hi = *reinterpret_cast<const bf16x4_t *>(g), lo = *reinterpret_cast<const bf16x4_t *>(g + 8);
+            if (ddt == VN_BF16 && lo_off) {      // -> [hi | lo] bf16 rows: the parts as they are
+                bf16_t *d = static_cast<bf16_t *>(dst) + m * dstride + c;
+                *reinterpret_cast<bf16x4_t *>(d) = hi;
+                *reinterpret_cast<bf16x4_t *>(d + lo_off) = lo;
+                continue;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (float)hi[j] + (float)lo[j];
+        } else if (sdt == VN_F32) {
             const float4 t = *reinterpret_cast<const float4 *>(static_cast<const float *>(src) + m * sstride + c);
             v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
         } else {

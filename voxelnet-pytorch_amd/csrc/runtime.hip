@@ -12,6 +12,7 @@
 // The per-layer call sequences are exactly those of voxelnet_amd/engine.py (the Python reference
 // orchestration, still used by the per-layer tests and the bf16x3 mode).
 #include "common.h"
+#include <functional>
 #include <new>
 #include <string.h>
 
@@ -91,6 +92,7 @@ struct Plan {
     // heads
     void *x3_src, *x3_rows;   // fp32x3: [hi|lo] bf16 copies of middle_layer.2's input and dy (its weight gradient runs on the bf16 patch kernel)
     bool x3;          // cfg->mode == 2 ("fp32x3"): fp32 storage, the convolutions' and weight gradients' products as three bf16 MFMAs
+    bool x3_store;    // fp32x3: activations / gradients that feed convolutions and weight gradients are stored split (VN_F32X3S)
     bool round_act;   // fp32 mode diagnostic (grad_storage & 16): activations rounded to bf16 VALUES, everything else exact fp32
     bool exact_heads; Rows d_rows32;   // grad_storage & 8: the fp32 logit gradient beside the bf16 one
     void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes; void *hcs_ws; size_t hcs_ws_bytes;
@@ -169,6 +171,7 @@ vnConv x3_wgrad_geom(const Plan &P, int l, void *src_hl, void *rows_hl, int src_
 }
 int m0_bn_knob();
 int box_zero_total();
+int x3_split_store_on();
 bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     // depth: every D whose three Conv3d layers (model.py:207-209: stride 2 / pad 1, stride 1 / no pad, stride 2 / pad 1)
     // end at depth 2, the BEV fold of model.py:262 — D = 9 ... 12 (the reference's grids are all D = 10; round 4 lifted the
@@ -180,6 +183,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     layer_table(c->block1_stride, P->spec);
     const bool f32 = c->mode != 0;      // modes 1 (fp32) and 2 (fp32x3) store everything in fp32
     P->x3 = c->mode == 2;
+    P->x3_store = P->x3 && x3_split_store_on() && vn_x3_presplit(32);
     P->esz = f32 ? 4 : 2;
     P->adt = f32 ? VN_F32 : VN_BF16;
     if (c->grad_storage & ~31) return false;
@@ -193,7 +197,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     Arena A{base, 0, 0};
     auto rows_new = [&](int dtype, const int d[3], int C, int64_t width = 0) {
         if (!width) width = C;
-        void *p = A.take((size_t)B * d[0] * d[1] * d[2] * width * (dtype == VN_F32 ? 4 : 2));
+        void *p = A.take((size_t)B * d[0] * d[1] * d[2] * width * (dtype == VN_BF16 ? 2 : 4));
         return dense_rows(p, dtype, B, d[0], d[1], d[2], C, width);
     };
     // ---- dims walk
@@ -258,6 +262,11 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         } else {
             P->a[l] = rows_new(P->adt, P->odims[l], sp.cout);
         }
+        // fp32x3: the activations that only convolutions and weight gradients read are STORED split (VN_F32X3S: per 8
+        // channels their hi bf16 parts, then their lo parts — same bytes as fp32), written that way by the BatchNorm apply:
+        // no split work is left in the kernels that consume them.  Not the first layer's output (its sparse routes read it
+        // as numbers) and not the deconvs' (the concat feeds the 16-column heads)
+        if (P->x3_store && l >= 1 && !sp.transposed) P->a[l].dtype = VN_F32X3S;
     }
     P->hy = rows_new(VN_F32, fm, 16);
     // ---- sparse first layer
@@ -315,6 +324,9 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         }
         P->bslab[l] = (float *)A.take(bslab_floats * sizeof(float));
         P->dy[l] = rows_new(P->adt, P->odims[l], sp.cout);
+        // (fp32x3: dy of every layer whose two consumers — data gradient and weight gradient — are plain launches is stored
+        //  split by the BatchNorm backward apply; layers 0 and 1 have the sparse routes and box sums)
+        if (P->x3_store && l >= 2) P->dy[l].dtype = VN_F32X3S;
         // data gradient buffer of the layer's input (shared where two consumers accumulate)
         P->dx[l] = Rows{};
     }
@@ -351,7 +363,9 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
                 P->x3_src = A.take((size_t)B * P->in_dims[l][0] * P->in_dims[l][1] * P->in_dims[l][2] * 2 * sp.cin * 2);
                 P->x3_rows = A.take((size_t)B * P->odims[l][0] * P->odims[l][1] * P->odims[l][2] * 2 * sp.cout * 2);
             } else {   // the real launch geometry: the kernel variant (and its chunking) is chosen from it
-                const Rows xin = dense_rows(nullptr, P->adt, B, P->in_dims[l][0], P->in_dims[l][1], P->in_dims[l][2], sp.cin);
+                const int src_l = l == 0 ? -1 : (l == L_D1 || l == L_B2) ? L_D1 - 1 : (l == L_D2 || l == L_B3) ? L_D2 - 1 : l - 1;
+                const Rows xin = dense_rows(nullptr, src_l < 0 ? P->adt : P->a[src_l].dtype, B, P->in_dims[l][0], P->in_dims[l][1],
+                                            P->in_dims[l][2], sp.cin);
                 vnConv gw = wgrad_geom(*P, l, xin);
                 b = vn_conv_wgrad_workspace_bytes(cx(*P, gw), 0, 0);
             }
@@ -411,7 +425,7 @@ double layer_flops(const Spec &sp, const int in_dims[3], const int odims[3], int
     const int *d = sp.transposed ? in_dims : odims;
     return 2.0 * B * d[0] * d[1] * d[2] * (double)sp.cin * sp.cout * sp.k[0] * sp.k[1] * sp.k[2];
 }
-double rows_bytes(const Rows &r) { return (double)r.M() * r.C * (r.dtype == VN_F32 ? 4 : 2); }
+double rows_bytes(const Rows &r) { return (double)r.M() * r.C * (r.dtype == VN_BF16 ? 2 : 4); }
 // algorithmic bytes of the gradient unpack: every weight gradient read once and written once (the row-chunk partials it
 // also sums are an implementation artefact: not counted)
 double unpack_bytes(const vnUnpackJob *j, int n) {
@@ -580,6 +594,11 @@ int m0_bn_knob() {
     return v;
 }
 
+// tuning aid VN_X3_SPLIT_STORE=0: fp32x3 with every operand stored as plain fp32 and split by the kernels (round 4's form)
+int x3_split_store_on() {
+    static const int v = vn_knob("VN_X3_SPLIT_STORE", 1);
+    return v;
+}
 int heads_stream_on() {   // tuning aid VN_HEADS_STREAM=0: the heads through k_gather_gemm as before
     static const int v = vn_knob("VN_HEADS_STREAM", 1);
     return v;
@@ -946,6 +965,16 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     };
     const bool nocat = !P.exact_heads && P.adt == VN_BF16 && P.cdt == VN_BF16 && heads_stream_on() && heads_nocat_on();
     bool heads_forked = false;     // the side stream already waits for the main stream's state after the heads
+    // tuning aid VN_WG_LATE (round 5, the one scheduling experiment of the bf16 step): bit 0 — no flush at the end of the
+    // block3 chain: the weight gradients of deconv3 + block3 wait for the flush behind block2.0 and run beside block1 (big
+    // images, MFMA / HBM-bound kernels that pay least for sharing CUs) instead of beside block2's latency-bound small-image
+    // launches; bit 1 — the heads' weight gradient and bias sums wait for that flush too.  (single-call backward without
+    // bucket events only: a bucket's group-final event needs its weight gradients.)
+    static const int wg_late = vn_knob("VN_WG_LATE", 0);
+    const bool wg_late_ok = side_stream && !cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
+    const bool wg_late_b3 = wg_late_ok && (wg_late & 1), wg_late_hold_heads = wg_late_ok && (wg_late & 2);
+    bool heads_pending = false;
+    std::function<int()> heads_side;
     // ---- heads
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
@@ -953,7 +982,6 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         const int od[3] = {1, P.hf, P.wf};
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
-        int32_t hch = 1;
         const int64_t os[4] = {P.d_cat.sB, P.d_cat.sD, P.d_cat.sH, P.d_cat.sW};
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
         // the heads' weight gradient goes to the side stream behind ONE fork that also serves the early deconv
@@ -975,11 +1003,19 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         heads_forked = true;
         // the heads' bias gradients (column sums of d_rows: two small launches) are nobody's input: behind the fork, on the
         // side stream (the main stream when there is none), not between the loss and the first data gradient
-        RTT(T_MISC, NL, 0.0, 0.0, wstream,
-            vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, wstream));
-        RTT(T_WGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.cat), wstream,
-            vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, cx(P, gw), 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
-        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
+        const int hjob = nu;
+        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, 1, (int64_t)16 * 768};
+        heads_side = [&, gw, hjob]() mutable -> int {
+            int32_t hch = 1;
+            RTT(T_MISC, NL, 0.0, 0.0, wstream,
+                vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, wstream));
+            RTT(T_WGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.cat), wstream,
+                vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, cx(P, gw), 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
+            unpack[hjob].chunks = hch;     // (the unpack that holds this job is issued behind this launch)
+            return VN_OK;
+        };
+        if (wg_late_hold_heads) heads_pending = true;
+        else RT(heads_side());
     }
     auto cat_slice = [&](int off) {
         Rows r = P.d_cat;
@@ -1037,9 +1073,9 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         const Rows x = input_of(l);
         if (l == L_M2 && P.x3) {
             RTT(T_MISC, l, 0.0, 2.0 * rows_bytes(x), wstream,
-                vn_cast_rows(x.ptr, VN_F32, x.sW, x.M(), sp.cin, P.x3_src, VN_BF16, 2 * sp.cin, sp.cin, wstream));
+                vn_cast_rows(x.ptr, (vnDtype)x.dtype, x.sW, x.M(), sp.cin, P.x3_src, VN_BF16, 2 * sp.cin, sp.cin, wstream));
             RTT(T_MISC, l, 0.0, 2.0 * rows_bytes(dy), wstream,
-                vn_cast_rows(dy.ptr, VN_F32, dy.sW, dy.M(), C, P.x3_rows, VN_BF16, 2 * C, C, wstream));
+                vn_cast_rows(dy.ptr, (vnDtype)dy.dtype, dy.sW, dy.M(), C, P.x3_rows, VN_BF16, 2 * C, C, wstream));
             const size_t pass_bytes = P.dwp_bytes[l] / 3;
             int32_t total = 0;
             for (int pass = 0; pass < 3; ++pass) {
@@ -1072,8 +1108,12 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // ~6 us bubble there: measured) and issues the queued ones on the side stream.  Flushed after every block chain.
     int pending[NL], npend = 0;
     auto flush = [&]() -> int {
-        if (npend == 0) return VN_OK;
+        if (npend == 0 && !heads_pending) return VN_OK;
         RT(fork());
+        if (heads_pending) {
+            heads_pending = false;
+            RT(heads_side());
+        }
         for (int i = 0; i < npend; ++i) {
             const int l = pending[i];
             // (layers 0 and 1 keep the side stream: their sparse routes are launch sequences with the box sums / unpack)
@@ -1326,7 +1366,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             // gradients are 60 us each: started early they fill the side stream while the chain goes on; measured 480 vs
             // 473 pc/s against one flush per block), at the end of the block2 / block3 chains (per-layer flushes there
             // measure nothing: 470) and after each Conv3d
-            if ((l >= L_B1 && l < L_D1) || l == L_B2 || l == L_B3 || l <= L_M2) RT(flush());
+            if ((l >= L_B1 && l < L_D1) || l == L_B2 || (l == L_B3 && !wg_late_b3) || l <= L_M2) RT(flush());
             if (l == L_B1 && tail_balance && early_unpack_on) {
                 RT(join_wg());
                 RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack, nu), wstream, vn_unpack_wgrads_batch(unpack, nu, wstream));

@@ -66,8 +66,11 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, char *lds
 
 // swizzle of the 16-B chunk index inside a row, as a function of the row, so that the
 // transposed 8-B reads of a 32-lane half hit 32 distinct bank pairs.
-template <int ROW_BYTES, bool F32>
+template <int ROW_BYTES, bool F32, bool PS = false>
 __device__ __forceinline__ int chunk_swz(int row) {
+    // split fp32 tiles (VN_F32X3S, rows >= 256 B): a 16-column MFMA tile is the hi granules c and c + 2 (lo: c + 1, c + 3) of
+    // a row — BOTH even — so the eight rows {0..3, 8..11} of a 32-lane half must spread them with bits 0, 2 and 3
+    if (PS) return (row & 1) | (((row >> 1) & 1) << 2) | (((row >> 3) & 1) << 3);
     if (F32) return (row & 3) << 2;   // fp32 tiles (rows >= 256 B) are read with ds_read_b32: 64-B shifts by row&3
     if (ROW_BYTES == 128) return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
     return ((row & 3) << 1) | (((row >> 3) & 1) << 3);   // 256-B rows
@@ -75,8 +78,13 @@ __device__ __forceinline__ int chunk_swz(int row) {
 
 // wave tile in units of 16 channels; 2 x WKW waves (WKW = 4: eight waves on the same 128 x 128 tile, two waves per SIMD
 // at one workgroup per CU — these launches have ~256 workgroups); taps per workgroup
-template <int TN, int TK, bool F32, int TPB, int WKW = 2>
+// PS (with F32): both operands are stored split (VN_F32X3S: per 8 channels their eight hi bf16 parts, then their eight lo
+// parts) — 32 sites per stage as for fp32, the fragments by transposed reads of the hi and lo granules as in the bf16 kernel,
+// three MFMAs per tile pair and no split work (round 5; the in-register form below reads eight floats and spends 24 VALU
+// operations per fragment)
+template <int TN, int TK, bool F32, int TPB, int WKW = 2, bool PS = false>
 __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
+    static_assert(!PS || F32, "split storage is fp32-sized");
     constexpr int NWV = 2 * WKW;                            // waves per workgroup
     constexpr int ESZ = F32 ? 4 : 2;
     constexpr int ROWS = F32 ? 32 : 64;                     // sites per stage (same bytes either way)
@@ -227,7 +235,7 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
 #pragma unroll
         for (int i = 0; i < IN; ++i) {
             const int r = ((i * NWV + wave) * 1024) / RBN + lane / LPR_N;
-            const int c = (lane % LPR_N) ^ chunk_swz<RBN, F32>(r);
+            const int c = (lane % LPR_N) ^ chunk_swz<RBN, F32, PS>(r);
             const uint32_t ro = t[r * TW + TPB];
             const bool ok = ro != WG_OOB && (n0 + c * (16 / ESZ)) < p.N;
             lds_dma16(rs_r, ln + i * (1024 * NWV), ok ? ro + (uint32_t)c * 16u : WG_OOB, r_col);
@@ -238,7 +246,7 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
 #pragma unroll
             for (int i = 0; i < IK; ++i) {
                 const int r = ((i * NWV + wave) * 1024) / RBK + lane / LPR_K;
-                const int c = (lane % LPR_K) ^ chunk_swz<RBK, F32>(r);
+                const int c = (lane % LPR_K) ^ chunk_swz<RBK, F32, PS>(r);
                 const uint32_t so = t[r * TW + j];
                 const bool ok = so != WG_OOB && (k0 + c * (16 / ESZ)) < p.C;
                 lds_dma16(rs_s, lk + i * (1024 * NWV), ok ? so + (uint32_t)c * 16u : WG_OOB, s_col);
@@ -269,7 +277,39 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
         if (wave == 0 && s + 2 < nstages) table_write(s + 2);
         const char *ln = smem + buf * STAGE;
         const char *lk0 = smem + buf * STAGE + TILE_N;
-        if constexpr (F32) {
+        if constexpr (PS) {
+            // split operands: lane = 16g + 4q + pp reads, of a 16-channel tile (64 B of a row), the 8-B piece pp of rows
+            // 8g + q and 8g + q + 4: channels 4 pp .. 4 pp + 3 — hi at byte (pp >> 1) * 32 + (pp & 1) * 8, lo 16 B further
+            typedef __attribute__((address_space(3))) s16x4_t lds_s16x4_t;
+            static_assert(ROWS == 32, "one 32-site MFMA per stage");
+            const int r0 = g * 8 + q, r1 = r0 + 4;
+            const int sw0 = chunk_swz<RBN, true, true>(r0), sw1 = chunk_swz<RBN, true, true>(r1);
+            const int pc = (pp >> 1) * 2, ph = (pp & 1) * 8;          // 16-B chunk inside the tile, 8-B half
+            auto frag = [&](const char *tile, int row_bytes, int t16, int lo) {
+                const int c16 = t16 * 4 + pc + lo;
+                const char *p0 = tile + r0 * row_bytes + ((c16 ^ sw0) << 4) + ph;
+                const char *p1 = tile + r1 * row_bytes + ((c16 ^ sw1) << 4) + ph;
+                const s16x4_t v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p0);
+                const s16x4_t v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t *)p1);
+                const s16x8_t t8 = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                return __builtin_bit_cast(bf16x8_t, t8);
+            };
+            bf16x8_t ah[TN], al[TN];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                ah[i] = frag(ln, RBN, wn * TN + i, 0);
+                al[i] = frag(ln, RBN, wn * TN + i, 1);
+            }
+#pragma unroll
+            for (int t = 0; t < TPB; ++t)
+#pragma unroll
+                for (int j = 0; j < TK; ++j) {
+                    const bf16x8_t bh = frag(lk0 + t * TILE_K, RBK, wk * TK + j, 0);
+                    const bf16x8_t bl = frag(lk0 + t * TILE_K, RBK, wk * TK + j, 1);
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) acc[t][i][j] = vn_mfma_x3(ah[i], al[i], bh, bl, acc[t][i][j]);
+                }
+        } else if constexpr (F32) {
             // v_mfma_f32_16x16x4_f32: lane (c = lane&15, kq = lane>>4) supplies element [site 4s+kq][col c]
             const int fc = lane & 15, kq = lane >> 4;
             if (p.x3) {
@@ -615,15 +655,15 @@ __global__ void __launch_bounds__(256 * NH, 2) k_wgrad_patch(const WPParams p) {
         }
 }
 
-template <int TN, int TK, bool F32, int TPB, int WKW = 2>
+template <int TN, int TK, bool F32, int TPB, int WKW = 2, bool PS = false>
 int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
     constexpr int DN = 32 * TN, DK = 16 * WKW * TK;
     // same stage bytes for bf16 (64 sites) and fp32 (32 sites); + the row table
     constexpr size_t lds = 2u * 64u * (DN + TPB * DK) * 2u + 2u * 64u * (TPB + 1) * 4u;
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK, F32, TPB, WKW>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad<TN, TK, F32, TPB, WKW, PS>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (attr != hipSuccess) return (int)attr;
-    k_wgrad<TN, TK, F32, TPB, WKW><<<grid, 128 * WKW, lds, st>>>(p);
+    k_wgrad<TN, TK, F32, TPB, WKW, PS><<<grid, 128 * WKW, lds, st>>>(p);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -661,7 +701,7 @@ static WGPlan wgrad_plan(const vnConv *g, int32_t split, int64_t M) {
     // fp32x3 (VALU / LDS-latency-bound stages, one workgroup does not fill a CU): 192 / 256 / 384 / 512 -> 246 / 259 / 265 /
     // 262 point-clouds/s in that mode (round 4)
     static const int knob = vn_knob("VN_WG_BLOCKS", 0);   // tuning aid; 0 = 256 (384 for fp32x3)
-    const int target = knob > 0 ? knob : (g->dtype == VN_F32X3 ? 384 : 256);
+    const int target = knob > 0 ? knob : ((g->dtype == VN_F32X3 || g->dtype == VN_F32X3S) ? 384 : 256);
     int64_t chunks = target / ((int64_t)w.groups * w.tiles_n * w.tiles_k);
     const int64_t slabs = vn_ceil_div(M, 64);
     if (chunks > slabs / 10) chunks = slabs / 10;
@@ -794,7 +834,10 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     VN_CHECK_ARG(g->kD >= 1 && g->kH >= 1 && g->kW >= 1 && g->kD * g->kH * g->kW <= 65535);
     if (!row_list && (g->divD != 1 || g->divH != 1 || g->divW != 1)) return VN_EUNSUPPORTED;
     if (g->divD < 1 || g->divH < 1 || g->divW < 1) return VN_EINVAL;
-    VN_CHECK_ARG(g->dtype == VN_BF16 || ((g->dtype == VN_F32 || g->dtype == VN_F32X3) && !split));
+    VN_CHECK_ARG(g->dtype == VN_BF16 || ((g->dtype == VN_F32 || g->dtype == VN_F32X3 || g->dtype == VN_F32X3S) && !split));
+    const bool ps = g->dtype == VN_F32X3S;    // both operands stored split: 16-channel tiles, strides in whole 8-channel groups
+    if (ps && ((g->Cs & 15) || (g->Cr & 15) || ((g->src_sB | g->src_sD | g->src_sH | g->src_sW | g->out_sB | g->out_sD | g->out_sH | g->out_sW) & 7)))
+        return VN_EUNSUPPORTED;
     const bool f32 = g->dtype != VN_BF16;
     const int esz = f32 ? 4 : 2, al = 16 / esz - 1;
     if (g->Cs <= 0 || (g->Cs & al) || g->Cr <= 0 || (g->Cr & al)) return VN_EUNSUPPORTED;
@@ -814,7 +857,7 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     p.padD = g->padD; p.padH = g->padH; p.padW = g->padW;
     p.kD = g->kD; p.kH = g->kH; p.kW = g->kW;
     p.C = g->Cs; p.N = g->Cr; p.split = split ? 1 : 0;
-    p.x3 = g->dtype == VN_F32X3;
+    p.x3 = g->dtype == VN_F32X3 || ps;
     const int wmul = split ? 2 : 1;
     const int64_t sbytes = ((int64_t)(g->B - 1) * g->src_sB + (int64_t)(g->Ds - 1) * g->src_sD +
                             (int64_t)(g->Hs - 1) * g->src_sH + (int64_t)(g->Ws - 1) * g->src_sW + wmul * g->Cs) * esz;
@@ -911,7 +954,12 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     static const int tri_waves = vn_knob("VN_WG_TRI_WAVES", 8);   // waves per workgroup of the three-tap tiles (4: round 2)
     if (tri && tri_waves == 8) rc = k128 ? launch_wgrad<2, 2, false, 3, 4>(p, grid, st) : launch_wgrad<2, 1, false, 3, 4>(p, grid, st);
     else if (tri) rc = k128 ? launch_wgrad<2, 4, false, 3>(p, grid, st) : launch_wgrad<2, 2, false, 3>(p, grid, st);
-    else if (f32 && p.x3) {
+    else if (ps) {
+        if (n128 && k128) rc = launch_wgrad<4, 2, true, 1, 4, true>(p, grid, st);
+        else if (n128) rc = launch_wgrad<4, 1, true, 1, 4, true>(p, grid, st);
+        else if (k128) rc = launch_wgrad<2, 2, true, 1, 4, true>(p, grid, st);
+        else rc = launch_wgrad<2, 1, true, 1, 4, true>(p, grid, st);
+    } else if (f32 && p.x3) {
         // fp32x3: a stage is 48 bf16 MFMAs per 128 x 128 tile instead of 128 fp32 ones — the four-wave workgroup that the
         // exact fp32 path can afford (its MFMAs hide everything) leaves the fragment gathers exposed: eight waves
         if (n128 && k128) rc = launch_wgrad<4, 2, true, 1, 4>(p, grid, st);

@@ -80,6 +80,7 @@ _P = ctypes.POINTER
 SIGNATURES = {
     "vn_abi_version": (c_i32, []),
     "vn_build_info": (ctypes.c_char_p, []),
+    "vn_build_id": (ctypes.c_char_p, []),
     "vn_voxelize_workspace_bytes": (c_sz, [c_i64, _P(VnGrid)]),
     "vn_voxelize_index": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_vp, c_vp]),
     "vn_voxelize_gather": (c_i32, [c_vp, c_i64, _P(VnGrid), c_vp, c_sz, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
@@ -209,7 +210,7 @@ class VoxelnetHipError(RuntimeError):
     pass
 
 
-ABI_VERSION = 3     # include/voxelnet_hip.h: vn_abi_version()
+ABI_VERSION = 4     # include/voxelnet_hip.h: vn_abi_version()
 
 
 def load():
