@@ -154,7 +154,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="car", choices=sorted(CONFIGS),
                     help="car = BASELINE configs[1] (the metric's workload, default), ped = configs[2], dense = configs[4]")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "bf16x3", "fp32x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32", "fp32x3"])
     ap.add_argument("--batch", type=int, default=0, help="frames per GPU (default: the config's: 2, 2, 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -479,7 +479,7 @@ def main():
     # ---- per-kernel durations: the native executor's own HIP events around every launch (same path as the timed region),
     #      torch events around the launch groups the Python side issues (voxelizer, VFE, loss, optimizer)
     recs, sect = None, None
-    native_timed = model.native_executor and args.precision in ("bf16", "fp32", "fp32x3")
+    native_timed = bool(model.native_executor)
     if not args.no_kernel_timer and (rank == 0 or world > 1):
         sect = E.KernelTimer()
         E.SECTIONS = sect
@@ -512,10 +512,10 @@ def main():
         maps["bf16"] = maps_of(build_model("bf16"))
         parity = {}
         for prec, nsteps, note in (("fp32", 5, "fp32 operands on v_mfma_f32_16x16x4_f32: the mode of the <= 1e-3 parity tests"),
-                                   ("fp32x3", 5, "fp32 storage, every conv / weight-gradient product as three bf16 MFMAs on hi / lo splits made "
-                                                 "in registers (VN_F32X3), native executor: the fast mode INSIDE the 1e-3 map tolerance"),
-                                   ("bf16x3", 3, "[hi|lo] bf16 operand pairs, three bf16 MFMA products per fp32 product; per-layer "
-                                                 "orchestration from Python (not the native executor: host-bound)")):
+                                   ("fp32x3", 5, "fp32-sized storage, every conv / weight-gradient product as three bf16 MFMAs on hi / lo "
+                                                 "splits (VN_F32X3); round 5: activations and gradients are STORED split by the BatchNorm "
+                                                 "passes (VN_F32X3S), no split work in the kernels; native executor: the fast mode INSIDE "
+                                                 "the 1e-3 map tolerance")):
             pm = build_model(prec)
             maps[prec] = maps_of(pm)
             state.update(model=pm, params=list(pm.parameters()), named=list(pm.named_parameters()),
@@ -533,7 +533,7 @@ def main():
             state.update(model=model, params=params, named=named, opt=opt)
             del pm
         M.set_precision(args.precision)
-        for prec in ("bf16", "bf16x3", "fp32x3"):
+        for prec in ("bf16", "fp32x3"):
             (pa, ra), (pb, rb) = maps[prec], maps["fp32"]
             err = {"prob_max_over_max": float((pa - pb).abs().max() / pb.abs().max()), "prob_rel_l2": float((pa - pb).norm() / pb.norm()),
                    "reg_max_over_max": float((ra - rb).abs().max() / rb.abs().max()), "reg_rel_l2": float((ra - rb).norm() / rb.norm())}
@@ -542,9 +542,9 @@ def main():
 
     if rank == 0:
         value = world * B * args.steps / dt
-        # fp32x3 / bf16x3 evaluate every algorithmic (fp32) product as THREE bf16 MFMA products: the roof for algorithmic FLOPs
+        # fp32x3 evaluates every algorithmic (fp32) product as THREE bf16 MFMA products: the roof for algorithmic FLOPs
         # is a third of the dense bf16 MFMA peak
-        peak = {"fp32": PEAK_F32_MATRIX_TFLOPS, "fp32x3": PEAK_BF16_DENSE_TFLOPS / 3.0, "bf16x3": PEAK_BF16_DENSE_TFLOPS / 3.0}.get(
+        peak = {"fp32": PEAK_F32_MATRIX_TFLOPS, "fp32x3": PEAK_BF16_DENSE_TFLOPS / 3.0}.get(
             args.precision, PEAK_BF16_DENSE_TFLOPS)
         metric = "point-clouds/sec fwd+bwd, KITTI car voxel grid, batch=2"
         if args.config != "car":
@@ -556,7 +556,7 @@ def main():
             # the spread over --windows timed regions of --steps steps in this run (the first one is `value`)
             "value_min": vals[0], "value_median": vals[len(vals) // 2], "value_max": vals[-1], "windows": len(vals),
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"bf16": "bf16", "fp32": "f32", "bf16x3": "bf16x3", "fp32x3": "f32 storage / bf16x3 products"}[args.precision], "data": "synthetic",
+            "dtype": {"bf16": "bf16", "fp32": "f32", "fp32x3": "f32 storage / bf16x3 products"}[args.precision], "data": "synthetic",
             "config": {"workload": "%s, batch=%d per GPU, fwd+bwd train step (BASELINE configs[%d])" % (cfg_desc, B, cfg_index),
                        "global_batch": world * B, "points_per_frame": int(frames_np[0].shape[0]),
                        "parallelism": "dp%d" % world,
@@ -581,6 +581,7 @@ def main():
             red = model.grad_reducer
             res["allreduce"] = {"exposed_ms_per_step": exposed_ms, "bucket_bytes": [int(b["flat"].numel() * 4) for b in red.buckets],
                                 "path": "vn_allreduce_bucket (library RCCL wrapper)" if red.comm is not None else "torch.distributed (%s)" % (dist.get_backend() if world > 1 else "world 1: no collective"),
+                                "comm_stream": red.comm_stream_kind,      # VN_COMM_STREAM=private | pipeline (default): parallel.py
                                 "rccl_version_bound_by_library": int(_lib.load().vn_comm_rccl_version()),
                                 "torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
                                 "note": "exposed = median time the training stream waits in GradAllReducer.finish (HIP events, 10 steps, "
@@ -656,7 +657,6 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": 1e3 * t / n, "launches_per_step": n / ns,
                     "gflop_per_step": f / ns / 1e9, "ms_per_step": t / ns,
                     "peak_note": {"fp32x3": "2500 / 3 TFLOP/s: three bf16 MFMA products per algorithmic fp32 product",
-                                  "bf16x3": "2500 / 3 TFLOP/s: three bf16 MFMA products per algorithmic fp32 product",
                                   "fp32": "v_mfma_f32_16x16x4_f32 dense peak"}.get(args.precision, "dense bf16 MFMA peak"),
                     "note": "algorithmic FLOPs (SURVEY.md 8d; the launches that skip constant data — the rulebook first layer, "
                             "the row-list data gradients at its active sites — with the FLOPs they execute) / summed "

@@ -192,10 +192,9 @@ int vn_scatter_dense_bwd(const void *d_dense, vnDtype dtype, const int64_t *coor
  * classes of a stride-1 gather, all inside one launch.
  *
  * Operands are bf16 with fp32 accumulation on v_mfma_f32_16x16x32_bf16.
- * "split" (fp32-accurate, bf16x3) mode: activations are stored as 2C-wide rows
- * [hi | lo] (hi = bf16(x), lo = bf16(x - hi)), weights are packed 3C-wide along
- * K as [hi ; hi ; lo], Cs = 3C and src_wrap = 2C: K index k reads source column
- * k (k < 2C) or k - 2C, i.e. a_hi*w_hi + a_lo*w_hi + a_hi*w_lo.
+ * (The "split" bf16x3 mode of rounds 1-4 — [hi | lo] 2C-wide rows, weights [hi ; hi ; lo], src_wrap = 2C — was retired in
+ * round 5: vnConv.src_wrap, the `split` argument of the weight-gradient entry points and vn_pack_weight's split3 must be 0
+ * (VN_EUNSUPPORTED otherwise).  The fp32-accurate products are VN_F32X3 / VN_F32X3S: same error, one launch.)
  * Addresses are explicit strides in ELEMENTS, so channel slices of a wider
  * buffer (the 768-channel concat, model.py:271-273) and the BEV fold
  * (model.py:262) are views, not copies.
@@ -207,7 +206,7 @@ typedef struct {
     int32_t Ds, Hs, Ws;   /* source (gathered) tensor sites */
     int32_t Dr, Hr, Wr;   /* row (produced) tensor sites */
     int32_t Cs;           /* GEMM K per tap (multiple of 8 bf16 / 4 fp32 elements; 3C in split mode) */
-    int32_t src_wrap;     /* 0, or 2C in split mode (see above) */
+    int32_t src_wrap;     /* must be 0 (the K wrap of the retired bf16x3 mode) */
     int32_t Cr;           /* GEMM N = row channels (multiple of 4) */
     int32_t kD, kH, kW;   /* taps */
     int32_t mulD, mulH, mulW;
@@ -237,9 +236,8 @@ int32_t vn_conv_plan_id(const vnConv *geom);
  * The sum over m is split into row chunks whose partial tiles go to `workspace`
  * (vn_conv_wgrad_workspace_bytes; n_rows = 0 for the dense form) and are then added in a fixed order: no
  * atomics, bit-reproducible.  A NULL / smaller workspace only means fewer chunks (less parallelism).
- * rows_* strides address the (B,Dr,Hr,Wr,Cr) gradient.  split != 0: src rows are [hi|lo] 2C wide and rows
- * are [hi|lo] 2Cr wide; the three bf16x3 products are accumulated.
- * geom->Cs is the real C here and geom->src_wrap is ignored. */
+ * rows_* strides address the (B,Dr,Hr,Wr,Cr) gradient.  split must be 0 (retired, see above).
+ * geom->dtype VN_F32X3S: BOTH operands are stored split; VN_F32X3: both are fp32 and split in registers. */
 size_t vn_conv_wgrad_workspace_bytes(const vnConv *geom, int32_t split, int64_t n_rows);
 int vn_conv_wgrad(const void *src /*bf16*/, const void *rows /*bf16*/, float *dw_packed,
                   const vnConv *geom, int32_t split, void *workspace, size_t workspace_bytes,
@@ -311,7 +309,7 @@ int vn_fill_rows(void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stride, c
  * mode 1: Conv weight                 -> data-grad operand [tap][Cin][Cout]
  * mode 2: ConvTranspose weight (Cin,Cout,kh,kw) -> forward operand [tap][Cout][Cin]
  * mode 3: ConvTranspose weight        -> data-grad operand [tap][Cin][Cout]
- * split3: emit the bf16x3 expansion [hi;hi;lo] along K (3x wide rows).
+ * split3: must be 0 (the [hi;hi;lo] K expansion of the retired bf16x3 mode).
  * packed_dtype VN_F32X3 (operand of a convolution launched with vnConv.dtype VN_F32X3): rows of K fp32-sized slots
  * in the "split fp32" format of VN_F32X3S: every aligned group of 8 input channels (32 B) = the eight hi bf16 parts, then
  * the eight lo parts (hi = bf16(w), lo = bf16(w - hi)) — a lane of the kernels reads the group 8 fq .. 8 fq + 7 of each
@@ -378,7 +376,7 @@ int vn_fov_crop(const float *points, int64_t n, const float *P_3x4, const float 
  * a caller can start the gradient all-reduce of finished parameter groups in between.
  * ---------------------------------------------------------------------- */
 typedef struct {
-    int32_t B, D, H, W;      /* dense voxel grid (D must be 10) */
+    int32_t B, D, H, W;      /* dense voxel grid; D = 9 .. 12 (every depth whose three Conv3d layers fold to 2: model.py:207-209, 262) */
     int32_t block1_stride;   /* 2: Car, 1: Pedestrian/Cyclist (model.py:212-227) */
     int32_t mode;            /* 0 bf16, 1 fp32, 2 fp32x3 (fp32 storage, conv / weight-gradient products as three bf16 MFMAs: VN_F32X3) */
     int32_t training;        /* BatchNorm: batch statistics + running-stat update, or running statistics */
@@ -499,20 +497,6 @@ int vn_bn_stats(const void *y, vnDtype dtype, int64_t M, int32_t C, int64_t stri
 int vn_bn_finalize(const double *sums, int64_t M, int32_t C, int32_t fold, const float *shift,
                    const float *gamma, const float *beta, float *running_mean, float *running_var,
                    int32_t training, float momentum, float eps, float *stats, vnStream stream);
-/* vn_bn_finalize_slab + vn_bn_apply in ONE launch (round 4: the small layers' finalize launches are pure latency on the
- * step's dependency chain): a workgroup owns 8 channels x a range of rows, reduces its 64 B of every slab row in the
- * order vn_bn_finalize_slab uses and applies; stats, running statistics and a are bit-identical to the two calls. */
-int vn_bn_finalize_apply_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *shift,
-                              const float *gamma, const float *beta, float *running_mean, float *running_var,
-                              float momentum, float eps, float *stats, const void *y, vnDtype y_dtype,
-                              int64_t y_stride, int32_t relu, void *a, vnDtype a_dtype, int64_t a_stride,
-                              vnStream stream);
-/* vn_bn_bwd_finalize_slab + vn_bn_bwd_apply in ONE launch, same construction: coef, d_gamma, d_beta and dy bit-identical. */
-int vn_bn_bwd_finalize_apply_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *gamma,
-                                  const float *stats, float *coef, float *d_gamma, float *d_beta, const void *da,
-                                  vnDtype da_dtype, int64_t da_stride, const void *y, vnDtype y_dtype,
-                                  int64_t y_stride, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
-                                  vnStream stream);
 /* same, from a vn_conv_gather_gemm stats slab: float[rows][2][C] partial sums of (y - shift) */
 int vn_bn_finalize_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *shift,
                         const float *gamma, const float *beta, float *running_mean, float *running_var,
@@ -547,19 +531,6 @@ int vn_bn_bwd_apply(const void *da, vnDtype da_dtype, int64_t da_stride, const v
                     vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
                     const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
                     int64_t lo_off, vnStream stream);
-/* The same two passes for a deconv that feeds the heads (model.py:272-281 backward; /root/reference/voxelnet/model.py:251-281),
- * with da formed in the pass itself: da[m][c] = sum_k d_rows[m][k] * W[c_base + c][k] (fp32 FMA chain over k = 0..15 of the
- * bf16 operands) — d_rows (M,16) bf16 = the heads' conv-output gradient (vn_heads_bwd), w_packed_dgrad = the packed [768][16]
- * bf16 data-gradient operand of the heads (vn_pack_weight mode 1), c_base = the deconv's first channel in the concat.  The
- * (M,768) concat gradient (vn_heads_dgrad: 108 MB at the car size, read twice per deconv) is then never written.  Grids, slab
- * rows (vn_bn_bwd_slab_rows) and summation order are those of vn_bn_bwd_reduce_slab / vn_bn_bwd_apply. */
-int vn_bn_bwd_reduce_slab_heads(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, int32_t c_base,
-                                const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C,
-                                const float *stats, int32_t relu, float *slab, vnStream stream);
-int vn_bn_bwd_apply_heads(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, int32_t c_base,
-                          const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
-                          const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
-                          vnStream stream);
 /* BEV-fold variants for the last Conv3d (model.py:262): y / dy are its plain (B*2*H*W, C=64) rows, a / da the
  * (B,1,H,W,2C) tensor block1 sees (row stride wide_stride, channel = d*C + c).  hw = H*W.  One launch each. */
 int vn_bn_apply_bev(const void *y, vnDtype y_dtype, int64_t M, int32_t C, int64_t hw, const float *stats,

@@ -13,6 +13,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
 DDP_REHEARSAL = {}     # filled by pytest_sessionstart on a GPU run: {"procs": [...], "dir": ..., "error": ...}
+BENCH_RUN = {}         # bench.py started beside them: {"proc": ..., "dir": ...}
 
 
 def pytest_configure(config):
@@ -50,12 +51,19 @@ def pytest_sessionstart(session):
             procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), "2", port, d],
                                           stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT))
         DDP_REHEARSAL.update(procs=procs, dir=d)
+        # tests/test_gpu_bench_contract.py: bench.py's N = 1 path with the reducer attached, 2 steps, as its own process
+        # (started here for the same reason as the ranks above)
+        blog = open(os.path.join(d, "bench.err"), "w")
+        bout = open(os.path.join(d, "bench.json"), "w")
+        BENCH_RUN.update(dir=d, proc=subprocess.Popen(
+            [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--windows", "1", "--timer-steps", "1",
+             "--force-reducer", "--no-parity-mode"], stdout=bout, stderr=blog, env=env, cwd=ROOT))
     except Exception as e:  # noqa: BLE001 - reported by the test
         DDP_REHEARSAL["error"] = repr(e)
 
 
 def pytest_sessionfinish(session, exitstatus):
-    for p in DDP_REHEARSAL.get("procs", []):
+    for p in DDP_REHEARSAL.get("procs", []) + ([BENCH_RUN["proc"]] if "proc" in BENCH_RUN else []):
         if p.poll() is None:
             p.kill()
 

@@ -133,10 +133,9 @@ def plan_ids(_lib, spec, B, in_dims):
             lib.vn_conv_wgrad_plan_id(ctypes.byref(gw), 0, 0))
 
 
-# weight-gradient kernel of the wide stride-1 3x3 layers: 44 = the single-tap 128 x 128 row form (default), 202 = the
-# 128 x 64 nine-tap patch tile when the whole test process runs under VN_WGRAD_PATCH=3 (tools/final_run.sh runs this file
-# a second time that way, so the alternative kernel keeps its half-ulp coverage)
-WG9 = 202 if (int(os.environ.get("VN_WGRAD_PATCH", "1")) & 2) else 44
+# weight-gradient kernel of the wide stride-1 3x3 layers: 44 = the single-tap 128 x 128 row form (round 4's nine-tap 128 x 64
+# patch tile, plan 202, left the library in round 5)
+WG9 = 44
 
 # name, kind, dim, cin, cout, k, stride, pad | test (B, input spatial) | production (B, input spatial) it stands for |
 # expected (forward, data-gradient, weight-gradient) kernel ids (vn_conv_plan_id / vn_conv_wgrad_plan_id)
@@ -666,67 +665,3 @@ def test_heads_streaming_kernels():
         dcat = torch.full((M, 768), float("nan"), dtype=torch.bfloat16, device=DEV)
         _lib.call("vn_heads_dgrad", g_d.data_ptr(), 16, wd.data_ptr(), dcat.data_ptr(), 768, M, E.stream())
         assert_rounded(dcat.float(), (g.double() @ w.double()).numpy(), "heads data gradient")
-
-
-def test_deconv_bn_backward_from_the_heads_rows():
-    """vn_bn_bwd_reduce_slab_heads / vn_bn_bwd_apply_heads (round 4: the deconvs' BatchNorm backward forms the gradient w.r.t.
-    their activation from d_rows (M,16) and the heads' packed weights — the (M,768) concat gradient of vn_heads_dgrad is never
-    written; model.py:251-281 backward) against float64 on the bf16 operands: the slab sums (-> d_gamma, d_beta, coef through
-    the SAME finalize launch) as fp32 sums, dy correctly rounded; for every concat slice, at the full 2 x 200 x 176 map with
-    regression gradients at ~0.1 % of the sites (the benchmarked case: two products per channel elsewhere) and with dense
-    regression gradients (every site takes the sixteen-term path)."""
-    from voxelnet_amd import _lib, engine as E
-    lib = _lib.load()
-    C = 256
-    for (M, dense_reg) in ((2 * 200 * 176, False), (3001, True)):
-        w = bf16r(seeded((16, 768), 9600 + M, 0.05))
-        wd = w.t().contiguous().to(torch.bfloat16).to(DEV)                  # [768][16]: vn_pack_weight mode 1
-        g = bf16r(seeded((M, 16), 9700 + M, 0.3))
-        if not dense_reg:
-            keep = torch.from_numpy(np.random.default_rng(5).random(M) < 1e-3)
-            g[~keep, 2:] = 0.0
-        g_d = g.to(torch.bfloat16).to(DEV)
-        for cb in (0, 256, 512):
-            y = bf16r(seeded((M, C), 9800 + cb, 1.0))
-            y_d = y.to(torch.bfloat16).to(DEV)
-            gamma = (seeded((C,), 9900 + cb, 0.2) + 1.0).to(DEV)
-            mean = y.double().mean(0)
-            var = y.double().var(0, unbiased=False)
-            invstd = 1.0 / torch.sqrt(var + 1e-5)
-            beta = seeded((C,), 9950 + cb, 0.3)
-            stats = torch.cat([mean.float(), invstd.float(), gamma.cpu() * invstd.float(), beta]).to(DEV)   # [mean|invstd|S|beta]
-            rows = int(lib.vn_bn_bwd_slab_rows(M, C))
-            slab = torch.full((rows, 2, C), float("nan"), device=DEV)
-            _lib.call("vn_bn_bwd_reduce_slab_heads", g_d.data_ptr(), 16, wd.data_ptr(), cb, y_d.data_ptr(), _lib.VN_BF16, C, M, C,
-                      stats.data_ptr(), 1, slab.data_ptr(), E.stream())
-            # float64 restatement on the operands the pass reads (stats as stored in fp32)
-            st = stats.double().cpu()
-            da = g.double() @ w.double()[:, cb:cb + C]                       # (M, C)
-            d0 = y.double() - st[:C]
-            z = st[2 * C:3 * C] * d0 + st[3 * C:]
-            dz = torch.where(z > 0, da, torch.zeros_like(da))
-            xhat = d0 * st[C:2 * C]
-            s1, s2 = dz.sum(0), (dz * xhat).sum(0)
-            got = slab.double().sum(0).cpu()
-            assert_fp32_sum(got[0], s1.numpy(), dz.abs().sum(0).numpy(), "heads-fed reduce: sum dz", l2_tol=1e-4)
-            assert_fp32_sum(got[1], s2.numpy(), (dz * xhat).abs().sum(0).numpy(), "heads-fed reduce: sum dz xhat", l2_tol=1e-4)
-            coef = torch.empty(3 * C, device=DEV)
-            dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
-            _lib.call("vn_bn_bwd_finalize_slab", slab.data_ptr(), rows, M, C, gamma.data_ptr(), stats.data_ptr(), coef.data_ptr(),
-                      dgam.data_ptr(), dbet.data_ptr(), E.stream())
-            dy = torch.full((M, C), float("nan"), dtype=torch.bfloat16, device=DEV)
-            _lib.call("vn_bn_bwd_apply_heads", g_d.data_ptr(), 16, wd.data_ptr(), cb, y_d.data_ptr(), _lib.VN_BF16, C, M, C,
-                      stats.data_ptr(), coef.data_ptr(), 1, dy.data_ptr(), _lib.VN_BF16, C, E.stream())
-            cf = coef.double().cpu()
-            dy_ref = cf[:C] * dz + cf[C:2 * C] * d0 + cf[2 * C:]
-            assert_rounded(dy.float(), dy_ref.numpy(), f"heads-fed apply (slice {cb})")
-            # and against the stored route: vn_heads_dgrad -> vn_bn_bwd_reduce_slab (da rounded to bf16 on the way): same sums
-            # to the rounding of da (2^-9 per element, averaging out over the rows)
-            dcat = torch.empty((M, 768), dtype=torch.bfloat16, device=DEV)
-            _lib.call("vn_heads_dgrad", g_d.data_ptr(), 16, wd.data_ptr(), dcat.data_ptr(), 768, M, E.stream())
-            slab2 = torch.empty((rows, 2, C), device=DEV)
-            _lib.call("vn_bn_bwd_reduce_slab", dcat[:, cb:].data_ptr(), _lib.VN_BF16, 768, y_d.data_ptr(), _lib.VN_BF16, C, M, C,
-                      stats.data_ptr(), 1, slab2.data_ptr(), E.stream())
-            old = slab2.double().sum(0).cpu()
-            scale = dz.abs().sum(0)
-            assert float(((old[0] - got[0]).abs() / scale).max()) < 2e-3

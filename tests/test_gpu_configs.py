@@ -120,7 +120,7 @@ def test_car_full_size_batch2_fp32_maps():
     from voxelnet_amd.config import grid_config
     grid = grid_config("Car")
     assert grid.dims == (10, 400, 352) and grid.T == 35 and grid.block1_stride == 2
-    frames = synth.workload_frames(1, batch=2)                    # bench.py's frames (BASELINE configs[1])
+    frames = synth.workload_frames(2, batch=2)                    # bench.py's frames: workload 2 = BASELINE configs[1] (bench.py CONFIGS["car"])
     feats, coords = voxelize_frames(frames, grid)
     assert len(feats) == 2 and feats[0].shape[1:] == (35, 7)
     sd = tr.make_state_dict("Car")
@@ -159,7 +159,7 @@ def test_car_full_size_batch2_fp32_maps():
             prob, reg = m.detect(feats, coords)
         eb = rel_err(prob, rp), rel_err(reg, rr)
         print(f"car full size batch 2, bf16 mode vs CPU oracle: prob {eb[0]:.2e}, reg {eb[1]:.2e} (reported; bars: test_gpu_bf16_parity.py)")
-        assert eb[0] < 0.25 and eb[1] < 0.25
+        assert eb[0] < 0.12 and eb[1] < 0.12          # (measured 8.1e-2 / 4.5e-2 on workload 1, round 4: measured + 50 %)
     finally:
         M.set_precision("bf16")
 

@@ -67,7 +67,7 @@ def x3_flag():
     E.X3["on"] = False
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "fp32x3"])
+@pytest.mark.parametrize("mode", ["fp32", "fp32x3"])
 @pytest.mark.parametrize("case", PER_LAYER_CASES, ids=lambda c: c[0])
 def test_layer_fwd_bwd(golden, case, mode, x3_flag):
     from voxelnet_amd import engine as E
@@ -130,7 +130,7 @@ def test_layer_fwd_bwd(golden, case, mode, x3_flag):
             assert rel_err(Bf[k_], g[f"{name}.buf.batch_norm.{k_}"]) < 1e-3
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3", "bf16"])
+@pytest.mark.parametrize("mode", ["fp32", "bf16"])
 def test_heads_fused(mode):
     """prob_conv + reg_conv (model.py:253-254,276-281) as one N=16 GEMM with the sigmoid epilogue."""
     from oracle import torch_ref as tr
@@ -150,7 +150,7 @@ def test_heads_fused(mode):
     assert rel_err(reg, ref[:, 2:].numpy()) < TOL[mode]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.mark.parametrize("mode", ["fp32"])
 def test_bev_fold_and_strided_views(mode):
     """middle_layer.2 -> BEV reshape (model.py:262) -> block1.0, against the oracle."""
     from oracle import torch_ref as tr
@@ -589,75 +589,6 @@ def test_data_gradient_with_fused_batchnorm_backward_sums(dt, shape):
     for a, bb in zip(out0[1:], out1[1:]):                                  # d_gamma, d_beta: fp32 partials in another grouping
         assert float((a - bb).abs().max()) < 1e-5 * sc * 3
     assert torch.allclose(out0[0], out1[0], rtol=1e-4, atol=1e-5 * sc / M)
-
-
-@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
-@pytest.mark.parametrize("M,C,rows,a_stride", [(17600, 128, 275, 128), (4400, 256, 69, 256), (70400, 128, 550, 128),
-                                                (70400, 256, 640, 768), (1003, 64, 7, 64), (513, 8, 300, 8)],
-                         ids=["block2", "block3", "block1", "deconv-into-concat", "ragged", "narrow"])
-def test_fused_batchnorm_finalize_apply_is_bit_identical_to_the_two_launches(dt, M, C, rows, a_stride):
-    """vn_bn_finalize_apply_slab / vn_bn_bwd_finalize_apply_slab (round 4: one launch per BatchNorm and direction on the
-    small layers; model.py:142,153,162,193,198) against vn_bn_finalize_slab + vn_bn_apply and vn_bn_bwd_finalize_slab +
-    vn_bn_bwd_apply: the statistics, the running statistics, the activation, coef, d_gamma, d_beta and dy must be the
-    SAME BITS (the fused kernel repeats the finalize kernels' summation order)."""
-    from voxelnet_amd import _lib
-    from voxelnet_amd import engine as E
-    dev = "cuda:0"
-    vdt = _lib.VN_BF16 if dt == torch.bfloat16 else _lib.VN_F32
-    g = torch.Generator(device="cpu").manual_seed(M * 7 + C)
-    y = (torch.randn((M, C), generator=g) * 1.7 + 0.3).to(dt).to(dev)
-    da = (torch.randn((M, C), generator=g) * 1e-2).to(dt).to(dev)
-    slab = (torch.randn((rows, 2, C), generator=g).abs() * 50.0).to(dev)
-    slab[:, 0] *= torch.sign(torch.randn((rows, C), generator=g)).to(dev)        # sums of (y - shift): either sign
-    slab[:, 1] += slab[:, 0] ** 2 / max(M // rows, 1)                            # keeps the variance positive
-    bslab = (torch.randn((rows, 2, C), generator=g) * 3e-2).to(dev)
-    shift = torch.randn(C, generator=g).to(dev)
-    gamma = (1.0 + 0.2 * torch.randn(C, generator=g)).to(dev)
-    beta = (0.1 * torch.randn(C, generator=g)).to(dev)
-    st = E.stream()
-
-    def forward(fused):
-        rm, rv = torch.zeros(C, device=dev) + 0.25, torch.ones(C, device=dev) * 1.5
-        stats = torch.full((4 * C,), float("nan"), device=dev)
-        a = torch.full((M, a_stride), -7.0, dtype=dt, device=dev)
-        if fused:
-            _lib.call("vn_bn_finalize_apply_slab", slab.data_ptr(), rows, M, C, shift.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                      rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, stats.data_ptr(), y.data_ptr(), vdt, C, 1, a.data_ptr(), vdt,
-                      a_stride, st)
-        else:
-            _lib.call("vn_bn_finalize_slab", slab.data_ptr(), rows, M, C, shift.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                      rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, stats.data_ptr(), st)
-            _lib.call("vn_bn_apply", y.data_ptr(), vdt, C, M, C, stats.data_ptr(), 1, a.data_ptr(), vdt, a_stride, 0, st)
-        torch.cuda.synchronize()
-        return rm, rv, stats, a
-
-    f0, f1 = forward(False), forward(True)
-    for name, u, v in zip(("running_mean", "running_var", "stats", "a"), f0, f1):
-        assert torch.equal(u.view(torch.int16 if u.dtype == torch.bfloat16 else torch.int32),
-                           v.view(torch.int16 if v.dtype == torch.bfloat16 else torch.int32)), name
-    assert torch.isfinite(f1[2]).all() and (f1[3][:, C:] == -7.0).all()             # nothing written outside the C columns
-    stats = f0[2]
-
-    def backward(fused):
-        coef = torch.full((3 * C,), float("nan"), device=dev)
-        dg, db = torch.full((C,), float("nan"), device=dev), torch.full((C,), float("nan"), device=dev)
-        dy = torch.full((M, C), 5.0, dtype=dt, device=dev)
-        if fused:
-            _lib.call("vn_bn_bwd_finalize_apply_slab", bslab.data_ptr(), rows, M, C, gamma.data_ptr(), stats.data_ptr(), coef.data_ptr(),
-                      dg.data_ptr(), db.data_ptr(), da.data_ptr(), vdt, C, y.data_ptr(), vdt, C, 1, dy.data_ptr(), vdt, C, st)
-        else:
-            _lib.call("vn_bn_bwd_finalize_slab", bslab.data_ptr(), rows, M, C, gamma.data_ptr(), stats.data_ptr(), coef.data_ptr(),
-                      dg.data_ptr(), db.data_ptr(), st)
-            _lib.call("vn_bn_bwd_apply", da.data_ptr(), vdt, C, y.data_ptr(), vdt, C, M, C, stats.data_ptr(), coef.data_ptr(), 1,
-                      dy.data_ptr(), vdt, C, 0, st)
-        torch.cuda.synchronize()
-        return coef, dg, db, dy
-
-    b0, b1 = backward(False), backward(True)
-    for name, u, v in zip(("coef", "d_gamma", "d_beta", "dy"), b0, b1):
-        assert torch.equal(u.view(torch.int16 if u.dtype == torch.bfloat16 else torch.int32),
-                           v.view(torch.int16 if v.dtype == torch.bfloat16 else torch.int32)), name
-    assert torch.isfinite(b1[0]).all() and torch.isfinite(b1[3].float()).all()
 
 
 def test_fp32x3_conv3d_weight_gradient_through_hi_lo_copies():

@@ -36,44 +36,46 @@ def test_train_trajectory(golden, mode):
     g = golden("trajectory_tiny")
     steps = int(g["steps"])
     grid = traj_grid(g)
-    M.set_precision(mode)
-    m = M.RPN3D("Car")
-    m.load_state_dict(tr.make_state_dict("Car"))
-    m.feature_net._grid = replace(m.feature_net._grid, H=grid.H, W=grid.W)
-    m = m.to(DEV)
-    gen = TargetGenerator("Car", DEV, anchors=g["anchors"])
-    m.target_fn = lambda label, shape: gen(label)          # (the fixture's 24 x 24 anchor grid instead of the class default)
-    batches = []
-    for j in range(4):
-        feats, coords, nums = [], [], []
-        for i, cloud in enumerate(batch_clouds(g, j)):
-            f, c, n = voxelize_device(torch.from_numpy(cloud).to(DEV), grid, i, coord_cols=4)
-            feats.append(f); coords.append(c); nums.append(n)
-        assert [f.shape[0] for f in feats] == list(g[f"K{j}"])
-        labels = fixture_labels(g, j)
-        check_targets(g, j, *[t.cpu().numpy() for t in gen(labels)], tgt_rtol=1e-6)
-        batches.append(([f"b{j}s0", f"b{j}s1"], labels, feats, nums, coords, None, None))
-    opt = ClipSGD(m.parameters(), lr=float(g["lr"]), max_norm=float(g["clip"]))
-    losses = []
-    for it in range(steps):
-        m.train(True)
-        out = m(batches[int(g["order"][it])], DEV)
-        out[2].backward()
-        total = opt.step()
-        opt.zero_grad()
-        scal = [float(v) for v in out[2:]]
-        if it == 0:
-            tol0 = {"fp32": 1e-4, "fp32x3": 5e-4}.get(mode, 2e-2)   # (fp32x3, round 4: three bf16 MFMAs per product, ~2^-16 each)
-            np.testing.assert_allclose(scal, g["scalars"][0], rtol=tol0, atol=1e-6)
-            # (the total gradient norm is a chained quantity: ReLU-mask flips move it by ~1e-3 in fp32, tests/test_gpu_model.py)
-            assert abs(float(total) - g["grad_norm"][0]) <= (0.2 if mode == "bf16" else 5e-3) * g["grad_norm"][0]
-        losses.append(scal[0])
-    torch.cuda.synchronize()
-    assert np.isfinite(losses).all()
-    floor, wm, mm = (3e-2, 2.0, 3.0) if mode == "bf16" else (1e-3, 2.0, 3.0)
-    check_trajectory(g, losses, floor, 3.0, f"HIP {mode}")
-    check_final_state(g, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, steps, f"HIP {mode}", wm, mm)
-    M.set_precision("bf16")
+    try:
+        M.set_precision(mode)
+        m = M.RPN3D("Car")
+        m.load_state_dict(tr.make_state_dict("Car"))
+        m.feature_net._grid = replace(m.feature_net._grid, H=grid.H, W=grid.W)
+        m = m.to(DEV)
+        gen = TargetGenerator("Car", DEV, anchors=g["anchors"])
+        m.target_fn = lambda label, shape: gen(label)          # (the fixture's 24 x 24 anchor grid instead of the class default)
+        batches = []
+        for j in range(4):
+            feats, coords, nums = [], [], []
+            for i, cloud in enumerate(batch_clouds(g, j)):
+                f, c, n = voxelize_device(torch.from_numpy(cloud).to(DEV), grid, i, coord_cols=4)
+                feats.append(f); coords.append(c); nums.append(n)
+            assert [f.shape[0] for f in feats] == list(g[f"K{j}"])
+            labels = fixture_labels(g, j)
+            check_targets(g, j, *[t.cpu().numpy() for t in gen(labels)], tgt_rtol=1e-6)
+            batches.append(([f"b{j}s0", f"b{j}s1"], labels, feats, nums, coords, None, None))
+        opt = ClipSGD(m.parameters(), lr=float(g["lr"]), max_norm=float(g["clip"]))
+        losses = []
+        for it in range(steps):
+            m.train(True)
+            out = m(batches[int(g["order"][it])], DEV)
+            out[2].backward()
+            total = opt.step()
+            opt.zero_grad()
+            scal = [float(v) for v in out[2:]]
+            if it == 0:
+                tol0 = {"fp32": 1e-4, "fp32x3": 5e-4}.get(mode, 2e-2)   # (fp32x3, round 4: three bf16 MFMAs per product, ~2^-16 each)
+                np.testing.assert_allclose(scal, g["scalars"][0], rtol=tol0, atol=1e-6)
+                # (the total gradient norm is a chained quantity: ReLU-mask flips move it by ~1e-3 in fp32, tests/test_gpu_model.py)
+                assert abs(float(total) - g["grad_norm"][0]) <= (0.2 if mode == "bf16" else 5e-3) * g["grad_norm"][0]
+            losses.append(scal[0])
+        torch.cuda.synchronize()
+        assert np.isfinite(losses).all()
+        floor, wm, mm = (3e-2, 2.0, 3.0) if mode == "bf16" else (1e-3, 2.0, 3.0)
+        check_trajectory(g, losses, floor, 3.0, f"HIP {mode}")
+        check_final_state(g, {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}, steps, f"HIP {mode}", wm, mm)
+    finally:
+        M.set_precision("bf16")        # (also on a failing assertion: the precision is process-global)
 
 
 @pytest.mark.parametrize("mode", ["fp32", "fp32x3", "bf16"])

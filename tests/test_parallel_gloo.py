@@ -116,9 +116,29 @@ def test_bench_pins_each_rank_to_its_own_slice_of_the_cores():
 def test_direct_rccl_is_refused_for_more_than_one_rank(monkeypatch):
     """the library's own RCCL wrapper has only ever run on a one-rank communicator: GradAllReducer(direct_rccl=True) must not
     become the path of a multi-GPU run silently (bench.py --direct-rccl raises the same way before any GPU work)"""
-    import re
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = open(os.path.join(root, "voxelnet-pytorch_amd", "voxelnet_amd", "parallel.py")).read()
-    assert re.search(r"self\.world > 1 and os\.environ\.get\(\"VN_DIRECT_RCCL_UNSAFE\"\) != \"1\"", src)
-    bsrc = open(os.path.join(root, "bench.py")).read()
-    assert "VN_DIRECT_RCCL_UNSAFE" in bsrc and "raise SystemExit" in bsrc
+    import torch
+    import torch.distributed as dist
+    from voxelnet_amd import _lib, parallel
+    from voxelnet_amd import model as M
+    named = [(n, p) for n, p in M.RPN3D("Car").named_parameters()]
+    # a fake two-rank world (no process group needed: the constructor only asks for the sizes)
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 2)
+    monkeypatch.setattr(dist, "get_rank", lambda group=None: 0)
+    monkeypatch.delenv("VN_DIRECT_RCCL_UNSAFE", raising=False)
+    monkeypatch.delenv("VN_DIRECT_RCCL", raising=False)
+    with pytest.raises(_lib.VoxelnetHipError, match="never run on two devices"):
+        parallel.GradAllReducer(named, direct_rccl=True)
+    monkeypatch.setenv("VN_DIRECT_RCCL", "1")                  # the environment default must be refused the same way
+    with pytest.raises(_lib.VoxelnetHipError, match="never run on two devices"):
+        parallel.GradAllReducer(named)
+    monkeypatch.delenv("VN_DIRECT_RCCL")
+    red = parallel.GradAllReducer(named)                      # the default path (torch.distributed) constructs
+    assert red.world == 2 and red.comm is None and len(red.buckets) == 5
+    monkeypatch.setenv("VN_DIRECT_RCCL_UNSAFE", "1")           # asked for by name: allowed (CPU parameters: no communicator made)
+    red = parallel.GradAllReducer(named, direct_rccl=True)
+    assert red.comm is None
+    # one world: nothing to refuse
+    monkeypatch.setattr(dist, "get_world_size", lambda group=None: 1)
+    monkeypatch.delenv("VN_DIRECT_RCCL_UNSAFE")
+    parallel.GradAllReducer(named, direct_rccl=True)

@@ -42,5 +42,11 @@ out = {"family": "k_conv_patch + k_gather_gemm (+ the two row-list launches)", "
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python3 bench.py --steps 3 --warmup 2 "
                  "--no-cpu-baseline --no-kernel-timer`; FETCH_SIZE x2 (gfx950 correction)"}
 out.update(others)
+# which library build these passes profiled (bench.py only reports `traffic` when it is the build that is running)
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "voxelnet-pytorch_amd")]
+from voxelnet_amd import _lib
+out["library_build_id"] = _lib.load().vn_build_id().decode()
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out, indent=1))

@@ -472,117 +472,6 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const void *__restrict__ d
     }
 }
 
-// ---- BatchNorm backward of the three deconvs WITHOUT the 768-channel concat gradient (model.py:272-281 backward): the
-// gradient w.r.t. a deconv's activation is d_rows (M,16) . W_heads[:, c] — sixteen products per channel of values the
-// pass can form itself from 32 B of d_rows per row, instead of reading back the (M,768) tensor vn_heads_dgrad wrote (108 MB
-// at the car size, read twice).  d_rows = [d_prob p (1-p) | d_reg]: the fourteen regression columns are zero at every site
-// without a positive anchor, so all but a few rows cost two FMAs per channel (the test is wave-divergent only there).
-// da is the fp32 FMA chain over k = 0..15 of the bf16 operands (never rounded to bf16 as the stored tensor was).
-struct HeadsDa {
-    const bf16_t *drows;      // [M][dstride] bf16, 16 used
-    int64_t dstride;
-    const bf16_t *wd;         // packed data-gradient weights [768][16] bf16 (vn_pack_weight mode 1), row = concat channel
-};
-__device__ __forceinline__ float bf_lo(uint32_t w) { return __builtin_bit_cast(float, w << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xffff0000u); }
-// the thread's eight channels c0 .. c0+7 of row m; w01[e][0/1] = W[c0+e][0/1]
-__device__ __forceinline__ void heads_da8(const HeadsDa &h, int64_t m, int c0, const float (&w01)[8][2], float (&dv)[8]) {
-    const uint4 g0 = *reinterpret_cast<const uint4 *>(h.drows + m * h.dstride);
-    const uint4 g1 = *reinterpret_cast<const uint4 *>(h.drows + m * h.dstride + 8);
-    const float k0 = bf_lo(g0.x), k1 = bf_hi(g0.x);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dv[e] = fmaf(k1, w01[e][1], k0 * w01[e][0]);
-    const uint32_t rest = (g0.y | g0.z | g0.w | g1.x | g1.y | g1.z | g1.w) & 0x7fff7fffu;
-    if (rest) {      // a site with regression gradients (positive anchors): the other fourteen terms
-        const uint32_t gw[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint4 wa = *reinterpret_cast<const uint4 *>(h.wd + (int64_t)(c0 + e) * 16);
-            const uint4 wb = *reinterpret_cast<const uint4 *>(h.wd + (int64_t)(c0 + e) * 16 + 8);
-            const uint32_t ww[8] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w};
-            float a = dv[e];
-#pragma unroll
-            for (int q = 1; q < 8; ++q) {
-                a = fmaf(bf_lo(gw[q]), bf_lo(ww[q]), a);
-                a = fmaf(bf_hi(gw[q]), bf_hi(ww[q]), a);
-            }
-            dv[e] = a;
-        }
-    }
-}
-__device__ __forceinline__ void heads_w01(const HeadsDa &h, int c0, float (&w01)[8][2]) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const uint32_t w = *reinterpret_cast<const uint32_t *>(h.wd + (int64_t)(c0 + e) * 16);
-        w01[e][0] = bf_lo(w); w01[e][1] = bf_hi(w);
-    }
-}
-
-// k_bn_bwd_reduce<false> with da from heads_da8 (one row per lane and iteration: the d_rows loads are L1 broadcasts)
-__global__ void __launch_bounds__(256) k_bn_bwd_reduce_heads(const HeadsDa h, int c_base, const void *__restrict__ y, int ydt,
-                                                             int64_t ystride, int64_t M, int C, const float *__restrict__ stats,
-                                                             int relu, float *__restrict__ slab) {
-    VN_PRIO_MAIN();
-    const int groups = C >> 3, rpb = 256 / groups;
-    const int g = threadIdx.x % groups, rr = threadIdx.x / groups;
-    float mean[8], invstd[8], S[8], be[8], w01[8][2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int c = g * 8 + j;
-        mean[j] = stats[c]; invstd[j] = stats[C + c]; S[j] = stats[2 * C + c]; be[j] = stats[3 * C + c];
-    }
-    heads_w01(h, c_base + g * 8, w01);
-    float s1[8] = {0}, s2[8] = {0};
-    if (rr < rpb) {
-        const int64_t step = (int64_t)gridDim.x * rpb;
-        for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += step) {
-            float yv[8], dv[8];
-            load8(y, ydt, m * ystride + g * 8, yv);
-            heads_da8(h, m, c_base + g * 8, w01, dv);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d0 = yv[j] - mean[j];
-                const float z = fmaf(S[j], d0, be[j]);
-                const float dz = (!relu || z > 0.f) ? dv[j] : 0.f;
-                s1[j] += dz;
-                s2[j] += dz * (d0 * invstd[j]);
-            }
-        }
-    }
-    block_reduce_slab(s1, s2, groups, rpb, C, slab + (size_t)blockIdx.x * 2 * C);
-}
-
-// k_bn_bwd_apply with da from heads_da8
-__global__ void __launch_bounds__(256) k_bn_bwd_apply_heads(const HeadsDa h, int c_base, const void *__restrict__ y, int ydt,
-                                                            int64_t ystride, int64_t M, int C, const float *__restrict__ stats,
-                                                            const float *__restrict__ coef, int relu, void *__restrict__ dy,
-                                                            int dydt, int64_t dystride) {
-    VN_PRIO_MAIN();
-    const int groups = C >> 3, rpb = 256 / groups;
-    const int c = (threadIdx.x % groups) << 3, rr = threadIdx.x / groups;
-    if (rr >= rpb) return;
-    float mean[8], S[8], be[8], c0[8], c1[8], c2[8], w01[8][2];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        mean[j] = stats[c + j]; S[j] = stats[2 * C + c + j]; be[j] = stats[3 * C + c + j];
-        c0[j] = coef[c + j]; c1[j] = coef[C + c + j]; c2[j] = coef[2 * C + c + j];
-    }
-    heads_w01(h, c_base + c, w01);
-    for (int64_t m = (int64_t)blockIdx.x * rpb + rr; m < M; m += (int64_t)gridDim.x * rpb) {
-        float yv[8], dv[8], o[8];
-        load8(y, ydt, m * ystride + c, yv);
-        heads_da8(h, m, c_base + c, w01, dv);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float d0 = yv[j] - mean[j];
-            const float z = fmaf(S[j], d0, be[j]);
-            const float dz = (!relu || z > 0.f) ? dv[j] : 0.f;
-            o[j] = fmaf(c0[j], dz, fmaf(c1[j], d0, c2[j]));
-        }
-        store8(dy, dydt, 0, m * dystride + c, o);
-    }
-}
-
 // dy = c0 dz + c1 (y - mean) + c2 at the rows of an explicit list only ((b,d,h,w) int64 coordinates of the dense
 // (B,D,H,W,C) tensors, *count valid entries): the first middle layer's gradient kernels read dy at its active sites only
 __global__ void __launch_bounds__(256) k_bn_bwd_apply_list(const void *__restrict__ da, int dadt, const void *__restrict__ y,
@@ -877,10 +766,6 @@ inline int apply_epl(int64_t total) {
     const int64_t r = total / (256 * 2048);
     return r < 1 ? 1 : (r > 4 ? 4 : (int)r);
 }
-inline int apply_hoist() {   // tuning aid VN_BN_HOIST: the plain forward apply keeps its per-channel constants in registers
-    static const int v = vn_knob("VN_BN_HOIST", 1);
-    return v;
-}
 inline bool rows_ok(int C, int64_t stride) { return C >= 8 && (C & 7) == 0 && C <= 2048 && (stride & 7) == 0; }
 
 }  // namespace
@@ -924,7 +809,7 @@ extern "C" int vn_bn_apply(const void *y, vnDtype y_dtype, int64_t y_stride, int
     VN_CHECK_ARG(y && a && stats);
     k_bn_apply<false><<<gs_blocks(M * (C >> 3), 256, 8192), 256, 0, vn_stream(stream)>>>(y, (int)y_dtype, y_stride, M, C, stats,
                                                                                           relu, a, (int)a_dtype, a_stride, lo_off, 0,
-                                                                                          nullptr, nullptr, apply_hoist());
+                                                                                          nullptr, nullptr, 1);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -972,37 +857,6 @@ extern "C" int vn_bn_bwd_reduce_slab(const void *da, vnDtype da_dtype, int64_t d
     k_bn_bwd_reduce<false><<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(da, (int)da_dtype, da_stride, y,
                                                                                  (int)y_dtype, y_stride, M, C, stats,
                                                                                  relu, nullptr, slab, 0, nullptr, nullptr);
-    VN_LAUNCH_STATUS();
-    return VN_OK;
-}
-
-// The two passes for a deconv under the heads (model.py:272-281 backward), da formed from d_rows and the heads' packed
-// data-gradient weights instead of read from the concat gradient: see HeadsDa.  c_base = the deconv's first concat channel.
-// Same grids, slab layout (vn_bn_bwd_slab_rows) and summation order as vn_bn_bwd_reduce_slab / vn_bn_bwd_apply.
-extern "C" int vn_bn_bwd_reduce_slab_heads(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, int32_t c_base,
-                                           const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C,
-                                           const float *stats, int32_t relu, float *slab, vnStream stream) {
-    VN_CHECK_ARG(slab && M > 0 && rows_ok(C, y_stride) && d_rows && w_packed_dgrad && y && stats && d_rows_stride >= 16 &&
-                 (d_rows_stride & 7) == 0 && c_base >= 0 && (c_base & 7) == 0 && c_base + C <= 768 && 256 % (C >> 3) == 0);
-    if ((reinterpret_cast<uintptr_t>(d_rows) & 15) || (reinterpret_cast<uintptr_t>(w_packed_dgrad) & 15)) return VN_EUNSUPPORTED;
-    const int rpb = 256 / (C >> 3);
-    const HeadsDa h{static_cast<const bf16_t *>(d_rows), d_rows_stride, static_cast<const bf16_t *>(w_packed_dgrad)};
-    k_bn_bwd_reduce_heads<<<gs_blocks(M, rpb * bwd_rpl(M, rpb), 2048), 256, 0, vn_stream(stream)>>>(h, c_base, y, (int)y_dtype, y_stride,
-                                                                                             M, C, stats, relu, slab);
-    VN_LAUNCH_STATUS();
-    return VN_OK;
-}
-extern "C" int vn_bn_bwd_apply_heads(const void *d_rows, int64_t d_rows_stride, const void *w_packed_dgrad, int32_t c_base,
-                                     const void *y, vnDtype y_dtype, int64_t y_stride, int64_t M, int32_t C, const float *stats,
-                                     const float *coef, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
-                                     vnStream stream) {
-    VN_CHECK_ARG(M > 0 && rows_ok(C, y_stride) && d_rows && w_packed_dgrad && y && stats && coef && dy && d_rows_stride >= 16 &&
-                 (d_rows_stride & 7) == 0 && (dy_stride & 7) == 0 && c_base >= 0 && (c_base & 7) == 0 && c_base + C <= 768 &&
-                 256 % (C >> 3) == 0);
-    if ((reinterpret_cast<uintptr_t>(d_rows) & 15) || (reinterpret_cast<uintptr_t>(w_packed_dgrad) & 15)) return VN_EUNSUPPORTED;
-    const HeadsDa h{static_cast<const bf16_t *>(d_rows), d_rows_stride, static_cast<const bf16_t *>(w_packed_dgrad)};
-    k_bn_bwd_apply_heads<<<gs_blocks(M * (C >> 3), 256 * apply_epl(M * (C >> 3)), 8192), 256, 0, vn_stream(stream)>>>(
-        h, c_base, y, (int)y_dtype, y_stride, M, C, stats, coef, relu, dy, (int)dy_dtype, dy_stride);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -1067,214 +921,6 @@ extern "C" int vn_bn_bwd_apply_flagged(const void *da, vnDtype da_dtype, int64_t
     k_bn_bwd_apply<<<gs_blocks(M * (C >> 3), 256 * apply_epl(M * (C >> 3)), 8192), 256, 0, vn_stream(stream)>>>(
         da, (int)da_dtype, da_stride, y, (int)y_dtype, y_stride, M, C, stats, coef, relu, dy, (int)dy_dtype, dy_stride, 0,
         row_flags, 0);
-    VN_LAUNCH_STATUS();
-    return VN_OK;
-}
-
-namespace {
-
-// ---------------------------------------------------------------------------------------------------------------
-// Finalize + apply as ONE launch (round 4), for the layers whose tensors are small enough that the two launches are
-// pure latency on the step's dependency chain (the 100 x 88 / 50 x 44 / 200 x 176 images: a finalize costs ~4.6 us of
-// step time for moving a few hundred KB, 46 times per step).  The two earlier fusions lost because every APPLY
-// workgroup (which owns whole rows = all channels) had to re-reduce the whole slab (160-300 KB each).  Here the work is
-// cut the other way: a workgroup owns ONE group of 8 channels x a range of rows.  Its part of the slab is 64 B per slab
-// row (9-35 KB in all), reduced exactly as k_bn_finalize_slab / k_bn_bwd_finalize_slab reduce a channel — thread t sums
-// rows t, t + 256, ... in double, xor-shuffle tree over the wave, the four waves as (w0 + w1) + (w2 + w3) — so the
-// statistics, the running statistics and the BatchNorm gradients are BIT-IDENTICAL to the two-launch path
-// (tests/test_gpu_layers.py).  The apply then moves 16 B per row and lane.  Workgroup b = group * splits + split with
-// splits a multiple of 8: the workgroups that touch the same rows (the 16 B pieces of one 128-B line) have equal b mod 8
-// = one XCD under round-robin placement, so a line is fetched into ONE L2 (speed only; nothing depends on it).
-// Every workgroup computes the statistics of its channel group; the ones with split 0 store them.
-struct FinApply {
-    const float *slab; int32_t rows; int64_t M; int32_t C;
-    const float *shift, *gamma, *beta; float *running_mean, *running_var; float momentum, eps;   // forward
-    float *stats;                    // forward: written (split 0); backward: read
-    float *coef, *d_gamma, *d_beta;  // backward
-    const void *y; int32_t ydt; int64_t ystride;
-    const void *da; int32_t dadt; int64_t dastride;          // backward: gradient w.r.t. the activation
-    void *out; int32_t odt; int64_t ostride;                 // forward: a; backward: dy
-    int32_t relu, splits;
-};
-
-template <bool BWD>
-__global__ void __launch_bounds__(256) k_bn_fin_apply(const FinApply p) {
-    VN_PRIO_MAIN();
-    __shared__ double r1[4][8], r2[4][8];
-    __shared__ float cst[6][8];
-    const int split = blockIdx.x % p.splits, cg = blockIdx.x / p.splits;
-    const int c0 = cg << 3, C = p.C;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // per-channel parameters requested before the slab loop (one memory round trip less on a latency-bound launch)
-    float pa = 0.f, pb = 0.f, pc = 0.f, pd = 0.f, pe = 0.f;
-    if (threadIdx.x < 8) {
-        const int c = c0 + threadIdx.x;
-        if (BWD) { pa = p.stats[C + c]; pb = p.gamma[c]; }
-        else {
-            pa = p.shift ? p.shift[c] : 0.f; pb = p.gamma[c]; pc = p.beta[c];
-            if (p.running_mean) pd = p.running_mean[c];
-            if (p.running_var) pe = p.running_var[c];
-        }
-    }
-    // rows of this split, four in flight per lane; the FIRST round's loads are issued here, in front of the slab reduction
-    // (they do not depend on the statistics): their latency hides behind it
-    const int64_t per = (p.M + p.splits - 1) / p.splits;
-    const int64_t mb = (int64_t)split * per;
-    int64_t me = mb + per;
-    if (me > p.M) me = p.M;
-    constexpr int U = 4;
-    float yv[U][8], dv[U][8];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-        const int64_t mu = mb + threadIdx.x + u * 256;
-        if (mu < me) {
-            load8(p.y, p.ydt, mu * p.ystride + c0, yv[u]);
-            if (BWD) load8(p.da, p.dadt, mu * p.dastride + c0, dv[u]);
-        }
-    }
-    double s1[8], s2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { s1[j] = 0.0; s2[j] = 0.0; }
-    for (int r = threadIdx.x; r < p.rows; r += 256) {
-        const float *q = p.slab + ((size_t)r * 2) * C + c0;
-        const float4 a0 = *reinterpret_cast<const float4 *>(q), a1 = *reinterpret_cast<const float4 *>(q + 4);
-        const float4 b0 = *reinterpret_cast<const float4 *>(q + C), b1 = *reinterpret_cast<const float4 *>(q + C + 4);
-        s1[0] += (double)a0.x; s1[1] += (double)a0.y; s1[2] += (double)a0.z; s1[3] += (double)a0.w;
-        s1[4] += (double)a1.x; s1[5] += (double)a1.y; s1[6] += (double)a1.z; s1[7] += (double)a1.w;
-        s2[0] += (double)b0.x; s2[1] += (double)b0.y; s2[2] += (double)b0.z; s2[3] += (double)b0.w;
-        s2[4] += (double)b1.x; s2[5] += (double)b1.y; s2[6] += (double)b1.z; s2[7] += (double)b1.w;
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            s1[j] += __shfl_xor(s1[j], o, 64);
-            s2[j] += __shfl_xor(s2[j], o, 64);
-        }
-    if (lane == 0) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { r1[wave][j] = s1[j]; r2[wave][j] = s2[j]; }
-    }
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        const int j = threadIdx.x, c = c0 + j;
-        const double t1 = (r1[0][j] + r1[1][j]) + (r1[2][j] + r1[3][j]), t2 = (r2[0][j] + r2[1][j]) + (r2[2][j] + r2[3][j]);
-        const double n = (double)p.M;
-        if (BWD) {
-            const float invstd = pa, S = pb * invstd;
-            const float k0 = S, k1 = -S * invstd * (float)(t2 / n), k2 = -S * (float)(t1 / n);
-            cst[3][j] = k0; cst[4][j] = k1; cst[5][j] = k2;
-            cst[0][j] = p.stats[c]; cst[1][j] = p.stats[2 * C + c]; cst[2][j] = p.stats[3 * C + c];
-            if (split == 0) {
-                if (p.d_gamma) p.d_gamma[c] = (float)t2;
-                if (p.d_beta) p.d_beta[c] = (float)t1;
-                p.coef[c] = k0; p.coef[C + c] = k1; p.coef[2 * C + c] = k2;
-            }
-        } else {
-            const double ms = t1 / n;
-            double var = t2 / n - ms * ms;
-            if (var < 0.0) var = 0.0;
-            const double mean = ms + (double)pa;
-            const float invstd = (float)(1.0 / sqrt(var + (double)p.eps));
-            cst[0][j] = (float)mean; cst[1][j] = pb * invstd; cst[2][j] = pc;
-            if (split == 0) {
-                if (p.running_mean) p.running_mean[c] = (float)((1.0 - p.momentum) * pd + p.momentum * mean);
-                if (p.running_var) {
-                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-                    p.running_var[c] = (float)((1.0 - p.momentum) * pe + p.momentum * unb);
-                }
-                p.stats[c] = (float)mean; p.stats[C + c] = invstd; p.stats[2 * C + c] = pb * invstd; p.stats[3 * C + c] = pc;
-            }
-        }
-    }
-    __syncthreads();
-    float mean[8], S[8], be[8], k0[8], k1[8], k2[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        mean[j] = cst[0][j]; S[j] = cst[1][j]; be[j] = cst[2][j];
-        k0[j] = BWD ? cst[3][j] : 0.f; k1[j] = BWD ? cst[4][j] : 0.f; k2[j] = BWD ? cst[5][j] : 0.f;
-    }
-    const int relu = p.relu;
-    for (int64_t m = mb + threadIdx.x; m < me; m += 256 * U) {
-        if (m != mb + threadIdx.x) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int64_t mu = m + u * 256;
-                if (mu < me) {
-                    load8(p.y, p.ydt, mu * p.ystride + c0, yv[u]);
-                    if (BWD) load8(p.da, p.dadt, mu * p.dastride + c0, dv[u]);
-                }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int64_t mu = m + u * 256;
-            if (mu >= me) continue;
-            float o[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float d0 = yv[u][j] - mean[j];
-                const float z = fmaf(S[j], d0, be[j]);
-                if (BWD) {
-                    const float dz = (!relu || z > 0.f) ? dv[u][j] : 0.f;
-                    o[j] = fmaf(k0[j], dz, fmaf(k1[j], d0, k2[j]));
-                } else {
-                    o[j] = (relu & 1) ? fmaxf(z, 0.f) : z;
-                    if (relu & 2) o[j] = (float)(bf16_t)o[j];
-                }
-            }
-            store8(p.out, p.odt, 0, mu * p.ostride + c0, o);
-        }
-    }
-}
-
-inline int fin_apply_splits(int64_t M, int groups) {
-    // ~256 workgroups, at least 512 rows per workgroup, a multiple of 8 (see the XCD note above)
-    int64_t s = 256 / groups;
-    if (s > M / 512) s = M / 512;
-    s = (s + 7) / 8 * 8;
-    if (s < 8) s = 8;
-    return (int)s;
-}
-
-}  // namespace
-
-// vn_bn_finalize_slab + vn_bn_apply in one launch (same stats, running statistics and activation bits).
-extern "C" int vn_bn_finalize_apply_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *shift,
-                                         const float *gamma, const float *beta, float *running_mean, float *running_var,
-                                         float momentum, float eps, float *stats, const void *y, vnDtype y_dtype,
-                                         int64_t y_stride, int32_t relu, void *a, vnDtype a_dtype, int64_t a_stride,
-                                         vnStream stream) {
-    VN_CHECK_ARG(slab && gamma && beta && stats && y && a && slab_rows > 0 && slab_rows < (1ll << 31) && M > 0);
-    VN_CHECK_ARG(rows_ok(C, y_stride) && (a_stride & 7) == 0 && !(reinterpret_cast<uintptr_t>(slab) & 15) && (C & 3) == 0);
-    FinApply p{};
-    p.slab = slab; p.rows = (int32_t)slab_rows; p.M = M; p.C = C;
-    p.shift = shift; p.gamma = gamma; p.beta = beta; p.running_mean = running_mean; p.running_var = running_var;
-    p.momentum = momentum; p.eps = eps; p.stats = stats;
-    p.y = y; p.ydt = (int)y_dtype; p.ystride = y_stride;
-    p.out = a; p.odt = (int)a_dtype; p.ostride = a_stride;
-    p.relu = relu; p.splits = fin_apply_splits(M, C >> 3);
-    k_bn_fin_apply<false><<<(unsigned)((C >> 3) * p.splits), 256, 0, vn_stream(stream)>>>(p);
-    VN_LAUNCH_STATUS();
-    return VN_OK;
-}
-
-// vn_bn_bwd_finalize_slab + vn_bn_bwd_apply in one launch (same coef, d_gamma, d_beta and dy bits).
-extern "C" int vn_bn_bwd_finalize_apply_slab(const float *slab, int64_t slab_rows, int64_t M, int32_t C, const float *gamma,
-                                             const float *stats, float *coef, float *d_gamma, float *d_beta, const void *da,
-                                             vnDtype da_dtype, int64_t da_stride, const void *y, vnDtype y_dtype,
-                                             int64_t y_stride, int32_t relu, void *dy, vnDtype dy_dtype, int64_t dy_stride,
-                                             vnStream stream) {
-    VN_CHECK_ARG(slab && gamma && stats && coef && da && y && dy && slab_rows > 0 && slab_rows < (1ll << 31) && M > 0);
-    VN_CHECK_ARG(rows_ok(C, y_stride) && (da_stride & 7) == 0 && (dy_stride & 7) == 0 && !(reinterpret_cast<uintptr_t>(slab) & 15));
-    FinApply p{};
-    p.slab = slab; p.rows = (int32_t)slab_rows; p.M = M; p.C = C;
-    p.gamma = gamma; p.stats = const_cast<float *>(stats); p.coef = coef; p.d_gamma = d_gamma; p.d_beta = d_beta;
-    p.y = y; p.ydt = (int)y_dtype; p.ystride = y_stride;
-    p.da = da; p.dadt = (int)da_dtype; p.dastride = da_stride;
-    p.out = dy; p.odt = (int)dy_dtype; p.ostride = dy_stride;
-    p.relu = relu; p.splits = fin_apply_splits(M, C >> 3);
-    k_bn_fin_apply<true><<<(unsigned)((C >> 3) * p.splits), 256, 0, vn_stream(stream)>>>(p);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

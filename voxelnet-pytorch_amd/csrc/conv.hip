@@ -65,7 +65,6 @@ struct GGParams {
     int32_t x3;                 // fp32 storage, products as three bf16 MFMAs (VN_F32X3): the F32 kernels' alternative inner loop;
                                 // 2 = the packed weights hold hi / lo bf16 granules (Cs % 32 == 0), 1 = fp32 weights split in registers,
                                 // 3 = as 2 and the SOURCE rows are stored split as well (VN_F32X3S: no split pass at all)
-    int32_t kc_rot;             // k_conv_patch2d: workgroups start their K-chunk loop at chunk (tile mod nk) — tuning aid VN_P2D_ROT
     uint32_t w_bytes;
     int64_t src_batch_extent;   // elements spanned by one batch item (for num_records)
     // row-list mode (sparse first Conv3d): rows are an explicit list of (b,d,h,w) coordinates
@@ -402,10 +401,10 @@ __global__ void __launch_bounds__(256, 2) k_gather_gemm(const GGParams p) {
         c.tapbits = (1u << tp.id) | (16u << tp.ih) | (256u << tp.iw);
         const int64_t de = (int64_t)cl.offD[tp.id] * p.sD + (int64_t)cl.offH[tp.ih] * p.sH +
                            (int64_t)cl.offW[tp.iw] * p.sW;
-        // this lane's K position inside the step; split rows wrap (k >= 2C reads the hi part again)
+        // this lane's K position inside the step
         const int k_lane = kc * BKE + a_chunk * EPC;
         c.k_ok = live && k_lane < p.Cs;
-        const int k_src = (p.src_wrap > 0 && k_lane >= p.src_wrap) ? k_lane - p.src_wrap : k_lane;
+        const int k_src = k_lane;
         c.a_off = (uint32_t)(int32_t)(de * ESZ) + (uint32_t)k_src * (uint32_t)ESZ;
         c.b_koff = (uint32_t)k_lane * (uint32_t)ESZ;
         c.b_soff = __builtin_amdgcn_readfirstlane((uint32_t)((int64_t)tp.widx * p.N * p.Cs * ESZ));
@@ -684,7 +683,7 @@ __global__ void __launch_bounds__(256, 2) k_conv_patch(const GGParams p) {
     auto stage_patch = [&](int sd, int kc) {
         const int k_lane = kc * BKE + k_lane0;
         const bool k_ok = k_lane < p.Cs;
-        const int k_src = (p.src_wrap > 0 && k_lane >= p.src_wrap) ? k_lane - p.src_wrap : k_lane;
+        const int k_src = k_lane;
         const uint32_t off = (uint32_t)(((int64_t)sd * p.sD + k_src) * ESZ);
 #pragma unroll
         for (int i = 0; i < PA; ++i)
@@ -912,7 +911,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
     auto stage_patch = [&](int sd, int kc, char *patch) {
         const int k_lane = kc * BKE + k_lane0;
         const bool k_ok = k_lane < p.Cs;
-        const int k_src = (p.src_wrap > 0 && k_lane >= p.src_wrap) ? k_lane - p.src_wrap : k_lane;
+        const int k_src = k_lane;
         const uint32_t off = (uint32_t)(((int64_t)sd * p.sD + k_src) * ESZ);
 #pragma unroll
         for (int i = 0; i < PA; ++i)
@@ -930,11 +929,7 @@ __global__ void __launch_bounds__(64 * WM * WN, WM * WN == 4 ? 2 : 1) k_conv_pat
     const int sd = qd * p.mulD + cl.offD[0];
     const int total = ((unsigned)sd < (unsigned)p.Ds) ? nk * 9 : 0;
     const int wbase = wbase_of(0);
-    // (p.kc_rot: neighbouring workgroups walk the K chunks from different starting points, so the 140-280 workgroups of a
-    //  launch — which otherwise all request the SAME 16-KB weight tile at the same moment, 36 times — spread over nk tiles;
-    //  the accumulation order of a tile then depends on its position, still fixed run to run)
-    const int rot = p.kc_rot ? tile % nk : 0;
-    auto kc_of = [&](int kc) { const int k = kc + rot; return k >= nk ? k - nk : k; };
+    auto kc_of = [&](int kc) { return kc; };
     auto stage_step = [&](int s) {
         const int kc = s / 9;
         stage_b(wbase, s - kc * 9, kc_of(kc), s % NSB);
@@ -1150,11 +1145,7 @@ PatchCfg patch_config(const vnConv *g) {
     }
     // 64-channel Conv3d layers: 6 x 32 pixels (patch 35 KB + 2 weight stages = 51 KB: THREE workgroups per CU; measured
     // 1340 vs 1183 TFLOP/s on middle_layer.2 against 8 x 32 pixels / two workgroups per CU)
-    static const int p1_rows = vn_knob("VN_PATCH_P1", 192);   // tuning aid
-    if (g->Cr == 64) return p1_rows == 192 ? PatchCfg{3, 192, 64, 32} : PatchCfg{1, 256, 64, 32};
-    static const int p0_rows = vn_knob("VN_PATCH_P0", 160);   // tuning aid
-    if (p0_rows == 96) return PatchCfg{4, 96, 128, 16};      // 6 x 16 pixels, three workgroups per CU
-    if (p0_rows == 128) return PatchCfg{5, 128, 128, 16};    // 8 x 16 pixels
+    if (g->Cr == 64) return PatchCfg{3, 192, 64, 32};
     return PatchCfg{0, 160, 128, 16};                        // 10 x 16 pixels
 }
 int64_t patch_tiles(const PatchCfg &c, int B, int qD, int qH, int qW) {
@@ -1187,22 +1178,16 @@ int patch2d_stages() {   // VN_PATCH2D=0: the two-stage kernel for the small ima
 }
 int launch_patch_cfg(const PatchCfg &c, bool f32, const GGParams &p, dim3 grid, hipStream_t st) {
     if (c.id == 2 && p.Ds == 1 && p.nclasses == 1 && p.cls[0].nD == 1 && patch2d_stages() >= 3) {
-        static const int rot = vn_knob("VN_P2D_ROT", 0);
-        GGParams q = p;
-        q.kc_rot = rot;
-        // eight waves (4 x 2 of 16 x 64) for the bf16 kernels; tuning aid VN_PATCH2D_WAVES=4: the four-wave kernel of round 2
-        static const int waves = vn_knob("VN_PATCH2D_WAVES", 8);
-        if (patch2d_stages() == 3 && waves == 8 && !f32) return launch_patch2d<4, 2, 1, 16, 3, false>(q, grid, st);
+        const GGParams &q = p;
+        // eight waves (4 x 2 of 16 x 64) for the bf16 kernels (the four-wave kernel of round 2 stays for the exact fp32 path)
+        if (patch2d_stages() == 3 && !f32) return launch_patch2d<4, 2, 1, 16, 3, false>(q, grid, st);
         // fp32x3: with the splits out of the tap loop its steps look like the bf16 kernel's (DMA issue, fragment reads, 24 bf16
         // MFMAs per 16 x 64 sub-tile) — the same eight-wave arrangement; the exact fp32 path (128 fp32 MFMAs per step) keeps four
-        if (patch2d_stages() == 3 && waves == 8 && f32 && q.x3) return launch_patch2d<4, 2, 1, 16, 3, true>(q, grid, st);
+        if (patch2d_stages() == 3 && f32 && q.x3) return launch_patch2d<4, 2, 1, 16, 3, true>(q, grid, st);
         if (patch2d_stages() == 3)
             return f32 ? launch_patch2d<2, 2, 2, 16, 3, true>(q, grid, st) : launch_patch2d<2, 2, 2, 16, 3, false>(q, grid, st);
         return f32 ? launch_patch2d<2, 2, 2, 16, 4, true>(q, grid, st) : launch_patch2d<2, 2, 2, 16, 4, false>(q, grid, st);
     }
-    if (c.id == 1) return f32 ? launch_patch<4, 1, 4, 32, true>(p, grid, st) : launch_patch<4, 1, 4, 32, false>(p, grid, st);
-    if (c.id == 4) return f32 ? launch_patch<2, 2, 3, 16, true>(p, grid, st) : launch_patch<2, 2, 3, 16, false>(p, grid, st);
-    if (c.id == 5) return f32 ? launch_patch<2, 2, 4, 16, true>(p, grid, st) : launch_patch<2, 2, 4, 16, false>(p, grid, st);
     if (c.id == 3) return f32 ? launch_patch<4, 1, 3, 32, true>(p, grid, st) : launch_patch<4, 1, 3, 32, false>(p, grid, st);
     if (c.id == 2) return f32 ? launch_patch<2, 2, 2, 16, true>(p, grid, st) : launch_patch<2, 2, 2, 16, false>(p, grid, st);
     return f32 ? launch_patch<2, 2, 5, 16, true>(p, grid, st) : launch_patch<2, 2, 5, 16, false>(p, grid, st);
@@ -1321,9 +1306,8 @@ extern "C" int vn_conv_gather_gemm_rows(const void *src, const void *w_packed, c
                 p.taps[ntap++] = GGTap{i, j, k, (sd.tap[i] * g->kH + sh.tap[j]) * g->kW + sw.tap[k]};
     c.ntaps = ntap;
     p.nclasses = 1;
-    // capacity launch: rows are not known on the host.  (tuning aid VN_GG_ROWS_CONFIG: one configuration for every list launch)
-    static const int rows_force = vn_knob("VN_GG_ROWS_CONFIG", -1);
-    const GGConfig cfg = rows_force >= 0 && rows_force < 5 ? GG_CFG[rows_force] : (g->Cr > 64 ? GG_CFG[1] : GG_CFG[0]);
+    // capacity launch: rows are not known on the host
+    const GGConfig cfg = g->Cr > 64 ? GG_CFG[1] : GG_CFG[0];
     const int64_t tiles_m = vn_ceil_div(row_cap, cfg.BM), tiles_n = vn_ceil_div(g->Cr, cfg.BN);
     const dim3 grid((unsigned)(tiles_m * tiles_n), 1);
     hipStream_t st = vn_stream(stream);
@@ -1405,7 +1389,7 @@ static int gather_gemm_impl(const void *src, const void *w_packed, const float *
     const int esz = f32 ? 4 : 2, bke = 128 / esz, align_e = 16 / esz;
     (void)bke;
     if (g->Cs <= 0 || (g->Cs % align_e) || g->Cr <= 0 || (g->Cr & 3)) return VN_EUNSUPPORTED;
-    if (g->src_wrap < 0 || (g->src_wrap % align_e) || (g->src_wrap > 0 && (g->src_wrap >= g->Cs || f32))) return VN_EUNSUPPORTED;
+    if (g->src_wrap != 0) return VN_EUNSUPPORTED;      // (K wrap of [hi|lo] sources: the retired bf16x3 mode, round 5)
     if (g->divD * g->divH * g->divW > GG_MAX_CLASSES) return VN_EUNSUPPORTED;
     if (((g->src_sB | g->src_sD | g->src_sH | g->src_sW) & (align_e - 1)) != 0) return VN_EUNSUPPORTED;   // 16-B chunks
     if (((g->out_sB | g->out_sD | g->out_sH | g->out_sW) & 3) != 0) return VN_EUNSUPPORTED;      // 8/16-B stores

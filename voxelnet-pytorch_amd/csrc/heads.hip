@@ -167,8 +167,8 @@ extern "C" int vn_heads_fwd(const void *cat_rows, int64_t cat_stride, const void
         return VN_EUNSUPPORTED;
     const int64_t groups = ((int64_t)B * S + 15) >> 4;
     int64_t blocks = (groups + 3) / 4;
-    // (every wave loads the 24 KB of weights first: few, long-lived waves — VN_HEADS_BLOCKS, default two workgroups per CU)
-    static const int cap = vn_knob("VN_HEADS_BLOCKS", 512);
+    // (every wave loads the 24 KB of weights first: few, long-lived waves — two workgroups per CU)
+    const int cap = 512;
     if (blocks > cap) blocks = cap;
     k_heads_fwd<<<(unsigned)blocks, 256, 0, vn_stream(stream)>>>(static_cast<const bf16_t *>(cat_rows), cat_stride,
                                                                  static_cast<const bf16_t *>(w_packed), bias, B, S, prob, reg);

@@ -447,7 +447,8 @@ inline unsigned gs_blocks(int64_t total, int per_block = 256, int cap = 8192) {
 extern "C" int vn_pack_weight(const float *w, int32_t c_out, int32_t c_in, int32_t taps, int32_t mode, int32_t split3,
                               int32_t cin_fold, void *packed, vnDtype packed_dtype, vnStream stream) {
     VN_CHECK_ARG(w && packed && c_out > 0 && c_in > 0 && taps > 0 && mode >= 0 && mode <= 3);
-    VN_CHECK_ARG(packed_dtype == VN_BF16 || ((packed_dtype == VN_F32 || packed_dtype == VN_F32X3) && !split3));
+    VN_CHECK_ARG(packed_dtype == VN_BF16 || packed_dtype == VN_F32 || packed_dtype == VN_F32X3);
+    if (split3) return VN_EUNSUPPORTED;      // ([hi;hi;lo] K expansion of the retired bf16x3 mode: round 5)
     VN_CHECK_ARG(cin_fold >= 1 && c_in % cin_fold == 0);
     const int64_t total = (int64_t)taps * c_out * c_in * (split3 ? 3 : 1);
     const int K = (mode == 0 || mode == 2) ? c_in : c_out;
@@ -477,7 +478,8 @@ extern "C" int vn_pack_weights_batch(const vnPackJob *jobs, int32_t n, vnStream 
         for (int j = 0; j < t.n; ++j) {
             const vnPackJob &q = jobs[base + j];
             VN_CHECK_ARG(q.w && q.packed && q.c_out > 0 && q.c_in > 0 && q.taps > 0 && q.mode >= 0 && q.mode <= 3);
-            VN_CHECK_ARG(q.packed_dtype == VN_BF16 || ((q.packed_dtype == VN_F32 || q.packed_dtype == VN_F32X3) && !q.split3));
+            VN_CHECK_ARG(q.packed_dtype == VN_BF16 || q.packed_dtype == VN_F32 || q.packed_dtype == VN_F32X3);
+            if (q.split3) return VN_EUNSUPPORTED;      // (retired with the bf16x3 mode: round 5)
             VN_CHECK_ARG(q.cin_fold >= 1 && q.c_in % q.cin_fold == 0);
             const int64_t total = (int64_t)q.taps * q.c_out * q.c_in * (q.split3 ? 3 : 1);
             int64_t nb = vn_ceil_div(total, 256 * 8);          // 8 elements per thread

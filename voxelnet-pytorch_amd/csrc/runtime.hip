@@ -12,7 +12,6 @@
 // The per-layer call sequences are exactly those of voxelnet_amd/engine.py (the Python reference
 // orchestration, still used by the per-layer tests and the bf16x3 mode).
 #include "common.h"
-#include <functional>
 #include <new>
 #include <string.h>
 
@@ -170,7 +169,6 @@ vnConv x3_wgrad_geom(const Plan &P, int l, void *src_hl, void *rows_hl, int src_
     return geom(xs, P.odims[l], sp.cin, sp.cout, sp.k, sp.s, ONE, sp.p, ONE, rs);
 }
 int m0_bn_knob();
-int box_zero_total();
 int x3_split_store_on();
 bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     // depth: every D whose three Conv3d layers (model.py:207-209: stride 2 / pad 1, stride 1 / no pad, stride 2 / pad 1)
@@ -304,7 +302,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
                       // capacity K * 18 is the bound): the row-list launch re-gathers every tap, the dense kernel stages
                       // halo patches — at 160k voxels (BASELINE configs[4]) the dense route is 3 % faster
                       P->acap * 10 <= P->y[0].M() * 3;
-        P->sparse_w1 = P->list_bwd && (m0_bn_knob() & 16) && !box_zero_total();
+        P->sparse_w1 = P->list_bwd && (m0_bn_knob() & 16);
         P->drows = P->sparse_w1 ? A.take((size_t)P->acap * 64 * P->esz) : nullptr;
     }
     // ---- backward buffers
@@ -463,16 +461,13 @@ struct vnNet {
     // hidden state without a check let a stale first phase stand in for a later step's)
     const void *prep_ws, *prep_coord;
     int64_t prep_K;
-    int32_t prep_dims[4];
+    int32_t prep_dims[9];   // B, D, H, W + training, mode, block1_stride, sparse_first, grad_storage (round-4 advisor: a prepare
+                            // for an eval / other-mode step must not stand in for a training step on the same arena)
     // the data-gradient orientation of the packed weights is first read by the BACKWARD: vn_net_prepare leaves those jobs
     // here and vn_net_forward issues them on the side stream behind deconv2, beside block3's small images (CUs to spare)
     // instead of beside the first layers (where the launch cost 0.03 ms of step time)
     vnPackJob deferred_pack[NL + 1];
     int n_deferred;
-    // round 4: the weight gradients of independent layers run CONCURRENTLY, dealt over the caller's side stream and these
-    // extra streams of the context (tuning aid VN_WG_STREAMS = total number, 1 = the side stream alone); the 128 x 64
-    // nine-tap tile (k_wgrad_patch<2>) takes a quarter of the CUs per launch, so several of them fit beside the main chain
-    hipStream_t wg_stream[3];
     hipEvent_t ring[64];
     unsigned next;
     hipEvent_t next_event() { return ring[next++ & 63]; }
@@ -522,8 +517,6 @@ extern "C" int vn_net_destroy(vnNet *n) {
         if (n->ring[i]) (void)hipEventDestroy(n->ring[i]);
     for (int i = 0; i < 2; ++i)
         if (n->prep_ev[i]) (void)hipEventDestroy(n->prep_ev[i]);
-    for (int i = 0; i < 3; ++i)
-        if (n->wg_stream[i]) (void)hipStreamDestroy(n->wg_stream[i]);
     for (int i = 0; i < n->t_made; ++i) {
         (void)hipEventDestroy(n->slots[i].e0);
         (void)hipEventDestroy(n->slots[i].e1);
@@ -603,32 +596,8 @@ int heads_stream_on() {   // tuning aid VN_HEADS_STREAM=0: the heads through k_g
     static const int v = vn_knob("VN_HEADS_STREAM", 1);
     return v;
 }
-// tuning aid VN_HEADS_NOCAT=1 (bf16 step): the three deconvs' BatchNorm-backward passes form the gradient w.r.t. their
-// activation from d_rows (M,16) and the heads' packed weights themselves (vn_bn_bwd_*_heads) — the (M,768) concat gradient is
-// never written (vn_heads_dgrad: 24 us between the loss and the fork, 108 MB that the six passes read back).  Measured (round
-// 4): 558.9 against 558.0 point-clouds/s over three interleaved pairs — nothing — and da is no longer rounded to bf16, which
-// moves the chaotic 200-step bf16 trajectory of tests/test_gpu_trajectory.py outside its band at iterations 4-5: off
-int heads_nocat_on() {
-    static const int v = vn_knob("VN_HEADS_NOCAT", 0);
-    return v;
-}
 int fuse_bwd_reduce_on() {   // tuning aid VN_FUSE_BWD_REDUCE=0: every BatchNorm backward reduction as its own launch
     static const int v = vn_knob("VN_FUSE_BWD_REDUCE", 1);
-    return v;
-}
-// tuning aid VN_BOX_ZERO=1: take the sum of middle_layer.1's dy over all sites as zero (the BatchNorm identity) instead of
-// summing it (measured: 509.7 vs 508.7 point-clouds/s — not worth a shortcut that drops the rounding noise of dy)
-int box_zero_total() {
-    static const int v = vn_knob("VN_BOX_ZERO", 0);
-    return v;
-}
-// BatchNorm finalize + apply as one launch (vn_bn_finalize_apply_slab / vn_bn_bwd_finalize_apply_slab) on the layers with
-// at most VN_BN_FUSE_ROWS rows (tuning aid; default 0 = the two launches everywhere).  Bit-identical results, one launch
-// less per BatchNorm and direction — and no faster: round 4 measured the fused launch at >= 6.1 us on the 100 x 88 /
-// 50 x 44 layers against 2.2 + 2.4 us + one boundary for the pair (two dependent memory phases either way), 558 vs 561
-// point-clouds/s with the small layers fused, 527 with the 200 x 176 ones too (16-B pieces of every row per workgroup)
-int64_t bn_fuse_rows() {
-    static const int v = vn_knob("VN_BN_FUSE_ROWS", 0);
     return v;
 }
 int bn_apply_rows(const Rows &y, const float *stats, const Rows &a, int C, int relu, vnStream st) {
@@ -674,7 +643,7 @@ static int net_prepare(vnNet *net, const vnNetConfig *cfg, const Plan &P, const 
     // (event 0; heads_w unused), 2 only the rest (event 1; needs a phase 1 for the same workspace / coord / K / grid)
     const int phase = own_stream ? cfg->prepared : 0;
     if (phase < 0 || phase > 2 || (phase != 1 && !heads_w)) return VN_EINVAL;
-    const int32_t dims[4] = {cfg->B, cfg->D, cfg->H, cfg->W};
+    const int32_t dims[9] = {cfg->B, cfg->D, cfg->H, cfg->W, cfg->training, cfg->mode, cfg->block1_stride, cfg->sparse_first, cfg->grad_storage};
     const bool rest_only = phase == 2;
     if (rest_only && !(net->prep_first_done && net->prep_ws == P.wp_f[0] && net->prep_coord == coord && net->prep_K == K &&
                        !memcmp(net->prep_dims, dims, sizeof(dims)))) {
@@ -764,7 +733,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
     if (cfg->prepared && !net->prep_recorded) return VN_EINVAL;   // "prepared" without a vn_net_prepare on this context (or already consumed)
     const bool prep_wait = cfg->prepared != 0;
     if (prep_wait) {        // the prepared step must be THIS one: same arena, voxel coordinates, K and grid
-        const int32_t dims[4] = {cfg->B, cfg->D, cfg->H, cfg->W};
+        const int32_t dims[9] = {cfg->B, cfg->D, cfg->H, cfg->W, cfg->training, cfg->mode, cfg->block1_stride, cfg->sparse_first, cfg->grad_storage};
         if (net->prep_ws != P.wp_f[0] || net->prep_K != K || (cfg->sparse_first && net->prep_coord != coord) ||
             memcmp(net->prep_dims, dims, sizeof(dims))) {
             net->prep_recorded = false;
@@ -822,13 +791,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
                 vn_conv_gather_gemm(x.ptr, P.wp_f[l], L[l].bias, y.ptr, (vnDtype)y.dtype, cx(P, g), 0, slab, stream));
         }
         const Rows &a = P.a[l];
-        const bool fuse_fin = slab && M <= bn_fuse_rows() && l != L_M2 && !(l == 0 && cfg->sparse_first);
-        if (fuse_fin) {
-            RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y) + 8.0 * P.slab_rows[l] * sp.cout, stream,
-                vn_bn_finalize_apply_slab(slab, P.slab_rows[l], M, sp.cout, L[l].bias, L[l].gamma, L[l].beta, L[l].running_mean,
-                                          L[l].running_var, mom, eps, P.stats[l], y.ptr, (vnDtype)y.dtype, y.sW, relu_fl, a.ptr,
-                                          (vnDtype)a.dtype, a.sW, stream));
-        } else if (slab) {
+        if (slab) {
             RTT(T_BN_FINALIZE, l, 0.0, 8.0 * P.slab_rows[l] * sp.cout, stream,
                 vn_bn_finalize_slab(slab, P.slab_rows[l], M, sp.cout, L[l].bias, L[l].gamma, L[l].beta, L[l].running_mean,
                                     L[l].running_var, mom, eps, P.stats[l], stream));
@@ -838,9 +801,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
             RT(vn_bn_finalize(training ? P.fsums[l] : nullptr, M, sp.cout, 1, L[l].bias, L[l].gamma, L[l].beta,
                               L[l].running_mean, L[l].running_var, training, mom, eps, P.stats[l], stream));
         }
-        if (fuse_fin) {
-            // (applied by the finalize launch above)
-        } else if (l == L_M2) {   // BEV fold: channel d*64 + c of the (B,1,H,W,128) activation
+        if (l == L_M2) {   // BEV fold: channel d*64 + c of the (B,1,H,W,128) activation
             RTT(T_BN_APPLY, l, 0.0, 2.0 * rows_bytes(y), stream,
                 vn_bn_apply_bev(y.ptr, (vnDtype)y.dtype, M, 64, (int64_t)P.odims[l][1] * P.odims[l][2], P.stats[l], relu_fl, a.ptr,
                                 (vnDtype)a.dtype, 128, stream));
@@ -933,48 +894,15 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // data-gradient / BatchNorm-backward launches: fork when dy exists, join before the segment's unpack.
     hipStream_t ws = side_stream ? vn_stream(side_stream) : hs;
     const vnStream wstream = side_stream ? side_stream : stream;
-    hipEvent_t last_fork = nullptr;
     auto fork = [&]() -> int {
         if (ws == hs) return VN_OK;
         hipEvent_t e = net->next_event();
         if (!e) return VN_EINVAL;
         VN_HIP(hipEventRecord(e, hs));
         VN_HIP(hipStreamWaitEvent(ws, e, 0));
-        last_fork = e;
         return VN_OK;
     };
-    // extra weight-gradient streams (vnNet::wg_stream): a queued weight gradient goes to stream (counter mod n_wg), 0 = the
-    // side stream itself; the others wait for the fork event first and are joined into the side stream before anything
-    // there reads a partial slab (the unpacks)
-    static const int wg_streams_knob = vn_knob("VN_WG_STREAMS", 1);
-    const int n_wg = ws == hs ? 1 : (wg_streams_knob < 1 ? 1 : (wg_streams_knob > 4 ? 4 : wg_streams_knob));
-    for (int i = 0; i + 1 < n_wg; ++i)      // (created on first use: the default, one stream, never needs them)
-        if (!net->wg_stream[i]) VN_HIP(hipStreamCreateWithFlags(&net->wg_stream[i], hipStreamNonBlocking));
-    unsigned wg_rr = 0;
-    bool wg_used[3] = {false, false, false};
-    auto join_wg = [&]() -> int {
-        for (int i = 0; i < 3; ++i) {
-            if (!wg_used[i]) continue;
-            hipEvent_t e = net->next_event();
-            if (!e) return VN_EINVAL;
-            VN_HIP(hipEventRecord(e, net->wg_stream[i]));
-            VN_HIP(hipStreamWaitEvent(ws, e, 0));
-            wg_used[i] = false;
-        }
-        return VN_OK;
-    };
-    const bool nocat = !P.exact_heads && P.adt == VN_BF16 && P.cdt == VN_BF16 && heads_stream_on() && heads_nocat_on();
     bool heads_forked = false;     // the side stream already waits for the main stream's state after the heads
-    // tuning aid VN_WG_LATE (round 5, the one scheduling experiment of the bf16 step): bit 0 — no flush at the end of the
-    // block3 chain: the weight gradients of deconv3 + block3 wait for the flush behind block2.0 and run beside block1 (big
-    // images, MFMA / HBM-bound kernels that pay least for sharing CUs) instead of beside block2's latency-bound small-image
-    // launches; bit 1 — the heads' weight gradient and bias sums wait for that flush too.  (single-call backward without
-    // bucket events only: a bucket's group-final event needs its weight gradients.)
-    static const int wg_late = vn_knob("VN_WG_LATE", 0);
-    const bool wg_late_ok = side_stream && !cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
-    const bool wg_late_b3 = wg_late_ok && (wg_late & 1), wg_late_hold_heads = wg_late_ok && (wg_late & 2);
-    bool heads_pending = false;
-    std::function<int()> heads_side;
     // ---- heads
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
@@ -986,9 +914,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         vnConv gd = geom(P.d_rows, od, 16, 768, hs16.k, ONE, NEG, hs16.p, ONE, os);
         // the heads' weight gradient goes to the side stream behind ONE fork that also serves the early deconv
         // branches (which need the data gradient): one event record less on the main stream (483 vs 480 pc/s)
-        if (nocat) {
-            // (no concat gradient: do_layer(L_D1 / L_D2 / L_D3) reads d_rows and P.hwp_d)
-        } else if (P.exact_heads) {
+        if (P.exact_heads) {
             RTT(T_MISC, NL, 0.0, 0.0, stream, vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows32.ptr, VN_F32, 16, 0, stream));
             RTT(T_CONV_DGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows32) + rows_bytes(P.d_cat), stream,
                 vn_heads_dgrad_f32(reinterpret_cast<const float *>(P.d_rows32.ptr), P.d_rows32.sW, heads_w, P.d_cat.ptr,
@@ -1003,19 +929,12 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         heads_forked = true;
         // the heads' bias gradients (column sums of d_rows: two small launches) are nobody's input: behind the fork, on the
         // side stream (the main stream when there is none), not between the loss and the first data gradient
-        const int hjob = nu;
-        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, 1, (int64_t)16 * 768};
-        heads_side = [&, gw, hjob]() mutable -> int {
-            int32_t hch = 1;
-            RTT(T_MISC, NL, 0.0, 0.0, wstream,
-                vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, wstream));
-            RTT(T_WGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.cat), wstream,
-                vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, cx(P, gw), 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
-            unpack[hjob].chunks = hch;     // (the unpack that holds this job is issued behind this launch)
-            return VN_OK;
-        };
-        if (wg_late_hold_heads) heads_pending = true;
-        else RT(heads_side());
+        int32_t hch = 1;
+        RTT(T_MISC, NL, 0.0, 0.0, wstream,
+            vn_col_sums(P.d_rows.ptr, (vnDtype)P.adt, 16, B * S, 16, d_heads_b, P.hcs_ws, P.hcs_ws_bytes, wstream));
+        RTT(T_WGRAD, NL, 2.0 * B * S * 768 * 16, rows_bytes(P.d_rows) + rows_bytes(P.cat), wstream,
+            vn_conv_wgrad_partials(P.cat.ptr, P.d_rows.ptr, cx(P, gw), 0, nullptr, 0, P.hdwp, P.hdwp_bytes, &hch, wstream));
+        unpack[nu++] = vnUnpackJob{P.hdwp, d_heads_w, 16, 768, 1, 0, 1, hch, (int64_t)16 * 768};
     }
     auto cat_slice = [&](int off) {
         Rows r = P.d_cat;
@@ -1108,24 +1027,10 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // ~6 us bubble there: measured) and issues the queued ones on the side stream.  Flushed after every block chain.
     int pending[NL], npend = 0;
     auto flush = [&]() -> int {
-        if (npend == 0 && !heads_pending) return VN_OK;
+        if (npend == 0) return VN_OK;
         RT(fork());
-        if (heads_pending) {
-            heads_pending = false;
-            RT(heads_side());
-        }
         for (int i = 0; i < npend; ++i) {
-            const int l = pending[i];
-            // (layers 0 and 1 keep the side stream: their sparse routes are launch sequences with the box sums / unpack)
-            const unsigned k = (n_wg > 1 && l >= 2 && last_fork) ? (wg_rr++ % (unsigned)n_wg) : 0u;
-            if (k == 0) {
-                RT(launch_wgrad(l, wstream));
-            } else {
-                hipStream_t xs = net->wg_stream[k - 1];
-                VN_HIP(hipStreamWaitEvent(xs, last_fork, 0));
-                RT(launch_wgrad(l, reinterpret_cast<vnStream>(xs)));
-                wg_used[k - 1] = true;
-            }
+            RT(launch_wgrad(pending[i], wstream));
         }
         npend = 0;
         return VN_OK;
@@ -1135,11 +1040,9 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // So the FIRST layer's weight gradient runs on the main stream (behind its data gradient), and everything up to
     // block1 is unpacked on the side stream before it waits for middle_layer.2's dy (a ~180 us idle gap there): only
     // the three Conv3d gradients are left for the final unpack.
-    static const int m0_main_on = vn_knob("VN_M0_MAIN", 1);
-    static const int early_unpack_on = vn_knob("VN_EARLY_UNPACK", 1);
     const bool tail_balance = ws != hs && cfg->defer_join && !cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
     const bool bucket_mode = ws != hs && cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
-    const bool m0_on_main = (tail_balance || bucket_mode) && m0_main_on;
+    const bool m0_on_main = tail_balance || bucket_mode;
     int u_early = 0;
     hipEvent_t box_ev = nullptr;       // recorded on the side stream behind the box sums of middle_layer.1's dy
     int64_t fused_rows[NL] = {0};      // > 0: layer's BatchNorm-backward slab was written by the data gradient above it (rows)
@@ -1161,18 +1064,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         else if (l == L_D1 - 1) da = P.dx[L_B2];
         else da = P.dx[l + 1];
         const Rows &dy = P.dy[l];
-        if (nocat && (l == L_D1 || l == L_D2 || l == L_D3)) {   // da = d_rows . W_heads[:, slice], formed by the passes
-            const int cb = l == L_D3 ? 0 : (l == L_D2 ? 256 : 512);
-            RTT(T_BN_BWD_REDUCE, l, 0.0, rows_bytes(y) + rows_bytes(P.d_rows), ls,
-                vn_bn_bwd_reduce_slab_heads(P.d_rows.ptr, P.d_rows.sW, P.hwp_d, cb, y.ptr, (vnDtype)y.dtype, y.sW, M, C,
-                                            P.stats[l], 1, P.bslab[l], ls));
-            RTT(T_BN_FINALIZE, l, 0.0, 8.0 * P.bslab_rows[l] * C, ls,
-                vn_bn_bwd_finalize_slab(P.bslab[l], P.bslab_rows[l], M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
-                                        G[l].beta, ls));
-            RTT(T_BN_BWD_APPLY, l, 0.0, 2.0 * rows_bytes(y) + rows_bytes(P.d_rows), ls,
-                vn_bn_bwd_apply_heads(P.d_rows.ptr, P.d_rows.sW, P.hwp_d, cb, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
-                                      P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW, ls));
-        } else if (l == L_M2) {   // da is the BEV gradient (B,1,H,W,128): channel d*64+c
+        if (l == L_M2) {   // da is the BEV gradient (B,1,H,W,128): channel d*64+c
             const int64_t hw = (int64_t)P.odims[l][1] * P.odims[l][2];
             RTT(T_BN_BWD_REDUCE, l, 0.0, 2.0 * rows_bytes(y), ls,
                 vn_bn_bwd_reduce_slab_bev(da.ptr, (vnDtype)da.dtype, 128, y.ptr, (vnDtype)y.dtype, M, C, hw, P.stats[l], 1,
@@ -1209,19 +1101,10 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 vn_bn_bwd_reduce_slab(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l], 1,
                                       P.bslab[l], ls));
             const int64_t brows = fused_rows[l] > 0 ? fused_rows[l] : P.bslab_rows[l];
-            const bool fuse_fin = M <= bn_fuse_rows() && !(l == 0 && cfg->sparse_first);
-            if (fuse_fin)
-                RTT(T_BN_BWD_APPLY, l, 0.0, 3.0 * rows_bytes(y) + 8.0 * brows * C, ls,
-                    vn_bn_bwd_finalize_apply_slab(P.bslab[l], brows, M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
-                                                  G[l].beta, da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, 1,
-                                                  dy.ptr, (vnDtype)dy.dtype, dy.sW, ls));
-            else
             RTT(T_BN_FINALIZE, l, 0.0, 8.0 * brows * C, ls,
                 vn_bn_bwd_finalize_slab(P.bslab[l], brows, M, C, L[l].gamma, P.stats[l], P.coef[l], G[l].gamma,
                                         G[l].beta, ls));
-            if (fuse_fin) {
-                // (applied by the finalize launch above)
-            } else if (l == 0 && cfg->sparse_first && !(m0_bn_knob() & 4))
+            if (l == 0 && cfg->sparse_first && !(m0_bn_knob() & 4))
                 RTT(T_BN_BWD_APPLY, l, 0.0, 0.0, ls,
                     vn_bn_bwd_apply_flagged(da.ptr, (vnDtype)da.dtype, da.sW, y.ptr, (vnDtype)y.dtype, y.sW, M, C, P.stats[l],
                                             P.coef[l], 1, dy.ptr, (vnDtype)dy.dtype, dy.sW,
@@ -1240,18 +1123,8 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         zj.ptr[zj.n] = G[l].bias; zj.len[zj.n] = C; ++zj.n;          // bias before a train-mode BN: gradient exactly 0
         const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
         // weight gradient: at once when this layer runs on the side stream itself, else queued for the next flush
-        // (tuning aid VN_WG_EARLY, bit l: layer l's weight gradient is forked HERE, in front of its data gradient — it only
-        //  needs dy — instead of behind it with the next flush)
-        static const int wg_early = vn_knob("VN_WG_EARLY", 0);
-        const bool w_early = ws != hs && !on_side && single_call && l >= 1 && ((wg_early >> l) & 1);
         if (on_side) RT(launch_wgrad(l, wstream));
         else if (l == 0 && m0_on_main) RT(launch_wgrad(l, stream));
-        else if (w_early) {
-            const bool had = npend > 0;
-            RT(flush());               // (forks once if anything was queued: the same point of the main stream)
-            if (!had) RT(fork());
-            RT(launch_wgrad(l, wstream));
-        }
         else pending[npend++] = l;
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
@@ -1266,13 +1139,12 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             // sites only (a row-list launch into [acap][cin] rows) and its sum over all sites (box sums of dy)
             // (the box sums are only read by the first layer's finalize, ~120 us down this stream, and by the weight
             //  gradient's constant part on the side stream: with a side stream they run there, beside the row-list launch)
-            static const int box_side = vn_knob("VN_BOX_SIDE", 1);
-            const bool box_on_side = box_side && ws != hs && !on_side && single_call;
+            const bool box_on_side = ws != hs && !on_side && single_call;
             if (box_on_side) RT(fork());
             const vnStream bs = box_on_side ? wstream : ls;
-            RTT(T_MISC, l, 0.0, box_zero_total() ? 0.0 : rows_bytes(dy), bs,
+            RTT(T_MISC, l, 0.0, rows_bytes(dy), bs,
                 vn_dgrad_total(dy.ptr, (vnDtype)dy.dtype, B, P.odims[l][0], P.odims[l][1], P.odims[l][2], C, sp.cin, sp.k[0],
-                               L[l].weight, box_zero_total(), P.dtot_ws, P.dtot_ws_bytes, P.dtot, bs));
+                               L[l].weight, 0, P.dtot_ws, P.dtot_ws_bytes, P.dtot, bs));
             if (box_on_side) {
                 box_ev = net->next_event();
                 if (!box_ev) return VN_EINVAL;
@@ -1336,8 +1208,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     int u_done = 0, z_done = 0;
     auto bucket_done = [&](int b) -> int {
         RT(flush());
-        RT(join_wg());
-        if (b == 3 && m0_on_main) RT(fork());     // the first layer's partials come from the main stream
+            if (b == 3 && m0_on_main) RT(fork());     // the first layer's partials come from the main stream
         RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack + u_done, nu - u_done), wstream, vn_unpack_wgrads_batch(unpack + u_done, nu - u_done, wstream));
         RT(after_unpack(u_done, nu, wstream));
         u_done = nu;
@@ -1366,22 +1237,10 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             // gradients are 60 us each: started early they fill the side stream while the chain goes on; measured 480 vs
             // 473 pc/s against one flush per block), at the end of the block2 / block3 chains (per-layer flushes there
             // measure nothing: 470) and after each Conv3d
-            if ((l >= L_B1 && l < L_D1) || l == L_B2 || (l == L_B3 && !wg_late_b3) || l <= L_M2) RT(flush());
-            if (l == L_B1 && tail_balance && early_unpack_on) {
-                RT(join_wg());
+            if ((l >= L_B1 && l < L_D1) || l == L_B2 || l == L_B3 || l <= L_M2) RT(flush());
+            if (l == L_B1 && tail_balance) {
                 RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack, nu), wstream, vn_unpack_wgrads_batch(unpack, nu, wstream));
                 RT(after_unpack(0, nu, wstream));
-                u_early = nu;
-            }
-            // middle_layer.2's partial slabs (85 row chunks, 37.6 MB: most of what the LAST unpack reads) are final ~135 us
-            // before the side stream gets middle_layer.1's dy: unpacked here, in that gap, instead of in the step's tail
-            // (tuning aid VN_UNPACK_M2)
-            static const int unpack_m2_on = vn_knob("VN_UNPACK_M2", 0);   // (round 4: 557.5 vs 559.2 pc/s over four pairs: off)
-            if (l == L_M2 && tail_balance && early_unpack_on && unpack_m2_on && nu > u_early) {
-                RT(join_wg());
-                RTT(T_UNPACK, L_M2, 0.0, unpack_bytes(unpack + u_early, nu - u_early), wstream,
-                    vn_unpack_wgrads_batch(unpack + u_early, nu - u_early, wstream));
-                RT(after_unpack(u_early, nu, wstream));
                 u_early = nu;
             }
         }
@@ -1393,7 +1252,6 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         }
     }
     RT(flush());
-    RT(join_wg());
     if (bucket_ev) return VN_OK;   // everything unpacked / zeroed per group; the caller joins the side stream
     if (ws != hs && cfg->defer_join && seg_end == NL + 1) {
         // last segment, join deferred to the caller: the unpack follows the weight gradients on the side stream

@@ -34,7 +34,6 @@ struct WGParams {
     int32_t mulD, mulH, mulW, tmulD, tmulH, tmulW, padD, padH, padW;
     int32_t kD, kH, kW;
     int32_t C, N;             // real source / row channels
-    int32_t split;
     int32_t x3;               // VN_F32X3: fp32 tiles, products as three bf16 MFMAs
     int32_t rows_per_chunk;   // multiple of 64
     int32_t tiles_k;          // number of DK tiles
@@ -49,10 +48,6 @@ struct WGParams {
     // adds into dw itself (one writer per element: no atomics either way)
     float *part;
     int64_t part_stride;
-    // XCD-aware launch (1-D grid): nchunks > 0 — workgroup L of the grid is (chunk, tap group, tile) with the tap groups of
-    // ONE chunk on linear ids that are equal mod 8 (= one XCD under round-robin placement; speed only): the chunk's `rows`
-    // and source slabs are then fetched into one L2 instead of up to eight.  0: the plain 3-D grid (chunk, group, tile)
-    int32_t nchunks, ngroups, ntiles_xcd;
 };
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -102,20 +97,7 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wn = wave / WKW, wk = wave % WKW;
-    int bx = blockIdx.x, by = blockIdx.y, tile = blockIdx.z, gx = gridDim.x;
-    if (p.nchunks > 0) {
-        // unit = (chunk, channel tile): its tap groups sit on linear ids L = batch * 8 * ngroups + group * 8 + (unit & 7),
-        // all equal mod 8; units go round-robin over the eight residues
-        const int ntiles = p.ntiles_xcd;
-        const int r = blockIdx.x;
-        const int batch = r / (8 * p.ngroups), w = r - batch * (8 * p.ngroups);
-        const int unit = batch * 8 + (w & 7);
-        by = w >> 3;
-        bx = unit / ntiles;
-        tile = unit - bx * ntiles;
-        gx = p.nchunks;
-        if (bx >= p.nchunks) return;           // (padding of the unit count to a multiple of 8)
-    }
+    const int bx = blockIdx.x, by = blockIdx.y, tile = blockIdx.z, gx = gridDim.x;
     const int tn = tile / p.tiles_k, tk = tile - tn * p.tiles_k;
     const int n0 = tn * DN, k0 = tk * DK;
     const int tap0 = by * TPB;          // TPB == 3: the three kW taps of one (kd, kh)
@@ -143,8 +125,7 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
         rend = M;
         slab_stride = (int64_t)gx * ROWS;
     }
-    const int nv = p.split ? 3 : 1;
-    const int nstages = nsteps * nv;
+    const int nstages = nsteps;
 
     const __amdgpu_buffer_rsrc_t rs_s = vn_uniform_rsrc(p.src, p.src_bytes);
     const __amdgpu_buffer_rsrc_t rs_r = vn_uniform_rsrc(p.rows, p.rows_bytes);
@@ -164,8 +145,8 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
         cb = (int)(t / p.Dr);
     }
     auto table_write = [&](int stage_idx) {
-        // wave 0 only: entries for slab (stage_idx / nv) into tbl[stage_idx & 1]
-        const int step = stage_idx / nv;
+        // wave 0 only: entries for slab stage_idx into tbl[stage_idx & 1]
+        const int step = stage_idx;
         uint32_t so[TPB], ro = WG_OOB;
 #pragma unroll
         for (int j = 0; j < TPB; ++j) so[j] = WG_OOB;
@@ -227,9 +208,8 @@ __global__ void __launch_bounds__(128 * WKW, 2) k_wgrad(const WGParams p) {
 
     // per-lane DMA geometry: instruction i of this wave covers LDS bytes ((i*4+wave)*1024 .. +1023) of a tile
     auto stage = [&](int sidx, int buf) {
-        const int v = sidx % nv;   // bf16x3 variant: 0 hi*hi, 1 lo(src)*hi(rows), 2 hi(src)*lo(rows)
-        const uint32_t s_col = __builtin_amdgcn_readfirstlane((uint32_t)((k0 + (v == 1 ? p.C : 0)) * ESZ));
-        const uint32_t r_col = __builtin_amdgcn_readfirstlane((uint32_t)((n0 + (v == 2 ? p.N : 0)) * ESZ));
+        const uint32_t s_col = __builtin_amdgcn_readfirstlane((uint32_t)(k0 * ESZ));
+        const uint32_t r_col = __builtin_amdgcn_readfirstlane((uint32_t)(n0 * ESZ));
         const uint32_t *t = tbl + (sidx & 1) * 64 * TW;
         char *ln = smem + buf * STAGE + wave * 1024;
 #pragma unroll
@@ -467,7 +447,8 @@ struct WPParams {
 };
 
 // NH = number of 64-channel halves of the `rows` tile: NH = 1 is the 64 x 64 x nine-tap tile of the 64-channel Conv3d
-// layers (four waves); NH = 2 (round 4) a 128 x 64 x nine-tap tile on EIGHT waves for the 128- / 256-channel 2-D layers:
+// layers (four waves) — the only instantiation the library ships since round 5; NH = 2 (round 4, measured slower in the step
+// and retired: wgrad_patch_enabled) a 128 x 64 x nine-tap tile on EIGHT waves for the 128- / 256-channel 2-D layers:
 // wave (wn, wk) owns rows channels 64 wn .. 64 wn + 63 x source channels 16 wk .. 16 wk + 15 of all nine taps (144
 // accumulator registers, two waves per SIMD).  A stage of 64 sites stages 16 KB of `rows` + 13.8 KB of patch for
 // 9 x 128 x 64 x 64 MACs: 6.3 staged bytes per kMAC against 30.5 for the single-tap 128 x 128 row form (k_wgrad<4,2,.,1,4>),
@@ -719,10 +700,9 @@ struct WPPlan {
     int64_t ntiles, chunks;
 };
 static int wgrad_patch_enabled() {   // tuning aid: VN_WGRAD_PATCH=0 keeps the row form everywhere, 1 (default) = the patch form on
-    // the 64-channel Conv3d layers, 3 = + the 128 x 64 nine-tap tile (k_wgrad_patch<2>) on the wider stride-1 2-D layers:
-    // measured in round 4 — alone 626 / 802 TFLOP/s on block1.1 / deconv1 at 246 workgroups (the single-tap row form: 427 /
-    // 465), but its partial-sum traffic is 4.5x per workgroup: in the step 554 (96-128 workgroups) ... 541 (256) against
-    // 559-562 point-clouds/s for the row form (DESIGN_HISTORY.md, round 4)
+    // the 64-channel Conv3d layers.  (Round 4's 128 x 64 nine-tap tile for the wider 2-D layers — 626 / 802 TFLOP/s alone, 526-554
+    // against 559 point-clouds/s in the step: 4.5x the partial-sum bytes per workgroup — left the library in round 5;
+    // DESIGN_HISTORY.md keeps the numbers, git the code.)
     static const int v = vn_knob("VN_WGRAD_PATCH", 1);
     return v;
 }
@@ -733,14 +713,9 @@ static WPPlan wgrad_patch_plan(const vnConv *g, int32_t split, bool list) {
         g->padW != 1 || g->tmulD != 1 || g->divD != 1 || g->divH != 1 || g->divW != 1)
         return w;
     if (g->Hs != g->Hr || g->Ws != g->Wr) return w;
-    const bool wide = g->Cr > 64;      // 128 x 64 nine-tap tile on eight waves (round 4); else the 64 x 64 four-wave tile
-    if (wide) {
-        if (!(wgrad_patch_enabled() & 2)) return w;
-    } else {
-        // measured (round 2): a win for the 64-channel Conv3d layers (1.3-1.4x) at 400 x 352
-        if (g->Hr < 128 || g->Wr < 128 || g->Cs > 64) return w;
-    }
-    w.nh = wide ? 2 : 1;
+    // measured (round 2): a win for the 64-channel Conv3d layers (1.3-1.4x) at 400 x 352
+    if (g->Cr > 64 || g->Hr < 128 || g->Wr < 128 || g->Cs > 64) return w;
+    w.nh = 1;
     w.tiles_x = (int)vn_ceil_div(g->Wr, 16);
     w.tiles_y = (int)vn_ceil_div(g->Hr, 4);
     w.tiles_n = (int)vn_ceil_div(g->Cr, 64 * w.nh);
@@ -749,12 +724,8 @@ static WPPlan wgrad_patch_plan(const vnConv *g, int32_t split, bool list) {
     // (one workgroup per CU: in the step these launches run on the side stream beside the data gradients;
     //  128 ... 512 workgroups measure within 1 %, 768 is 3 % slower)
     static const int ptarget = vn_knob("VN_WGP_BLOCKS", 256);   // tuning aid
-    // wide tile: the partial-sum traffic (chunks x the whole weight gradient, written here and read back by the unpack)
-    // is what more workgroups cost; VN_WGP2_BLOCKS workgroups and at least VN_WGP2_STAGES stages of 64 sites each
-    static const int ptarget2 = vn_knob("VN_WGP2_BLOCKS", 64);
-    static const int pstages2 = vn_knob("VN_WGP2_STAGES", 10);
-    int64_t chunks = (wide ? ptarget2 : ptarget) / ((int64_t)g->kD * w.tiles_n * w.tiles_k);
-    const int64_t min_stages = wide ? pstages2 : 8;
+    int64_t chunks = ptarget / ((int64_t)g->kD * w.tiles_n * w.tiles_k);
+    const int64_t min_stages = 8;
     if (chunks > w.ntiles / min_stages) chunks = w.ntiles / min_stages;
     if (chunks > 256) chunks = 256;
     if (chunks < 1) chunks = 1;
@@ -774,13 +745,13 @@ extern "C" size_t vn_conv_wgrad_workspace_bytes(const vnConv *g, int32_t split, 
     return (size_t)chunks * (size_t)w.dw_elems * sizeof(float);   // (>= one chunk: vn_conv_wgrad_partials always uses it)
 }
 
-// Which kernel vn_conv_wgrad / vn_conv_wgrad_partials pick for a geometry: 200 = k_wgrad_patch<1>, 202 = k_wgrad_patch<2>; else
+// Which kernel vn_conv_wgrad / vn_conv_wgrad_partials pick for a geometry: 200 = k_wgrad_patch<1>; else
 // 1000 * (three-tap mode) + 10 * TN + TK of k_wgrad<TN, TK, ., .> (tile = 32 TN x 32 TK channels).
 extern "C" int32_t vn_conv_wgrad_plan_id(const vnConv *g, int32_t split, int64_t n_rows) {
     if (!g || g->B <= 0 || g->Dr <= 0 || g->Hr <= 0 || g->Wr <= 0 || g->Cs <= 0 || g->Cr <= 0) return -1;
     const int64_t M = n_rows > 0 ? n_rows : (int64_t)g->B * g->Dr * g->Hr * g->Wr;
     const WPPlan wp = wgrad_patch_plan(g, split, n_rows > 0);
-    if (wp.ok) return wp.nh == 2 ? 202 : 200;
+    if (wp.ok) return 200;
     const WGPlan w = wgrad_plan(g, split, M);
     if (w.tri) return 1000 + 10 * 2 + (w.k128 ? 4 : 2);
     return 10 * (w.n128 ? 4 : 2) + (w.k128 ? 4 : 2);
@@ -856,9 +827,10 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     p.tmulD = g->tmulD; p.tmulH = g->tmulH; p.tmulW = g->tmulW;
     p.padD = g->padD; p.padH = g->padH; p.padW = g->padW;
     p.kD = g->kD; p.kH = g->kH; p.kW = g->kW;
-    p.C = g->Cs; p.N = g->Cr; p.split = split ? 1 : 0;
+    p.C = g->Cs; p.N = g->Cr;
+    if (split) return VN_EUNSUPPORTED;      // (the [hi|lo] three-pass form of the retired bf16x3 mode: round 5)
     p.x3 = g->dtype == VN_F32X3 || ps;
-    const int wmul = split ? 2 : 1;
+    const int wmul = 1;
     const int64_t sbytes = ((int64_t)(g->B - 1) * g->src_sB + (int64_t)(g->Ds - 1) * g->src_sD +
                             (int64_t)(g->Hs - 1) * g->src_sH + (int64_t)(g->Ws - 1) * g->src_sW + wmul * g->Cs) * esz;
     const int64_t rbytes = row_list ? ((n_rows - 1) * g->out_sW + wmul * g->Cr) * esz
@@ -898,13 +870,7 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
         q.src_bytes = p.src_bytes; q.rows_bytes = p.rows_bytes;
         hipStream_t pst = vn_stream(stream);
         const dim3 pgrid((unsigned)pchunks, (unsigned)g->kD, (unsigned)(wp.tiles_n * wp.tiles_k));
-        if (wp.nh == 2) {
-            constexpr size_t lds = 2 * (64 * 256 + 6 * 32 * 128);
-            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_patch<2>),
-                                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (attr != hipSuccess) return (int)attr;
-            k_wgrad_patch<2><<<pgrid, 512, lds, pst>>>(q);
-        } else {
+        {
             constexpr size_t lds = 2 * (64 * 128 + 6 * 32 * 128);
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_wgrad_patch<1>),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -942,18 +908,9 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     }
     p.part_stride = w.dw_elems;
     dim3 grid((unsigned)chunks, (unsigned)groups, (unsigned)(tiles_n * tiles_k));
-    static const int xcd_map = vn_knob("VN_WG_XCD", 0);   // tuning aid: the XCD-aware 1-D grid (WGParams::nchunks)
-    if (xcd_map && chunks > 1) {
-        p.nchunks = (int32_t)chunks;
-        p.ngroups = groups;
-        p.ntiles_xcd = tiles_n * tiles_k;
-        grid = dim3((unsigned)((((chunks * tiles_n * tiles_k) + 7) & ~7ll) * groups), 1, 1);
-    }
     hipStream_t st = vn_stream(stream);
     int rc;
-    static const int tri_waves = vn_knob("VN_WG_TRI_WAVES", 8);   // waves per workgroup of the three-tap tiles (4: round 2)
-    if (tri && tri_waves == 8) rc = k128 ? launch_wgrad<2, 2, false, 3, 4>(p, grid, st) : launch_wgrad<2, 1, false, 3, 4>(p, grid, st);
-    else if (tri) rc = k128 ? launch_wgrad<2, 4, false, 3>(p, grid, st) : launch_wgrad<2, 2, false, 3>(p, grid, st);
+    if (tri) rc = k128 ? launch_wgrad<2, 2, false, 3, 4>(p, grid, st) : launch_wgrad<2, 1, false, 3, 4>(p, grid, st);
     else if (ps) {
         if (n128 && k128) rc = launch_wgrad<4, 2, true, 1, 4, true>(p, grid, st);
         else if (n128) rc = launch_wgrad<4, 1, true, 1, 4, true>(p, grid, st);
@@ -972,16 +929,11 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
         else if (k128) rc = launch_wgrad<2, 4, true, 1>(p, grid, st);
         else rc = launch_wgrad<2, 2, true, 1>(p, grid, st);
     } else {
-        static const int wg_waves = vn_knob("VN_WG_WAVES", 8);   // waves per workgroup of the 128 x 128 bf16 tile (4: round 2)
-        if (wg_waves == 8) {
-            if (n128 && k128) rc = launch_wgrad<4, 2, false, 1, 4>(p, grid, st);
-            else if (n128) rc = launch_wgrad<4, 1, false, 1, 4>(p, grid, st);
-            else if (k128) rc = launch_wgrad<2, 2, false, 1, 4>(p, grid, st);
-            else rc = launch_wgrad<2, 1, false, 1, 4>(p, grid, st);
-        } else if (n128 && k128) rc = launch_wgrad<4, 4, false, 1>(p, grid, st);
-        else if (n128) rc = launch_wgrad<4, 2, false, 1>(p, grid, st);
-        else if (k128) rc = launch_wgrad<2, 4, false, 1>(p, grid, st);
-        else rc = launch_wgrad<2, 2, false, 1>(p, grid, st);
+        // eight waves on the 128 x 128 tile (two per SIMD at one workgroup per CU; the four-wave form of round 2 is gone)
+        if (n128 && k128) rc = launch_wgrad<4, 2, false, 1, 4>(p, grid, st);
+        else if (n128) rc = launch_wgrad<4, 1, false, 1, 4>(p, grid, st);
+        else if (k128) rc = launch_wgrad<2, 2, false, 1, 4>(p, grid, st);
+        else rc = launch_wgrad<2, 1, false, 1, 4>(p, grid, st);
     }
     if (rc != VN_OK) return rc;
     if (chunks > 1 && !partial_only) {

@@ -125,10 +125,6 @@ SIGNATURES = {
     "vn_conv_stats_slab_rows": (c_i64, [_P(VnConv)]),
     "vn_conv_plan_id": (c_i32, [_P(VnConv)]),
     "vn_conv_wgrad_plan_id": (c_i32, [_P(VnConv), c_i32, c_i64]),
-    "vn_bn_finalize_apply_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp, c_i32,
-                                          c_i64, c_i32, c_vp, c_i32, c_i64, c_vp]),
-    "vn_bn_bwd_finalize_apply_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i64, c_vp,
-                                              c_i32, c_i64, c_i32, c_vp, c_i32, c_i64, c_vp]),
     "vn_bn_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_f32, c_f32, c_vp, c_vp]),
     "vn_conv_wgrad_workspace_bytes": (c_sz, [_P(VnConv), c_i32, c_i64]),
     "vn_conv_wgrad": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_sz, c_vp]),
@@ -150,9 +146,6 @@ SIGNATURES = {
     "vn_bn_bwd_slab_rows": (c_i64, [c_i64, c_i32]),
     "vn_bn_bwd_reduce_slab": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "vn_bn_bwd_finalize_slab": (c_i32, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
-    "vn_bn_bwd_reduce_slab_heads": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
-    "vn_bn_bwd_apply_heads": (c_i32, [c_vp, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp, c_i32,
-                                      c_i64, c_vp]),
     "vn_bn_bwd_apply": (c_i32, [c_vp, c_i32, c_i64, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_i32, c_vp,
                                 c_i32, c_i64, c_i64, c_vp]),
     "vn_bn_apply_bev": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_i32, c_vp, c_i32, c_i64, c_vp]),

@@ -36,7 +36,8 @@ def _dt(t):
     return VN_F32 if t.dtype == torch.float32 else VN_BF16
 
 
-MODES = ("bf16", "fp32", "bf16x3", "fp32x3")
+MODES = ("bf16", "fp32", "fp32x3")      # ("bf16x3", [hi|lo] bf16 storage on the bf16 kernels, left in round 5: fp32x3
+#                                          reaches the same map error at 4x its speed; is_split() below is always False now)
 # "fp32x3" (round 4): fp32 storage exactly like "fp32", but the convolutions / weight gradients evaluate every product as
 # three bf16 MFMAs on hi / lo splits made in registers (vnDtype VN_F32X3) — ~1e-4 on the RPN maps at a fraction of the
 # exact fp32 MFMA cost.  The per-launch geometry carries the operand dtype, so the flag below is all the per-layer path needs.

@@ -33,7 +33,9 @@ _PRECISION = {"mode": "bf16"}
 def set_precision(mode):
     """'bf16' (bf16 storage + MFMA, BASELINE configs[1]), 'fp32' (exact fp32 MFMA, the parity
     mode), 'fp32x3' (fp32 storage, every conv product as three bf16 MFMAs: ~1e-4 maps, the fast mode inside the 1e-3
-    tolerance) or 'bf16x3' (see engine.py)."""
+    tolerance).  ('bf16x3' was retired in round 5: fp32x3 gives the same map error at four times its speed.)"""
+    if mode == "bf16x3":
+        raise ValueError("the 'bf16x3' mode was retired (round 5): use 'fp32x3' — same map error, inside the native executor")
     if mode not in E.MODES:
         raise ValueError(mode)
     _PRECISION["mode"] = mode

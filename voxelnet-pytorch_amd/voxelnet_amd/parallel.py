@@ -76,15 +76,25 @@ class GradAllReducer:
         # pipeline, this one, torch's) on the HIP runtime's four hardware queues, i.e. two of them serialised against each
         # other.  The pipeline stream is idle while the backward runs (the next batch was voxelized at
         # the start of the step), so waiting for the bucket events there delays nothing.
+        # UNTESTED with real RCCL kernels on that queue (no N > 1 hardware run exists yet): with the
+        # collectives of step i on the pipeline stream, batch i+1's copies / crop / voxelizer / target generation queue behind
+        # them.  VN_COMM_STREAM=private gives the reducer a stream of its own again (the five-stream arrangement) so that the
+        # first multi-GPU run can compare the two; `comm_stream_kind` says which one this reducer uses (bench.py prints it).
         self.comm_stream = None
+        self.comm_stream_kind = None
         if self.cuda and use_side_stream:
-            from .voxelize import pipeline_stream
-            self.comm_stream = pipeline_stream(self.buckets[0]["flat"].device)
+            if os.environ.get("VN_COMM_STREAM", "pipeline") == "private":
+                self.comm_stream = torch.cuda.Stream(device=self.buckets[0]["flat"].device)
+                self.comm_stream_kind = "private"
+            else:
+                from .voxelize import pipeline_stream
+                self.comm_stream = pipeline_stream(self.buckets[0]["flat"].device)
+                self.comm_stream_kind = "pipeline (shared with the input pipeline and the target generator)"
         self.defer_allreduce = False   # True: grad_ready only fills the buckets (HIP-graph capture); allreduce_all() later
         self.comm = None               # ncclComm_t of the direct path
         if direct_rccl is None:
             direct_rccl = os.environ.get("VN_DIRECT_RCCL") == "1"
-        if direct_rccl and self.cuda:
+        if direct_rccl:
             if self.world > 1 and os.environ.get("VN_DIRECT_RCCL_UNSAFE") != "1":
                 # vn_allreduce_bucket has only ever run on a one-rank communicator (the build pool hands out one GPU per
                 # call): refuse to be the path of a multi-GPU run until someone asks for it by name
@@ -92,7 +102,8 @@ class GradAllReducer:
                 raise _lib.VoxelnetHipError("GradAllReducer(direct_rccl=True) with world size %d: the library's own RCCL entry has "
                                             "never run on two devices — set VN_DIRECT_RCCL_UNSAFE=1 to try it; the default "
                                             "(torch.distributed, backend nccl = the same RCCL) needs nothing" % self.world)
-            self._init_direct()
+            if self.cuda:
+                self._init_direct()
         self.reset()
 
     def _init_direct(self):
