@@ -1,0 +1,97 @@
+// Drives the HOST side of the native step executor (vn_net_prepare x2 -> vn_net_forward -> vn_net_backward: the calls
+// voxelnet_amd/model.py makes per train step, train.py:148-151) with fake device pointers, under the stub HIP layer of
+// stub_hip.c.  Prints "<launches per step> <microseconds per step>" (median of 5 blocks).  Test infrastructure.
+//   drive_executor <libvoxelnet_hip.so> <steps> [bucket_events]
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dlfcn.h>
+#include <vector>
+#include "../../include/voxelnet_hip.h"
+
+extern "C" unsigned long long vn_stub_launches(void);
+
+#define SYM(name) auto p_##name = reinterpret_cast<decltype(&name)>(dlsym(lib, #name)); if (!p_##name) { fprintf(stderr, "missing %s\n", #name); return 2; }
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 2;
+    void *lib = dlopen(argv[1], RTLD_NOW);
+    if (!lib) { fprintf(stderr, "%s\n", dlerror()); return 2; }
+    const int steps = atoi(argv[2]);
+    const int buckets = argc > 3 ? atoi(argv[3]) : 0;
+    if (buckets < 0) {
+        // control: a private-memory workload of the executor's kind (struct fills and copies over ~48 KB, some integer
+        // arithmetic) that shares NOTHING between processes — what eight copies of it lose against one is the machine's
+        // doing (SMT siblings, shared caches, a noisy host), the yardstick for the executor's own ratio
+        std::vector<char> a(48 << 10), b(48 << 10);
+        std::vector<double> blocks;
+        unsigned acc = 1;
+        for (int blk = 0; blk < 5; ++blk) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int i = 0; i < steps; ++i) {
+                memset(a.data(), i & 0xff, a.size());
+                memcpy(b.data(), a.data(), a.size());
+                for (size_t k = 0; k < b.size(); k += 64) acc = acc * 1664525u + (unsigned char)b[k];
+            }
+            blocks.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps);
+        }
+        std::sort(blocks.begin(), blocks.end());
+        printf("%u %.2f\n", acc & 1u, blocks[2]);
+        return 0;
+    }
+    SYM(vn_net_workspace_bytes) SYM(vn_net_create) SYM(vn_net_destroy) SYM(vn_net_prepare) SYM(vn_net_forward) SYM(vn_net_backward)
+    vnNetConfig cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.B = 2; cfg.D = 10; cfg.H = 400; cfg.W = 352; cfg.block1_stride = 2; cfg.mode = 0; cfg.training = 1; cfg.sparse_first = 1;
+    const int64_t K = 12345;
+    const size_t ws_bytes = p_vn_net_workspace_bytes(&cfg, K);
+    if (!ws_bytes) return 3;
+    // fake device memory: addresses only (the stub never dereferences; the executor's host code never does either)
+    char *const dev = reinterpret_cast<char *>(0x7f0000000000ull);
+    char *ws = dev;
+    float *par = reinterpret_cast<float *>(dev + (ws_bytes + 4096) / 256 * 256);
+    vnLayerParams L[23];
+    vnLayerGrads G[23];
+    for (int l = 0; l < 23; ++l) {
+        L[l] = vnLayerParams{par, par + 1024, par + 2048, par + 3072, par + 4096, par + 5120};
+        G[l] = vnLayerGrads{par + 6144, par + 7168, par + 8192, par + 9216};
+        par += 1 << 20;
+    }
+    float *heads_w = par, *heads_b = par + 16384, *prob = par + 32768, *reg = par + (1 << 22), *dprob = par + (2 << 22),
+          *dreg = par + (3 << 22), *dhw = par + (4 << 22), *dhb = par + (5 << 22), *d_in = par + (6 << 22);
+    const int64_t *coord = reinterpret_cast<const int64_t *>(par + (7 << 22));
+    const void *vw_rows = par + (8 << 22);
+    vnNet *net = nullptr;
+    if (p_vn_net_create(&net)) return 4;
+    vnStream main_s = reinterpret_cast<vnStream>(0x10), side_s = reinterpret_cast<vnStream>(0x20);
+    auto one_step = [&]() -> int {
+        int rc;
+        cfg.bucket_events = 0; cfg.defer_join = 0;
+        cfg.prepared = 1;
+        if ((rc = p_vn_net_prepare(net, &cfg, L, nullptr, coord, K, ws, ws_bytes, side_s))) return rc;
+        cfg.prepared = 2;
+        if ((rc = p_vn_net_prepare(net, &cfg, L, heads_w, coord, K, ws, ws_bytes, side_s))) return rc;
+        cfg.prepared = 1;
+        if ((rc = p_vn_net_forward(net, &cfg, L, heads_w, heads_b, nullptr, coord, vw_rows, K, ws, ws_bytes, prob, reg, main_s, side_s))) return rc;
+        cfg.bucket_events = buckets; cfg.defer_join = 1;
+        return p_vn_net_backward(net, &cfg, L, heads_w, dprob, dreg, prob, nullptr, coord, vw_rows, K, ws, ws_bytes, G, dhw, dhb, d_in,
+                                 0, 24, main_s, side_s);
+    };
+    for (int i = 0; i < 20; ++i)
+        if (int rc = one_step()) { fprintf(stderr, "step failed: %d\n", rc); return 5; }
+    std::vector<double> blocks;
+    unsigned long long l0 = vn_stub_launches();
+    for (int b = 0; b < 5; ++b) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < steps; ++i)
+            if (int rc = one_step()) { fprintf(stderr, "step failed: %d\n", rc); return 5; }
+        blocks.push_back(std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / steps);
+    }
+    const double per_step = (double)(vn_stub_launches() - l0) / (5.0 * steps);
+    std::sort(blocks.begin(), blocks.end());
+    printf("%.1f %.2f\n", per_step, blocks[2]);
+    p_vn_net_destroy(net);
+    return 0;
+}

@@ -29,7 +29,7 @@ BN_MOMENTUM = 0.1
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.raw_stream()
 
 
 def _dt(t):

@@ -46,7 +46,7 @@ def fov_crop_device(points, P, Tr_velo_to_cam, R_cam_to_rect, image_rows, image_
         ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
         _lib.call("vn_fov_crop", points.data_ptr(), n, mats[0].ctypes.data, mats[1].ctypes.data, mats[2].ctypes.data,
                   int(image_rows), int(image_cols), out.data_ptr(), index.data_ptr() if index is not None else None,
-                  count.data_ptr(), ws.data_ptr(), ws.numel(), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                  count.data_ptr(), ws.data_ptr(), ws.numel(), _lib.raw_stream())
         if padded:
             return (out[:n], count, index) if return_index else (out[:n], count)
         k = int(count.item())

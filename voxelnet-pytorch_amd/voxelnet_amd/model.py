@@ -28,6 +28,7 @@ from .config import ALPHA, BETA, SIGMA, grid_config
 from .engine import Rows
 
 _PRECISION = {"mode": "bf16"}
+_PREP_JOIN = os.environ.get("VN_PREP_JOIN") == "1"      # A/B aid (read once): the round-2 one-call prepare + full join
 
 
 def set_precision(mode):
@@ -628,7 +629,7 @@ class _DetectorFn(torch.autograd.Function):
                     # weight packing reads — and the rest of the packing
                     side_t = rpn.__dict__["_side"]
                     side_t.wait_stream(torch.cuda.current_stream())
-                    two_phase = os.environ.get("VN_PREP_JOIN") != "1"      # ("1": the round-2 schedule, one call, for A/B runs)
+                    two_phase = not _PREP_JOIN      # ("1": the round-2 schedule, one call, for A/B runs)
                     if two_phase:
                         cfg.prepared = 1                       # phase 1: the first layer's needs only
                         _lib.call("vn_net_prepare", rpn._net_handle(dev_), ctypes.byref(cfg), arr, None, coord.data_ptr(), K,
@@ -655,7 +656,7 @@ class _DetectorFn(torch.autograd.Function):
                               _lib.VN_BF16, 128, 0, E.stream())
                 # (no join of the side stream here: vn_net_forward waits for vn_net_prepare's two events itself — the first
                 # layer's needs at its start, the rest of the weight packing in front of the second layer)
-                if side is not None and os.environ.get("VN_PREP_JOIN") == "1":     # A/B aid: the round-2 full join
+                if side is not None and _PREP_JOIN:     # A/B aid: the round-2 full join
                     torch.cuda.current_stream().wait_stream(side_t)
                 hf, wf = H // mid._block1_stride, W // mid._block1_stride
                 prob = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=vw.device)

@@ -10,7 +10,7 @@ from ._lib import VN_BF16, VN_F32
 
 
 def stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.raw_stream()
 
 
 def _need_cuda(*ts):

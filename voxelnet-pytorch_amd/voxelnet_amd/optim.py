@@ -101,7 +101,7 @@ class ClipSGD(torch.optim.Optimizer):
             # parameter storage (a `p.data = ...` / `set_()` swap keeps the Parameter object but not its memory): the chunk
             # table of raw pointers is still valid, nothing to rebuild or re-check
             with torch.cuda.device(self._table.device):
-                stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+                stream = _lib.raw_stream()
                 from . import engine as E
                 with E.section("clip_sgd", 16.0 * self._n_elems):
                     _lib.call("vn_clip_sgd", self._table.data_ptr(), self._n_chunks, self.max_norm, self.lr,
@@ -124,7 +124,7 @@ class ClipSGD(torch.optim.Optimizer):
         self._last_grads = [p.grad for p in plist] if len(pairs) == len(plist) else None
         self._last_pptrs = [p.data_ptr() for p in plist]
         with torch.cuda.device(dev):
-            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            stream = _lib.raw_stream()
             from . import engine as E
             with E.section("clip_sgd", 16.0 * sum(p.numel() for p, _ in pairs)):      # grad read twice, param read + written
                 _lib.call("vn_clip_sgd", self._table.data_ptr(), self._n_chunks, self.max_norm, self.lr, int(self.scale_grads),

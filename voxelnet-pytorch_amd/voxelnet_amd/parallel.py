@@ -142,7 +142,7 @@ class GradAllReducer:
         if self.comm is not None:
             from . import _lib
             _lib.call("vn_allreduce_bucket", self.comm, flat.data_ptr(), flat.numel(), 1.0 / self.world,
-                      ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                      _lib.raw_stream())
             return None
         flat.div_(self.world)
         return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)

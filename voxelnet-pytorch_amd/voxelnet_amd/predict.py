@@ -41,7 +41,7 @@ class BoxDecoder:
         with torch.cuda.device(dev):
             _lib.call("vn_rpn_predict", probs.data_ptr(), deltas.data_ptr(), self._anchors_dev.data_ptr(), B, N,
                       float(score_thres), float(nms_thres), int(top_k), self.anchor_h, boxes.data_ptr(), scores.data_ptr(),
-                      counts.data_ptr(), ws.data_ptr(), nbytes, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+                      counts.data_ptr(), ws.data_ptr(), nbytes, _lib.raw_stream())
         cnt = counts.cpu().numpy()
         bh, sh = boxes.cpu().numpy(), scores.cpu().numpy()
         return [bh[b, :cnt[b]].copy() for b in range(B)], [sh[b, :cnt[b]].copy() for b in range(B)]

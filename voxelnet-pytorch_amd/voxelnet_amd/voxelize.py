@@ -17,6 +17,8 @@ import torch
 import torch.utils.data
 
 from . import _lib
+
+_CAT_AHEAD = os.environ.get("VN_CAT_AHEAD") != "0"      # ("0": A/B aid, read once)
 from .config import grid_config
 
 
@@ -25,7 +27,7 @@ def _grid_struct(g):
 
 
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return _lib.raw_stream()
 
 
 def voxelize_device(points, grid, batch_index=0, coord_cols=4):
@@ -159,7 +161,7 @@ class VoxelBatch(list):
     @classmethod
     def ahead(cls, tensors, stream, dtype):
         out = cls(tensors)
-        if len(out) > 1 and out[0].is_cuda and os.environ.get("VN_CAT_AHEAD") != "0":   # ("0": A/B aid, the model concatenates)
+        if len(out) > 1 and out[0].is_cuda and _CAT_AHEAD:   # ("0": A/B aid, the model concatenates)
             with torch.cuda.stream(stream):
                 out.cat = torch.cat(list(out), dim=0).contiguous().to(dtype)
                 out.cat_event = torch.cuda.Event()
