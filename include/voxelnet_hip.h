@@ -252,6 +252,12 @@ int32_t vn_conv_wgrad_plan_id(const vnConv *geom, int32_t split, int64_t n_rows)
 int vn_conv_wgrad_partials(const void *src, const void *rows, const vnConv *geom, int32_t split,
                            const int64_t *row_list, int64_t n_rows, void *workspace,
                            size_t workspace_bytes, int32_t *chunks, vnStream stream);
+/* One of the three bf16 products of an fp32x3 weight gradient over operands in split storage (geom->dtype VN_F32X3S):
+ * pass 0 = hi(src).hi(rows), 1 = lo(src).hi(rows), 2 = hi(src).lo(rows) on the bf16 nine-tap patch kernel, reading the
+ * halves in place.  Only the geometries of that kernel (the 64-channel Conv3d layers, model.py:207-209), else
+ * VN_EUNSUPPORTED.  Lay the three passes' partial slabs one after the other; the unpack sums them like row chunks. */
+int vn_conv_wgrad_partials_split_pass(const void *src, const void *rows, const vnConv *geom, int32_t pass, void *workspace,
+                                      size_t workspace_bytes, int32_t *chunks, vnStream stream);
 
 /* A data-gradient launch (ConvMD backward, model.py:111-167) that also leaves the BatchNorm-backward sums of the layer
  * BELOW in its epilogue: out = the gradient w.r.t. that layer's activation a = relu(BN(y)); bn_y = that layer's conv

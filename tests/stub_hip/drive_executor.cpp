@@ -1,7 +1,7 @@
 // Drives the HOST side of the native step executor (vn_net_prepare x2 -> vn_net_forward -> vn_net_backward: the calls
 // voxelnet_amd/model.py makes per train step, train.py:148-151) with fake device pointers, under the stub HIP layer of
 // stub_hip.c.  Prints "<launches per step> <microseconds per step>" (median of 5 blocks).  Test infrastructure.
-//   drive_executor <libvoxelnet_hip.so> <steps> [bucket_events]
+//   drive_executor <libvoxelnet_hip.so> <steps> [bucket_events [mode [H W [K]]]]   (mode 0 bf16, 1 fp32, 2 fp32x3)
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -45,7 +45,10 @@ int main(int argc, char **argv) {
     vnNetConfig cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.B = 2; cfg.D = 10; cfg.H = 400; cfg.W = 352; cfg.block1_stride = 2; cfg.mode = 0; cfg.training = 1; cfg.sparse_first = 1;
-    const int64_t K = 12345;
+    int64_t K = 12345;
+    if (argc > 4) cfg.mode = atoi(argv[4]);
+    if (argc > 6) { cfg.H = atoi(argv[5]); cfg.W = atoi(argv[6]); }
+    if (argc > 7) K = atoll(argv[7]);
     const size_t ws_bytes = p_vn_net_workspace_bytes(&cfg, K);
     if (!ws_bytes) return 3;
     // fake device memory: addresses only (the stub never dereferences; the executor's host code never does either)

@@ -254,3 +254,50 @@ def test_executor_split_storage_matches_the_in_register_form(monkeypatch):
     # the exact per-kernel checks are above
     worst = max(float((g3[n] - g32[n]).norm() / (g32[n].norm() + 1e-30)) for n in g32 if g32[n].norm() > 0)
     assert worst < 0.3, worst
+
+
+def test_conv3d_weight_gradient_passes_read_the_split_halves_in_place(x3):
+    """vn_conv_wgrad_partials_split_pass (middle_layer.2's shape class, model.py:209: 64 -> 64 channels, 3x3x3, stride
+    (2,1,1), image >= 128 x 128): the three bf16 passes of the nine-tap patch kernel over operands in split storage, summed,
+    against the in-register fp32x3 weight gradient of the same fp32 tensors"""
+    E = x3
+    from voxelnet_amd import _lib
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(14)
+    spec = E.spec3("t", 64, 64, 3, (2, 1, 1), (1, 1, 1))
+    B, dims = 2, (3, 128, 144)
+    odims = spec.out_dims(dims)
+    x = torch.from_numpy(rng.standard_normal((B,) + dims + (64,)).astype(np.float32)).to(dev)
+    dy = torch.from_numpy(rng.standard_normal((B,) + odims + (64,)).astype(np.float32)).to(dev)
+    xr, dr = E.Rows(x, 64), E.Rows(dy, 64)
+    g = E._geom(B, xr, odims, 64, 0, 64, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1), dr.strides)
+    g.dtype = VN_F32X3
+    dw_reg = torch.zeros((27, 64, 64), dtype=torch.float32, device=dev)
+    ws, wsb = E.wgrad_workspace(g, 0, 0, dev)
+    _lib.call("vn_conv_wgrad", xr.ptr(), dr.ptr(), dw_reg.data_ptr(), ctypes.byref(g), 0, ws.data_ptr(), wsb, E.stream())
+    xs, ds = split_storage(x), split_storage(dy)
+    g.dtype = VN_F32X3S
+    gb = E._geom(B, E.Rows(x.to(torch.bfloat16), 64), odims, 64, 0, 64, spec.k, spec.stride, (1, 1, 1), spec.pad, (1, 1, 1),
+                 E.Rows(dy.to(torch.bfloat16), 64).strides)
+    assert _lib.load().vn_conv_wgrad_plan_id(ctypes.byref(gb), 0, 0) == 200          # the nine-tap patch kernel
+    pbytes = _lib.load().vn_conv_wgrad_workspace_bytes(ctypes.byref(gb), 0, 0)
+    total = torch.zeros((27, 64, 64), dtype=torch.float64, device=dev)
+    for p in range(3):
+        part = torch.full((pbytes // 4,), float("nan"), dtype=torch.float32, device=dev)
+        ch = ctypes.c_int32(0)
+        _lib.call("vn_conv_wgrad_partials_split_pass", xs.data_ptr(), ds.data_ptr(), ctypes.byref(g), p, part.data_ptr(), pbytes,
+                  ctypes.byref(ch), E.stream())
+        torch.cuda.synchronize()
+        assert 1 <= ch.value <= pbytes // (4 * 27 * 64 * 64)
+        total += part[:ch.value * 27 * 64 * 64].view(ch.value, 27, 64, 64).double().sum(0)
+    rel = float((total - dw_reg.double()).norm() / dw_reg.double().norm())
+    assert rel < 2e-6, rel
+    # a geometry outside the patch form is refused, not mis-computed
+    spec2 = E.spec2("t", 128, 128, 3, (1, 1), (1, 1))
+    x2 = torch.zeros((1, 1, 32, 32, 128), dtype=torch.float32, device=dev)
+    g2 = E._geom(1, E.Rows(x2, 128), (1, 32, 32), 128, 0, 128, spec2.k, spec2.stride, (1, 1, 1), spec2.pad, (1, 1, 1), E.Rows(x2, 128).strides)
+    g2.dtype = VN_F32X3S
+    ch = ctypes.c_int32(0)
+    with pytest.raises(_lib.VoxelnetHipError):
+        _lib.call("vn_conv_wgrad_partials_split_pass", x2.data_ptr(), x2.data_ptr(), ctypes.byref(g2), 0, x2.data_ptr(), 1 << 20,
+                  ctypes.byref(ch), E.stream())

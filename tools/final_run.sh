@@ -1,7 +1,7 @@
 # round-end measurement set (run on the GPU box through gpurun): tests, smoke, bench (three configs), rocprofv3 kernel
 # stats of the SAME command, the two HBM-traffic PMC passes and the MFMA-busy PMC pass (each --pmc pass on its own, never
 # combined with tracing).  Summaries are copied to profiles/ by hand afterwards (gpurun_out/ is scratch).
-R=${R:-r04}
+R=${R:-r05}
 mkdir -p $GRAFT_REPO_ROOT/gpurun_out
 set -e
 cd $GRAFT_REPO_ROOT
@@ -13,6 +13,8 @@ python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 cat gpurun_out/final_bench.json
 python bench.py --config ped --no-cpu-baseline > gpurun_out/final_bench_ped.json 2> gpurun_out/final_bench_ped.err
 python bench.py --config dense --no-cpu-baseline > gpurun_out/final_bench_dense.json 2> gpurun_out/final_bench_dense.err
+# the fast mode inside the 1e-3 map tolerance, with its own roofline (peak = 2500 / 3 TFLOP/s: three bf16 products per fp32 product)
+python bench.py --precision fp32x3 --no-cpu-baseline > gpurun_out/final_bench_fp32x3.json 2> gpurun_out/final_bench_fp32x3.err
 # the N > 1 code path, rehearsed with two ranks on the one GPU of this box (gloo carries the collective)
 VN_BENCH_SHARE_GPU=1 timeout -k 10 400 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/final_bench_n2_rehearsal.json 2> gpurun_out/final_bench_n2_rehearsal.err
 tail -c 600 gpurun_out/final_bench_n2_rehearsal.json

@@ -92,6 +92,8 @@ struct Plan {
     void *x3_src, *x3_rows;   // fp32x3: [hi|lo] bf16 copies of middle_layer.2's input and dy (its weight gradient runs on the bf16 patch kernel)
     bool x3;          // cfg->mode == 2 ("fp32x3"): fp32 storage, the convolutions' and weight gradients' products as three bf16 MFMAs
     bool x3_store;    // fp32x3: activations / gradients that feed convolutions and weight gradients are stored split (VN_F32X3S)
+    bool m2_passes;   // x3_store: middle_layer.2's weight gradient as three in-place bf16 passes of the nine-tap patch kernel
+                      // (its geometry class only: images >= 128 x 128; smaller grids take the split-operand row form)
     bool round_act;   // fp32 mode diagnostic (grad_storage & 16): activations rounded to bf16 VALUES, everything else exact fp32
     bool exact_heads; Rows d_rows32;   // grad_storage & 8: the fp32 logit gradient beside the bf16 one
     void *hwp_f, *hwp_d; Rows hy, cat, d_rows, d_cat; float *hdwp, *hcs; size_t hdwp_bytes; void *hcs_ws; size_t hcs_ws_bytes;
@@ -158,9 +160,9 @@ int32_t wdt(const Plan &P) { return P.x3 ? (int32_t)VN_F32X3 : (int32_t)P.adt; }
 // fp32x3, middle_layer.2's weight gradient: in fp32 the row form re-stages both operands once per tap (27 x: 2.4 ms); the
 // operands are cast to [hi|lo] bf16 rows once (row width 2 C) and the bf16 patch kernel runs three times over them —
 // hi.hi, lo(src).hi, hi(src).lo(rows) — into consecutive partial slabs that the unpack sums like row chunks
-vnConv x3_wgrad_geom(const Plan &P, int l, void *src_hl, void *rows_hl, int src_lo, int rows_lo) {
+vnConv x3_wgrad_geom(const Plan &P, int l, void *src_hl, void *rows_hl, int src_lo, int rows_lo, int B_plan = 0) {
     const Spec &sp = P.spec[l];
-    const int B = P.dy[l].B;
+    const int B = B_plan > 0 ? B_plan : P.dy[l].B;      // (B_plan: while the plan is still being laid out)
     Rows xs = dense_rows(src_hl, VN_BF16, B, P.in_dims[l][0], P.in_dims[l][1], P.in_dims[l][2], sp.cin, 2 * sp.cin);
     Rows ds = dense_rows(rows_hl, VN_BF16, B, P.odims[l][0], P.odims[l][1], P.odims[l][2], sp.cout, 2 * sp.cout);
     if (xs.ptr) xs.ptr += (size_t)(src_lo ? sp.cin : 0) * 2;
@@ -182,6 +184,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     const bool f32 = c->mode != 0;      // modes 1 (fp32) and 2 (fp32x3) store everything in fp32
     P->x3 = c->mode == 2;
     P->x3_store = P->x3 && x3_split_store_on() && vn_x3_presplit(32);
+    P->m2_passes = false;     // (set below, once the dims are known)
     P->esz = f32 ? 4 : 2;
     P->adt = f32 ? VN_F32 : VN_BF16;
     if (c->grad_storage & ~31) return false;
@@ -217,6 +220,10 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     P->wf = P->odims[L_D1][2];
     for (int l : {L_D2, L_D3})
         if (P->odims[l][1] != P->hf || P->odims[l][2] != P->wf) return false;
+    if (P->x3_store) {
+        const vnConv gb = x3_wgrad_geom(*P, L_M2, nullptr, nullptr, 0, 0, c->B);      // (P->dy is not laid out yet)
+        P->m2_passes = vn_conv_wgrad_plan_id(&gb, 0, 0) == 200;
+    }
     // ---- packed weights
     for (int l = 0; l < NL; ++l) {
         const Spec &sp = P->spec[l];
@@ -355,11 +362,15 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
                 b = ask(P->in_dims[0], sp.cout, sp.cin, sp.k, K > 0 ? K : 1);
             } else if (l == 1 && P->sparse_w1) {
                 b = ask(P->in_dims[1], sp.cout, sp.cin, sp.k, P->acap);
-            } else if (l == L_M2 && P->x3) {   // three passes of the bf16 kernel over [hi|lo] copies (x3_wgrad_geom)
+            } else if (l == L_M2 && P->x3 && !(P->x3_store && !P->m2_passes)) {
+                // three passes of the bf16 kernel: over the split-stored operands in place (x3_store; nine-tap patch form only)
+                // or over [hi|lo] copies (x3_wgrad_geom)
                 const vnConv gb = x3_wgrad_geom(*P, l, nullptr, nullptr, 0, 0);
                 b = 3 * vn_conv_wgrad_workspace_bytes(&gb, 0, 0);
-                P->x3_src = A.take((size_t)B * P->in_dims[l][0] * P->in_dims[l][1] * P->in_dims[l][2] * 2 * sp.cin * 2);
-                P->x3_rows = A.take((size_t)B * P->odims[l][0] * P->odims[l][1] * P->odims[l][2] * 2 * sp.cout * 2);
+                if (!P->x3_store) {      // (split storage: the passes read the halves where the BatchNorm passes left them)
+                    P->x3_src = A.take((size_t)B * P->in_dims[l][0] * P->in_dims[l][1] * P->in_dims[l][2] * 2 * sp.cin * 2);
+                    P->x3_rows = A.take((size_t)B * P->odims[l][0] * P->odims[l][1] * P->odims[l][2] * 2 * sp.cout * 2);
+                }
             } else {   // the real launch geometry: the kernel variant (and its chunking) is chosen from it
                 const int src_l = l == 0 ? -1 : (l == L_D1 || l == L_B2) ? L_D1 - 1 : (l == L_D2 || l == L_B3) ? L_D2 - 1 : l - 1;
                 const Rows xin = dense_rows(nullptr, src_l < 0 ? P->adt : P->a[src_l].dtype, B, P->in_dims[l][0], P->in_dims[l][1],
@@ -990,7 +1001,23 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             return VN_OK;
         }
         const Rows x = input_of(l);
-        if (l == L_M2 && P.x3) {
+        if (l == L_M2 && P.x3 && P.x3_store && P.m2_passes) {
+            // three bf16 passes of the nine-tap patch kernel over the split-stored operands, in place
+            vnConv gs = wgrad_geom(P, l, x);
+            if (gs.dtype != VN_F32X3S || dy.dtype != VN_F32X3S) return VN_EINVAL;
+            const size_t pass_bytes = P.dwp_bytes[l] / 3;
+            int32_t total = 0;
+            for (int pass = 0; pass < 3; ++pass) {
+                int32_t ch = 1;
+                float *slabs = P.dwp[l] + (size_t)total * dw_elems;
+                RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B) / 3.0, (rows_bytes(x) + rows_bytes(dy)) / 3.0, wstream,
+                    vn_conv_wgrad_partials_split_pass(x.ptr, dy.ptr, &gs, pass, slabs, pass_bytes, &ch, wstream));
+                total += ch;
+            }
+            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, total, dw_elems};
+            return VN_OK;
+        }
+        if (l == L_M2 && P.x3 && !P.x3_store) {
             RTT(T_MISC, l, 0.0, 2.0 * rows_bytes(x), wstream,
                 vn_cast_rows(x.ptr, (vnDtype)x.dtype, x.sW, x.M(), sp.cin, P.x3_src, VN_BF16, 2 * sp.cin, sp.cin, wstream));
             RTT(T_MISC, l, 0.0, 2.0 * rows_bytes(dy), wstream,

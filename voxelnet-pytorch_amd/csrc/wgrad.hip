@@ -444,6 +444,11 @@ struct WPParams {
     int32_t tiles_x, tiles_y;    // 4 x 16 tiles per plane
     int32_t tiles_per_chunk;
     uint32_t src_bytes, rows_bytes;
+    // where the 16-B chunk of channels 8c .. 8c+7 of a site lives: byte c * cb + part.  Plain bf16 rows: cb = 16, part = 0.
+    // One bf16 HALF of a tensor in split fp32 storage (VN_F32X3S: per 8 channels 16 B of hi parts, then 16 B of lo parts):
+    // cb = 32, part = 0 (hi) / 16 (lo) — the three bf16 passes of an fp32x3 weight gradient read the operands where the
+    // BatchNorm passes stored them (round 5; round 4 made [hi | lo] row copies first)
+    uint32_t s_cb, s_part, r_cb, r_part;
 };
 
 // NH = number of 64-channel halves of the `rows` tile: NH = 1 is the 64 x 64 x nine-tap tile of the 64-channel Conv3d
@@ -491,7 +496,7 @@ __global__ void __launch_bounds__(256 * NH, 2) k_wgrad_patch(const WPParams p) {
 
     const __amdgpu_buffer_rsrc_t rs_s = vn_uniform_rsrc(p.src, p.src_bytes);
     const __amdgpu_buffer_rsrc_t rs_r = vn_uniform_rsrc(p.rows, p.rows_bytes);
-    const uint32_t s_col = (uint32_t)(k0 * 2), r_col = (uint32_t)(n0 * 2);
+    const uint32_t s_col = (uint32_t)(k0 >> 3) * p.s_cb + p.s_part, r_col = (uint32_t)(n0 >> 3) * p.r_cb + p.r_part;
 
     // ---- loader state.  Per lane and piece, constant over the stages: the site / patch cell it loads (relative to the
     // tile origin), its byte offset relative to the tile's first site, its 16-B chunk.  Per stage only the tile origin
@@ -503,7 +508,7 @@ __global__ void __launch_bounds__(256 * NH, 2) k_wgrad_patch(const WPParams p) {
         const int r = (i * NWV + wave) * RPI + lane / LPR;                   // site 0..63
         const int c = (lane % LPR) ^ chunk_swz<RBN, false>(r);
         r_py[i] = r >> 4; r_px[i] = r & 15;
-        r_dlt[i] = (uint32_t)((((int64_t)(r >> 4)) * p.rH + (int64_t)(r & 15) * p.rW) * 2) + (uint32_t)c * 16u;
+        r_dlt[i] = (uint32_t)((((int64_t)(r >> 4)) * p.rH + (int64_t)(r & 15) * p.rW) * 2) + (uint32_t)c * p.r_cb;
         r_chunk[i] = (n0 + c * 8) < p.N ? 1u : 0u;
     }
     constexpr int IPP = (NPP + NWV - 1) / NWV;
@@ -518,7 +523,7 @@ __global__ void __launch_bounds__(256 * NH, 2) k_wgrad_patch(const WPParams p) {
         const int prow = ql * LP + qx;
         const int c = (lane % 8) ^ chunk_swz<RB, false>(prow);
         s_qy[i] = ql - 1; s_qx[i] = qx - 1;                                  // source cell relative to the tile origin
-        s_dlt[i] = (int32_t)((((int64_t)(ql - 1)) * p.sH + (int64_t)(qx - 1) * p.sW) * 2) + c * 16;
+        s_dlt[i] = (int32_t)((((int64_t)(ql - 1)) * p.sH + (int64_t)(qx - 1) * p.sW) * 2) + c * (int32_t)p.s_cb;
         s_ok[i] = (piece < NPP && qx < TW + 2 && (k0 + c * 8) < p.C) ? 1u : 0u;
         s_lds[i] = (uint32_t)((ql * LP + cg * 8) * RB);
     }
@@ -653,7 +658,7 @@ int launch_wgrad(const WGParams &p, dim3 grid, hipStream_t st) {
 
 static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
                       const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes, vnStream stream,
-                      int32_t *chunks_out = nullptr, const int32_t *row_count = nullptr);
+                      int32_t *chunks_out = nullptr, const int32_t *row_count = nullptr, int split_pass = -1);
 
 // tiling of one weight-gradient problem (shared by the launcher and the workspace query)
 struct WGPlan {
@@ -787,6 +792,24 @@ extern "C" int vn_conv_wgrad_partials_counted(const void *src, const void *rows,
                       chunks, row_count);
 }
 
+// One of the three bf16 products of an fp32x3 weight gradient whose operands are stored split (g->dtype VN_F32X3S, strides in
+// 4-byte elements as for every VN_F32X3S tensor): pass 0 = hi(src) . hi(rows), 1 = lo(src) . hi(rows), 2 = hi(src) . lo(rows),
+// each as a run of the bf16 nine-tap patch kernel over the halves where they lie (no [hi | lo] copies).  Only for the
+// geometries of that kernel (3x3 taps, stride 1 in H / W, <= 64 channels, images >= 128 x 128: the 64-channel Conv3d layers,
+// model.py:207-209); VN_EUNSUPPORTED otherwise.  Partials and *chunks as vn_conv_wgrad_partials (the caller lays the three
+// passes' slabs one after the other and the unpack sums them like row chunks).
+extern "C" int vn_conv_wgrad_partials_split_pass(const void *src, const void *rows, const vnConv *g, int32_t pass, void *workspace,
+                                                 size_t workspace_bytes, int32_t *chunks, vnStream stream) {
+    VN_CHECK_ARG(g && chunks && workspace && pass >= 0 && pass <= 2 && g->dtype == VN_F32X3S);
+    if ((g->Cs & 7) || (g->Cr & 7)) return VN_EUNSUPPORTED;
+    vnConv b = *g;
+    b.dtype = VN_BF16;
+    b.src_sB *= 2; b.src_sD *= 2; b.src_sH *= 2; b.src_sW *= 2;
+    b.out_sB *= 2; b.out_sD *= 2; b.out_sH *= 2; b.out_sW *= 2;
+    return wgrad_impl(src, rows, static_cast<float *>(workspace), &b, 0, nullptr, 0, workspace, workspace_bytes, stream, chunks,
+                      nullptr, pass);
+}
+
 extern "C" int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_packed, const vnConv *g,
                                   const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes,
                                   vnStream stream) {
@@ -797,7 +820,7 @@ extern "C" int vn_conv_wgrad_rows(const void *src, const void *rows, float *dw_p
 
 static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const vnConv *g, int32_t split,
                       const int64_t *row_list, int64_t n_rows, void *workspace, size_t workspace_bytes, vnStream stream,
-                      int32_t *chunks_out, const int32_t *row_count) {
+                      int32_t *chunks_out, const int32_t *row_count, int split_pass) {
     const bool partial_only = chunks_out != nullptr;   // leave the chunk partials in the workspace, no reduction
     if (partial_only) dw_packed = static_cast<float *>(workspace);
     VN_CHECK_ARG(src && rows && dw_packed && g);
@@ -830,7 +853,9 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
     p.C = g->Cs; p.N = g->Cr;
     if (split) return VN_EUNSUPPORTED;      // (the [hi|lo] three-pass form of the retired bf16x3 mode: round 5)
     p.x3 = g->dtype == VN_F32X3 || ps;
-    const int wmul = 1;
+    // split_pass >= 0: g describes ONE bf16 half of two split-storage tensors (strides in bf16 elements = twice the 4-byte
+    // ones, a site's channels spread over 2 C bf16 slots): only the patch form reads that layout
+    const int wmul = split_pass >= 0 ? 2 : 1;
     const int64_t sbytes = ((int64_t)(g->B - 1) * g->src_sB + (int64_t)(g->Ds - 1) * g->src_sD +
                             (int64_t)(g->Hs - 1) * g->src_sH + (int64_t)(g->Ws - 1) * g->src_sW + wmul * g->Cs) * esz;
     const int64_t rbytes = row_list ? ((n_rows - 1) * g->out_sW + wmul * g->Cr) * esz
@@ -868,6 +893,9 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
         q.tiles_per_chunk = (int32_t)vn_ceil_div(wp.ntiles, pchunks);
         pchunks = vn_ceil_div(wp.ntiles, q.tiles_per_chunk);
         q.src_bytes = p.src_bytes; q.rows_bytes = p.rows_bytes;
+        q.s_cb = q.r_cb = split_pass >= 0 ? 32u : 16u;
+        q.s_part = split_pass == 1 ? 16u : 0u;      // pass 1: lo(src) . hi(rows)
+        q.r_part = split_pass == 2 ? 16u : 0u;      // pass 2: hi(src) . lo(rows)
         hipStream_t pst = vn_stream(stream);
         const dim3 pgrid((unsigned)pchunks, (unsigned)g->kD, (unsigned)(wp.tiles_n * wp.tiles_k));
         {
@@ -889,6 +917,7 @@ static int wgrad_impl(const void *src, const void *rows, float *dw_packed, const
         }
         return VN_OK;
     }
+    if (split_pass >= 0) return VN_EUNSUPPORTED;      // (geometries outside the patch form)
     // as many row chunks as the workspace has room for partial sums (none: one chunk, accumulated in place)
     int64_t chunks = w.chunks;
     const int64_t room = workspace ? (int64_t)(workspace_bytes / ((size_t)w.dw_elems * sizeof(float))) : 0;

@@ -132,6 +132,7 @@ SIGNATURES = {
     "vn_conv_gather_gemm_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_i32, _P(VnConv), c_vp, c_i64, c_vp, c_i32, c_vp, c_vp]),
     "vn_conv_wgrad_partials": (c_i32, [c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_i64, c_vp, c_sz, c_vp, c_vp]),
     "vn_conv_wgrad_rows": (c_i32, [c_vp, c_vp, c_vp, _P(VnConv), c_vp, c_i64, c_vp, c_sz, c_vp]),
+    "vn_conv_wgrad_partials_split_pass": (c_i32, [c_vp, c_vp, _P(VnConv), c_i32, c_vp, c_sz, c_vp, c_vp]),
     "vn_active_sites_workspace_bytes": (c_sz, [_P(VnConv)]),
     "vn_active_sites": (c_i32, [c_vp, c_i64, _P(VnConv), c_vp, c_sz, c_vp, c_i64, c_vp, c_vp]),
     "vn_fill_rows": (c_i32, [c_vp, c_i32, c_i64, c_i32, c_i64, c_vp, c_vp]),
