@@ -197,6 +197,15 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal aid (NOT a benchmark configuration): VN_BENCH_FORCE_DIST=1 on a one-GPU box creates a ONE-rank RCCL process
+    # group and makes the reducer issue its collectives anyway (VN_FORCE_COLLECTIVE): torch.distributed's nccl backend,
+    # all_reduce(async_op) from the communication stream and the waits run on hardware before an N > 1 run exists
+    force_dist = world == 1 and os.environ.get("VN_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29547")
+        os.environ["VN_FORCE_COLLECTIVE"] = "1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if args.direct_rccl and world > 1 and not share and os.environ.get("VN_DIRECT_RCCL_UNSAFE") != "1":
         # the library's own RCCL entry (vn_allreduce_bucket) has only ever run on a ONE-rank communicator (this pool hands
         # out one GPU per call): it must not be what an 8-GPU measurement silently runs through
@@ -232,7 +241,7 @@ def main():
     if world > 1:
         for p in params:
             dist.broadcast(p.data, 0)
-    if world > 1 or args.force_reducer:
+    if world > 1 or args.force_reducer or force_dist:
         model.grad_reducer = parallel.GradAllReducer(named, direct_rccl=True if args.direct_rccl else None)
 
     frames_np = synth.workload_frames(workload_id, batch=B, frame0=rank * B)   # weak scaling: own frames per rank
@@ -580,7 +589,10 @@ def main():
         if model.grad_reducer is not None:
             red = model.grad_reducer
             res["allreduce"] = {"exposed_ms_per_step": exposed_ms, "bucket_bytes": [int(b["flat"].numel() * 4) for b in red.buckets],
-                                "path": "vn_allreduce_bucket (library RCCL wrapper)" if red.comm is not None else "torch.distributed (%s)" % (dist.get_backend() if world > 1 else "world 1: no collective"),
+                                "path": "vn_allreduce_bucket (library RCCL wrapper)" if red.comm is not None else "torch.distributed (%s)" % (
+                                    dist.get_backend() if world > 1 else ("nccl, ONE-rank group, collectives forced: rehearsal" if force_dist else "world 1: no collective")),
+                                "collective_calls_per_step": red.comm_calls,   # VN_COMM_CALLS (parallel.MERGE_PLANS): buckets merged into fewer calls
+                                "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)"),
                                 "comm_stream": red.comm_stream_kind,      # VN_COMM_STREAM=private | pipeline (default): parallel.py
                                 "rccl_version_bound_by_library": int(_lib.load().vn_comm_rccl_version()),
                                 "torch_nccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
@@ -686,7 +698,7 @@ def main():
         print(json.dumps(res))
     if model.grad_reducer is not None:
         model.grad_reducer.close()          # (the direct path's RCCL communicator)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

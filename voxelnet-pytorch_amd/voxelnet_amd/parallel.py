@@ -31,6 +31,20 @@ BUCKET_PLAN = [
 ]
 
 
+# Which buckets travel in ONE collective call (round 5).  A torch.distributed all_reduce costs ~75 us of host time per call
+# (ProcessGroupNCCL bookkeeping, two stream hops, the scaling launch) — measured with a one-rank RCCL group on one MI355X:
+# five calls per step take the step from 549.8 to 496.6 point-clouds/s (`profiles/r05_ab_one_rank_rccl.md`).  The buckets are
+# slices of ONE flat buffer, so consecutive ones can be reduced by a single call when the LAST of them is ready:
+#   "2" (default): [heads .. block1] = 25.4 MB when block1's gradients are final (the three Conv3d layers' backward, ~1 ms,
+#                  still runs beside it) + [middle_layer, vfe] = 1.8 MB at the end of the VFE backward (the exposed tail);
+#   "5": every bucket by itself (round 2-4's schedule).
+# torch.distributed collectives: "0" (default on the nccl backend) = synchronous op issued from the communication stream,
+# "1" = async_op on ProcessGroupNCCL's internal stream (rounds 2-4).  One-rank RCCL rehearsal on one MI355X
+# (profiles/r05_ab_collective_path.md): async -8.75 %, sync -7.73 % against the same step without a collective.
+_COMM_ASYNC = os.environ.get("VN_COMM_ASYNC")
+MERGE_PLANS = {"5": [(0,), (1,), (2,), (3,), (4,)], "2": [(0, 1, 2), (3, 4)], "1": [(0, 1, 2, 3, 4)]}
+
+
 def group_of(param_name):
     """state_dict key -> bucket group name"""
     if param_name.startswith("feature_net."):
@@ -54,22 +68,43 @@ class GradAllReducer:
         named_params = list(named_params)
         self.buckets = []          # dicts: flat, views{name: tensor}, pending(set), handle
         self.where = {}            # param name -> bucket index
+        # every bucket is a slice of ONE flat buffer (bucket starts aligned to 64 elements), so that consecutive buckets can
+        # travel in one collective call (MERGE_PLANS)
+        sizes = []
+        for groups in plan:
+            members = [(n, p) for n, p in named_params if group_of(n) in groups]
+            sizes.append(sum(p.numel() for _, p in members))
+        starts, tot = [], 0
+        for sz in sizes:
+            starts.append(tot)
+            tot += (sz + 63) // 64 * 64
+        dev0, dt0 = named_params[0][1].device, named_params[0][1].dtype
+        self.flat_all = torch.zeros(max(tot, 1), dtype=dt0, device=dev0)
+        self._span = []            # per bucket: (start, end) in flat_all
         for bi, groups in enumerate(plan):
             members = [(n, p) for n, p in named_params if group_of(n) in groups]
             if not members:
                 continue
             total = sum(p.numel() for _, p in members)
-            dev, dt = members[0][1].device, members[0][1].dtype
-            flat = torch.zeros(total, dtype=dt, device=dev)
+            flat = self.flat_all[starts[bi]:starts[bi] + total]
+            self._span.append((starts[bi], starts[bi] + total))
             views, off = {}, 0
             for n, p in members:
                 views[n] = flat[off:off + p.numel()].view_as(p)
                 off += p.numel()
                 self.where[n] = len(self.buckets)
-            self.buckets.append({"flat": flat, "views": views, "pending": set(), "handle": None, "names": list(views)})
+            self.buckets.append({"flat": flat, "views": views, "pending": set(), "handle": None, "names": list(views),
+                                 "index": len(self.buckets)})
         missing = [n for n, _ in named_params if n not in self.where]
         assert not missing, f"parameters without a bucket: {missing[:3]}"
         self.cuda = self.buckets[0]["flat"].is_cuda
+        merge = os.environ.get("VN_COMM_CALLS", "2")
+        if merge not in MERGE_PLANS or plan is not BUCKET_PLAN or len(self.buckets) != len(BUCKET_PLAN):
+            merge = "5" if len(self.buckets) == len(BUCKET_PLAN) else None
+        self.merge_plan = MERGE_PLANS[merge] if merge else [(i,) for i in range(len(self.buckets))]
+        self.comm_calls = len(self.merge_plan)
+        self._merge_of = {bi: g for g in self.merge_plan for bi in g}
+        self._ready = set()        # buckets of this step whose gradients are final (their merge group waits for all members)
         # The collectives are issued from the input pipeline's stream (voxelnet_amd.voxelize.pipeline_stream), not from a
         # stream of their own: torch.distributed runs an NCCL collective on ITS internal stream, ordered behind the stream it
         # is called from — with a private communication stream the process had five busy streams (training, executor side,
@@ -91,6 +126,10 @@ class GradAllReducer:
                 self.comm_stream = pipeline_stream(self.buckets[0]["flat"].device)
                 self.comm_stream_kind = "pipeline (shared with the input pipeline and the target generator)"
         self.defer_allreduce = False   # True: grad_ready only fills the buckets (HIP-graph capture); allreduce_all() later
+        # rehearsal aid (bench.py VN_BENCH_FORCE_DIST=1 on a ONE-GPU box): issue the collectives even at world size 1, so that
+        # process-group creation over RCCL, all_reduce(async_op) from the communication stream and handle.wait() run on real
+        # hardware before the first multi-GPU run does
+        self.force_collective = os.environ.get("VN_FORCE_COLLECTIVE") == "1" and dist.is_initialized()
         self.comm = None               # ncclComm_t of the direct path
         if direct_rccl is None:
             direct_rccl = os.environ.get("VN_DIRECT_RCCL") == "1"
@@ -136,21 +175,36 @@ class GradAllReducer:
         except Exception:   # noqa: BLE001 - interpreter shutdown
             pass
 
-    def _reduce(self, b):
-        """mean over the ranks of bucket b, in place, on the CURRENT stream; returns a work handle or None"""
-        flat = b["flat"]
+    def _bucket_ready(self, bi):
+        """bucket bi's gradients are final: the collective of its merge group runs when the group is complete -> the flat
+        slice to reduce now, or None"""
+        self._ready.add(bi)
+        g = self._merge_of[bi]
+        if not all(m in self._ready for m in g):
+            return None
+        return self.flat_all[self._span[g[0]][0]:self._span[g[-1]][1]]
+
+    def _reduce(self, flat):
+        """mean over the ranks of a flat gradient slice, in place, on the CURRENT stream; returns a work handle or None"""
         if self.comm is not None:
             from . import _lib
             _lib.call("vn_allreduce_bucket", self.comm, flat.data_ptr(), flat.numel(), 1.0 / self.world,
                       _lib.raw_stream())
             return None
+        # async_op=False (VN_COMM_ASYNC=0): torch >= 2.7 runs a synchronous NCCL collective ON THE CALLER'S STREAM — here the
+        # communication stream — instead of on ProcessGroupNCCL's internal stream behind two event hops: one busy HIP
+        # stream less in the process (the runtime maps streams onto four hardware queues)
+        async_op = (_COMM_ASYNC != "0") if _COMM_ASYNC is not None else dist.get_backend(self.pg) != "nccl"
+        if dist.get_backend(self.pg) == "nccl":      # RCCL averages itself (ncclAvg): no scaling launch in front of the collective
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.pg, async_op=async_op)
         flat.div_(self.world)
-        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.pg, async_op=async_op)
 
     def reset(self):
         for b in self.buckets:
             b["pending"] = set(b["names"])
             b["handle"] = None
+        self._ready = set()
 
     def grad_ready(self, name, grad):
         """called as soon as a parameter's gradient exists (in backward order)"""
@@ -162,16 +216,18 @@ class GradAllReducer:
             self._launch(b)
 
     def _launch(self, b):
-        if (self.world == 1 and self.comm is None) or self.defer_allreduce:
+        if (self.world == 1 and self.comm is None and not self.force_collective) or self.defer_allreduce:
             return
+        flat = self._bucket_ready(b["index"])
         if self.comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
-            with torch.cuda.stream(self.comm_stream):
-                b["handle"] = self._reduce(b)
-        else:
-            b["handle"] = self._reduce(b)
+            self.comm_stream.wait_event(ev)          # (every member of a merge group puts its wait on the comm stream)
+            if flat is not None:
+                with torch.cuda.stream(self.comm_stream):
+                    b["handle"] = self._reduce(flat)
+        elif flat is not None:
+            b["handle"] = self._reduce(flat)
 
     def launch_bucket(self, bi, wait_fn=None, after_event=None, prelude=None):
         """All-reduce bucket bi on the comm stream once (a) wait_fn(comm_stream) has made the comm stream wait for whatever
@@ -181,11 +237,13 @@ class GradAllReducer:
         b = self.buckets[bi]
         b["pending"] = set()
         st = self.comm_stream
+        live = (self.world > 1 or self.comm is not None or self.force_collective) and not self.defer_allreduce
         if st is None:                       # CPU tensors / no side stream: plain, in order
             if prelude is not None:
                 prelude()
-            if (self.world > 1 or self.comm is not None) and not self.defer_allreduce:
-                b["handle"] = self._reduce(b)
+            flat = self._bucket_ready(bi) if live else None
+            if flat is not None:
+                b["handle"] = self._reduce(flat)
             return
         with torch.cuda.stream(st):
             if after_event is not None:
@@ -194,14 +252,15 @@ class GradAllReducer:
                 wait_fn(st)
             if prelude is not None:
                 prelude()
-            if (self.world > 1 or self.comm is not None) and not self.defer_allreduce:
-                b["handle"] = self._reduce(b)
+            flat = self._bucket_ready(bi) if live else None
+            if flat is not None:
+                b["handle"] = self._reduce(flat)
 
     def allreduce_all(self):
         """deferred mode: all-reduce every (already filled) bucket now, largest first, and wait"""
         if self.world == 1 and self.comm is None:
             return
-        hs = [self._reduce(b) for b in self.buckets]
+        hs = [self._reduce(self.flat_all[self._span[g[0]][0]:self._span[g[-1]][1]]) for g in self.merge_plan]
         for h in hs:
             if h is not None:
                 h.wait()
