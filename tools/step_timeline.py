@@ -1,7 +1,7 @@
 """Two-stream timeline of ONE native-executor train step from the executor's own HIP events (vn_net_timing_begin/_read:
 every launch bracketed on its stream; start offsets relative to the first launch): which launches of the main chain
 run beside which weight gradients, where a stream sits idle, what the tail looks like.
-usage: python tools/step_timeline.py [--csv out.csv]"""
+usage: python tools/step_timeline.py [--csv out.csv] [--dense]   (--dense: BASELINE configs[4], batch 4, T = 64)"""
 import ctypes
 import os
 import sys
@@ -23,9 +23,11 @@ M.set_precision("bf16")
 torch.manual_seed(0)
 model = M.RPN3D("Car").to(dev).train()
 opt = ClipSGD(list(model.parameters()), 0.01, 5.0)
-grid = grid_config("Car")
-frames = [torch.from_numpy(f).to(dev) for f in synth.workload_frames(2, batch=2)]
-targets = bench.synthetic_targets(2, 200, 176, 99, dev)
+DENSE = "--dense" in sys.argv
+NB = 4 if DENSE else 2
+grid = grid_config("Car", T=64) if DENSE else grid_config("Car")
+frames = [torch.from_numpy(f).to(dev) for f in synth.workload_frames(5 if DENSE else 2, batch=NB)]
+targets = bench.synthetic_targets(NB, 200, 176, 99, dev)
 fc = [voxelize_device(p, grid, b, coord_cols=4) for b, p in enumerate(frames)]
 feats, coords = [x[0] for x in fc], [x[1] for x in fc]
 

@@ -588,6 +588,11 @@ __global__ void __launch_bounds__(256) k_zero_many(const ZeroJobs z) {
     float *p = z.ptr[blockIdx.x];
     for (int i = threadIdx.x; i < z.len[blockIdx.x]; i += 256) p[i] = 0.f;
 }
+int zero_many(const ZeroJobs &z, hipStream_t st) {
+    k_zero_many<<<z.n, 256, 0, st>>>(z);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
 
 // First middle layer (tuning aid VN_M0_BN, bits; default 31 = all on): 1 flagged forward apply (k_bn_apply<true>: the ~90 %
 // of rows without a flag are written without reading y), 2 flagged backward reduce, 4 list-based backward apply, 8 the
@@ -1069,7 +1074,11 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // the three Conv3d gradients are left for the final unpack.
     const bool tail_balance = ws != hs && cfg->defer_join && !cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
     const bool bucket_mode = ws != hs && cfg->bucket_events && seg_begin == 0 && seg_end == NL + 1;
-    const bool m0_on_main = tail_balance || bucket_mode;
+    // ... while that weight gradient is short: it is a K x 27-tap row-list launch, 38 us at the car's 12 k voxels but 0.45 ms at
+    // the dense config's 160 k — there it sat in front of the first layer's data gradient and the whole VFE backward (the
+    // step's last millisecond) while the side stream idled (round 5, `tools/step_timeline.py --dense`): above 40 k voxels it
+    // goes to the side stream like every other weight gradient
+    const bool m0_on_main = (tail_balance || bucket_mode) && K <= 40000;
     int u_early = 0;
     hipEvent_t box_ev = nullptr;       // recorded on the side stream behind the box sums of middle_layer.1's dy
     int64_t fused_rows[NL] = {0};      // > 0: layer's BatchNorm-backward slab was written by the data gradient above it (rows)
@@ -1152,7 +1161,15 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         // weight gradient: at once when this layer runs on the side stream itself, else queued for the next flush
         if (on_side) RT(launch_wgrad(l, wstream));
         else if (l == 0 && m0_on_main) RT(launch_wgrad(l, stream));
-        else pending[npend++] = l;
+        else {
+            pending[npend++] = l;
+            // The three Conv3d layers on their DENSE backward route (no list-based BatchNorm backward: the dense config's 160 k
+            // voxels): their weight gradients are the longest of the step (0.45-0.73 ms at batch 4) and only need dy — fork
+            // HERE, in front of the data gradient, not behind it: the side stream sat idle for the 0.28-0.41 ms of each of
+            // these data gradients and then finished the step alone (tools/step_timeline.py --dense, round 5).  The car /
+            // pedestrian steps (list route) keep their schedule: there the early fork measured nothing (round 4).
+            if (l <= L_M2 && !P.list_bwd && ws != hs && single_call) RT(flush());
+        }
         if (l == 0 && cfg->sparse_first) {
             const int64_t rs[4] = {0, 0, 0, 128};
             vnConv gw = geom(dy, P.in_dims[0], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
@@ -1243,8 +1260,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             ZeroJobs part{};
             part.n = zj.n - z_done;
             for (int i = 0; i < part.n; ++i) { part.ptr[i] = zj.ptr[z_done + i]; part.len[i] = zj.len[z_done + i]; }
-            k_zero_many<<<part.n, 256, 0, ws>>>(part);
-            VN_LAUNCH_STATUS();
+            RTT(T_MISC, -1, 0.0, 0.0, wstream, zero_many(part, ws));
             z_done = zj.n;
         }
         VN_HIP(hipEventRecord(net->bucket_ev[b][1], ws));
@@ -1286,8 +1302,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
         RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack + u_early, nu - u_early), wstream, vn_unpack_wgrads_batch(unpack + u_early, nu - u_early, wstream));
         RT(after_unpack(u_early, nu, wstream));
         if (zj.n > 0) {
-            k_zero_many<<<zj.n, 256, 0, ws>>>(zj);
-            VN_LAUNCH_STATUS();
+            RTT(T_MISC, -1, 0.0, 0.0, wstream, zero_many(zj, ws));
         }
         return VN_OK;
     }
@@ -1300,8 +1315,7 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     RTT(T_UNPACK, -1, 0.0, unpack_bytes(unpack, nu), stream, vn_unpack_wgrads_batch(unpack, nu, stream));
     RT(after_unpack(0, nu, stream));
     if (zj.n > 0) {
-        k_zero_many<<<zj.n, 256, 0, hs>>>(zj);
-        VN_LAUNCH_STATUS();
+        RTT(T_MISC, -1, 0.0, 0.0, stream, zero_many(zj, hs));
     }
     return VN_OK;
 }
