@@ -301,3 +301,31 @@ def test_conv3d_weight_gradient_passes_read_the_split_halves_in_place(x3):
     with pytest.raises(_lib.VoxelnetHipError):
         _lib.call("vn_conv_wgrad_partials_split_pass", x2.data_ptr(), x2.data_ptr(), ctypes.byref(g2), 0, x2.data_ptr(), 1 << 20,
                   ctypes.byref(ch), E.stream())
+
+
+def test_per_layer_backward_runs_in_the_mode_of_its_forward(golden):
+    """per-layer orchestration (native_executor = False): a set_precision() between a forward and its backward must not
+    change how the backward evaluates its products (round-4 advisor: the operand dtype and the packed-weight format were
+    read from a process global at call time).  Forward in fp32x3, precision switched to fp32, backward: the gradients are
+    BIT-identical to a forward + backward entirely in fp32x3."""
+    from test_gpu_model import make_model, split
+    from voxelnet_amd import model as M
+    g = golden("middle_tiny_car")
+    feats, coords = split(g)
+    feats, coords = [f.to("cuda:0") for f in feats], [c.to("cuda:0") for c in coords]
+    grads = {}
+    try:
+        for switch in (False, True):
+            m = make_model("Car", 16, 24, "fp32x3")
+            m.native_executor = False
+            m.train()
+            prob, reg = m.detect(feats, coords)
+            if switch:
+                M.set_precision("fp32")
+            torch.autograd.backward([prob, reg], [torch.ones_like(prob) * 0.1, torch.ones_like(reg) * 0.1])
+            torch.cuda.synchronize()
+            grads[switch] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    finally:
+        M.set_precision("bf16")
+    for k in grads[False]:
+        assert torch.equal(grads[False][k], grads[True][k]), k

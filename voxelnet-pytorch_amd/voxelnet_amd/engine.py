@@ -45,6 +45,24 @@ X3 = {"on": False}
 VN_F32X3 = 2
 
 
+class _x3_as_saved:
+    """a layer's backward evaluates its products the way its FORWARD did: the operand dtype (fp32 vs fp32x3) is a property
+    of the saved state, not of whatever the process-global precision is when backward() happens to run (round-4 advisor:
+    a set_precision() between a forward and its backward switched the operand dtype and the packed-weight format under
+    the saved tensors)"""
+
+    def __init__(self, st):
+        self.want = bool(getattr(st, "x3", X3["on"]))
+
+    def __enter__(self):
+        self.prev = X3["on"]
+        X3["on"] = self.want
+
+    def __exit__(self, *exc):
+        X3["on"] = self.prev
+        return False
+
+
 def is_f32_storage(mode):
     return mode in ("fp32", "fp32x3")
 
@@ -245,7 +263,7 @@ def gather_gemm(src, wp, bias, out, spec_k, Cs, Cr, mul, tmul, pad, div, row_dim
 
 class LayerState:
     """What a layer's backward needs (saved by layer_forward)."""
-    __slots__ = ("spec", "x", "y", "stats", "a", "in_dims", "out_dims", "training")
+    __slots__ = ("spec", "x", "y", "stats", "a", "in_dims", "out_dims", "training", "x3")
 
 
 def _bev_slices(B, D):
@@ -278,6 +296,7 @@ def layer_forward(spec, x, params, buffers, training, mode, out=None, y_dtype=No
         slab = torch.empty((slab_rows, 2, spec.cout), dtype=torch.float32, device=dev)
     gather_gemm(x, wp, bias, y, spec.k, spec.cin, spec.cout, mul, tmul, pad, div, odims, stats=slab)
     st = LayerState()
+    st.x3 = bool(X3["on"])
     st.spec, st.x, st.y, st.in_dims, st.out_dims = spec, x, y, x.dims, odims
     st.stats, st.a, st.training = None, None, bool(training)
     if not spec.bn:
@@ -324,6 +343,11 @@ def wgrad_workspace(g, split, n_rows, dev):
 
 
 def layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=False, bev_da=False):
+    with _x3_as_saved(st):
+        return _layer_backward(st, da, params, mode, need_dx, dx, dx_accumulate, bev_da)
+
+
+def _layer_backward(st, da, params, mode, need_dx=True, dx=None, dx_accumulate=False, bev_da=False):
     """da: Rows-like gradient w.r.t. the layer output activation (plain rows, f32 or bf16,
     any row stride) — or, for a layer without BN, w.r.t. the conv output as [hi|lo] Rows.
     Returns (grads dict, dx Rows or None)."""
@@ -459,6 +483,7 @@ def first_layer_forward_sparse(spec, x, coord, params, buffers, training, mode):
                   ctypes.byref(g), lst.data_ptr(), cap, cnt.data_ptr(), 0,
                   slab.data_ptr() if slab is not None else None, stream())
     st = LayerState()
+    st.x3 = bool(X3["on"])
     st.spec, st.x, st.y, st.in_dims, st.out_dims, st.training = spec, x, y, x.dims, odims, bool(training)
     stats = torch.empty(4 * spec.cout, dtype=torch.float32, device=dev)
     if slab is not None:
@@ -477,6 +502,11 @@ def first_layer_forward_sparse(spec, x, coord, params, buffers, training, mode):
 
 
 def first_layer_backward_sparse(st, da, params, mode, coord, vw_rows):
+    with _x3_as_saved(st):
+        return _first_layer_backward_sparse(st, da, params, mode, coord, vw_rows)
+
+
+def _first_layer_backward_sparse(st, da, params, mode, coord, vw_rows):
     """backward of first_layer_forward_sparse: BN backward on the dense rows, then weight gradient and data
     gradient ONLY over the K occupied voxels (row-list modes of k_wgrad / k_gather_gemm).
     vw_rows: (K,Cin) voxel features in the operand dtype.  -> (grads, d_vw (K,Cin) fp32)"""

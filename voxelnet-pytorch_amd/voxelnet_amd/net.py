@@ -56,6 +56,7 @@ def middle_forward(dense, P, Bf, block1_stride, training, mode, sparse=None):
     st.layers = {}
     st.block1_stride = block1_stride
     st.mode = mode
+    st.x3 = bool(E.X3["on"])       # (the backward runs its products as this forward did: engine._x3_as_saved)
     split = E.is_split(mode)
     dev = dense.t.device
     B = dense.B
@@ -105,6 +106,11 @@ def middle_forward(dense, P, Bf, block1_stride, training, mode, sparse=None):
 def middle_backward(st, d_prob, d_reg, P, need_dx=True, on_grads=None):
     """-> ({name: {weight,bias,gamma,beta}}, d_dense Rows (plain f32/bf16) or None).
     on_grads(layer_name, grads): called as soon as a layer's parameter gradients exist (DDP bucketing)."""
+    with E._x3_as_saved(st):
+        return _middle_backward(st, d_prob, d_reg, P, need_dx, on_grads)
+
+
+def _middle_backward(st, d_prob, d_reg, P, need_dx=True, on_grads=None):
     mode = st.mode
     split = E.is_split(mode)
     L = st.layers
