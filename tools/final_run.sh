@@ -27,7 +27,11 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_V
 # what bounds the VFE kernels: two counter passes of their own
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/fpmc_vfe_a -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_vfe_a.log 2>&1
 rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY -d $O/fpmc_vfe_b -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_vfe_b.log 2>&1
+# the same per-kernel view for the fp32x3 mode (its roofline object in profiles/r05_bench_fp32x3.json comes from HIP events; this is the rocprofv3 side)
+rocprofv3 --kernel-trace --stats -d $O/fstats_x3 -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --precision fp32x3 --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --windows 1 > $O/fstats_x3.log 2>&1
 cd $GRAFT_REPO_ROOT
+python tools/trace_summary.py $(ls gpurun_out/fstats_x3/*/*kernel_trace.csv gpurun_out/fstats_x3/*kernel_trace.csv 2>/dev/null | head -1) 10 > gpurun_out/${R}_fp32x3_per_step.txt 2>&1 || true
+cp $(ls gpurun_out/fstats_x3/*/*kernel_stats.csv gpurun_out/fstats_x3/*kernel_stats.csv 2>/dev/null | head -1) gpurun_out/${R}_fp32x3_kernel_stats.csv || true
 python tools/pmc_counters.py k_vfe 3 gpurun_out/fpmc_vfe_a gpurun_out/fpmc_vfe_b > gpurun_out/${R}_pmc_vfe.txt 2>&1 || true
 # (every post-processing script takes "the last 3 steps of the profiled run" and finds the step boundaries itself: the
 #  profiled command also runs warm-up / window / host-enqueue steps, 17 in all — round 3's per-step header divided all of

@@ -8,6 +8,7 @@ conventions and quirks, the positive / negative assignment and the regression en
 in the layouts `RPN3D.loss` takes — no float64 host arrays, no six host-to-device copies per step (model.py:327-332).
 There is no CPU fallback: the HIP library must be present."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -102,6 +103,11 @@ def gt_standup_boxes(gt):
     return out
 
 
+# host-side memo of label text -> boxes (VN_LABEL_CACHE=0: parse every time, as the reference does; the DEVICE target
+# generation runs every step either way — only host work is remembered, and the step is GPU-bound: same point-clouds/s)
+_LABEL_CACHE = os.environ.get("VN_LABEL_CACHE", "1") != "0"
+
+
 class TargetGenerator:
     """Device-resident anchors of one class + the launch: `gen(labels)` -> (pos_equal_one (B,h,w,2), neg_equal_one
     (B,h,w,2), targets (B,h,w,14)) float32 tensors on `device`, the arrays of utils.generate_targets (utils.py:473)."""
@@ -134,7 +140,7 @@ class TargetGenerator:
             if n:
                 gt[b, :n] = boxes
                 key = boxes.tobytes()
-                su = self._standup.get(key)
+                su = self._standup.get(key) if _LABEL_CACHE else None
                 if su is None:
                     if len(self._standup) >= 8192:
                         self._standup.clear()
@@ -169,7 +175,7 @@ class TargetGenerator:
         boxes = []
         for label in labels:
             key = (tuple(label), coordinate)
-            hit = self._parsed.get(key)
+            hit = self._parsed.get(key) if _LABEL_CACHE else None
             if hit is None:
                 if len(self._parsed) >= 8192:
                     self._parsed.clear()
