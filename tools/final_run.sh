@@ -9,6 +9,15 @@ python -m pytest tests/ -m gpu -x -q > gpurun_out/final_tests.log 2>&1
 tail -3 gpurun_out/final_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final_smoke.log 2>&1
 tail -1 gpurun_out/final_smoke.log
+# HBM traffic of THIS build first (two PMC passes of their own, never combined with tracing): bench.py only reports
+# `roofline.traffic` from a profiles/*_pmc_traffic.json that names the running library build (vn_build_id), so the passes
+# run before the bench and their summary goes to profiles/ on the box as well as to gpurun_out/ (which travels back)
+( cd /tmp && export TMPDIR=/tmp && O=$GRAFT_REPO_ROOT/gpurun_out && \
+  rocprofv3 --pmc FETCH_SIZE -d $O/fpmc_fetch -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_fetch.log 2>&1 && \
+  rocprofv3 --pmc WRITE_SIZE -d $O/fpmc_write -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_write.log 2>&1 )
+python tools/pmc_traffic.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 > gpurun_out/${R}_pmc_traffic_per_kernel.txt
+python tools/pmc_family.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 gpurun_out/${R}_pmc_traffic.json > /dev/null
+cp gpurun_out/${R}_pmc_traffic.json profiles/${R}_pmc_traffic.json
 python bench.py > gpurun_out/final_bench.json 2> gpurun_out/final_bench.err
 cat gpurun_out/final_bench.json
 python bench.py --config ped --no-cpu-baseline > gpurun_out/final_bench_ped.json 2> gpurun_out/final_bench_ped.err
@@ -21,8 +30,6 @@ tail -c 600 gpurun_out/final_bench_n2_rehearsal.json
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out
 rocprofv3 --kernel-trace --stats -d $O/fstats -o s --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-parity-mode --windows 1 > $O/fstats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $O/fpmc_fetch -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $O/fpmc_write -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_write.log 2>&1
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE -d $O/fpmc_mfma -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_mfma.log 2>&1
 # what bounds the VFE kernels: two counter passes of their own
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $O/fpmc_vfe_a -o p --output-format csv -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-parity-mode --no-kernel-timer --windows 1 > $O/fpmc_vfe_a.log 2>&1
@@ -36,8 +43,6 @@ python tools/pmc_counters.py k_vfe 3 gpurun_out/fpmc_vfe_a gpurun_out/fpmc_vfe_b
 # (every post-processing script takes "the last 3 steps of the profiled run" and finds the step boundaries itself: the
 #  profiled command also runs warm-up / window / host-enqueue steps, 17 in all — round 3's per-step header divided all of
 #  them by 3)
-python tools/pmc_traffic.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 > gpurun_out/${R}_pmc_traffic_per_kernel.txt
-python tools/pmc_family.py gpurun_out/fpmc_fetch gpurun_out/fpmc_write 3 gpurun_out/${R}_pmc_traffic.json
 python tools/pmc_mfma.py gpurun_out/fpmc_mfma 3 gpurun_out/${R}_pmc_mfma_per_kernel.txt | head -40
 python tools/trace_summary.py $(ls gpurun_out/fstats/*/*kernel_trace.csv gpurun_out/fstats/*kernel_trace.csv 2>/dev/null | head -1) 10 > gpurun_out/${R}_bench_per_step.txt 2>&1 || true
 cp $(ls gpurun_out/fstats/*/*kernel_stats.csv gpurun_out/fstats/*kernel_stats.csv 2>/dev/null | head -1) gpurun_out/${R}_bench_kernel_stats.csv || true
