@@ -89,3 +89,21 @@ def test_every_tuning_knob_is_listed_and_the_environment_is_read_in_one_place():
             assert "getenv" not in text, f"{f} reads the environment itself; route it through vn_knob()"
     assert used <= listed, f"knobs missing from abi.hip's KNOBS table: {sorted(used - listed)}"
     assert listed <= used, f"stale entries in abi.hip's KNOBS table: {sorted(listed - used)}"
+
+
+def test_build_id_names_the_sources_the_library_was_built_from():
+    """vn_build_id() = first 12 hex digits of the SHA-256 over csrc/*.hip (sorted), common.h and the public header — the
+    identity profiles/*_pmc_traffic.json carries and bench.py compares before it reports `roofline.traffic`.  (Round 5: a
+    phony make prerequisite once left the id ONE BUILD BEHIND the sources; it is now computed when the Makefile is read.)"""
+    import glob
+    import hashlib
+    from voxelnet_amd import _lib
+    if os.environ.get("VN_LIB_PATH"):
+        pytest.skip("another build of the library is loaded (VN_LIB_PATH)")
+    csrc = os.path.join(ROOT, "voxelnet-pytorch_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(csrc, "*.hip"))) + [os.path.join(csrc, "common.h"), os.path.join(ROOT, "include", "voxelnet_hip.h")]:
+        h.update(open(f, "rb").read())
+    lib = _lib.load()
+    assert lib.vn_build_id().decode() == h.hexdigest()[:12]
+    assert ("build " + h.hexdigest()[:12]) in lib.vn_build_info().decode()
