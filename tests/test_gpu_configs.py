@@ -271,7 +271,7 @@ def test_dense_config_vfe_full_K_and_train_step():
     assert peak < 48.0
 
 
-def test_dense_config_fp32_step_vs_oracle():
+def test_dense_config_fp32_step_vs_oracle():      # (and fp32x3, since round 5)
     """BASELINE configs[4] at batch 1 (one ~300k-point frame, K ~ 40k voxels, T = 64) as a WHOLE step in the fp32 parity
     mode against the CPU oracle: at this voxel count the native executor leaves the sparse routes of the first layer's
     boundary (the active-site list would cover every site: csrc/runtime.hip make_plan, `acap * 10 <= M * 3`) and runs
@@ -292,27 +292,34 @@ def test_dense_config_fp32_step_vs_oracle():
     dr = torch.from_numpy((rng.standard_normal((1, 14, 200, 176)) * 1e-2).astype(np.float32))
     rp, rr, ref = tr.forward_backward([f.cpu() for f in feats], [c.cpu() for c in coords], tr.make_state_dict("Car"),
                                       (10, 400, 352), "Car", dp, dr)
-    M.set_precision("fp32")
-    m = M.RPN3D("Car")
-    m.load_state_dict(tr.make_state_dict("Car"))
-    m.feature_net._grid = grid
-    m = m.to(DEV).train()
-    prob, reg = m.detect(feats, coords)
-    ep, er = rel_err(prob, rp), rel_err(reg, rr)
-    print(f"dense config, batch 1, fp32 mode vs CPU oracle: K = {K}, prob {ep:.2e}, reg {er:.2e}")
-    assert ep < 1e-3 and er < 1e-3, (ep, er)
-    torch.autograd.backward([prob, reg], [dp.to(DEV), dr.to(DEV)])
-    torch.cuda.synchronize()
-    worst = (None, 0.0)
-    for k, p in m.named_parameters():
-        if k.endswith("conv.bias") and "prob_conv" not in k and "reg_conv" not in k or k.endswith("deconv.bias"):
-            continue
-        r = ref[k].double()
-        l2 = float((p.grad.double().cpu() - r).norm() / (r.norm() + 1e-30))
-        if k.startswith("feature_net") or "middle_layer" in k:
-            print(f"   {k:50s} rel L2 {l2:.2e}")
-        if l2 > worst[1]:
-            worst = (k, l2)
-    print("dense config, batch 1: worst gradient", worst)
-    assert worst[1] < 0.1, worst
-    M.set_precision("bf16")
+    # both fp32-grade modes against the one oracle run: the exact fp32 mode and fp32x3 (round 5: the dense route of the
+    # first layers on split storage, the Conv3d weight gradients forked in front of their data gradients)
+    try:
+        for mode in ("fp32", "fp32x3"):
+            M.set_precision(mode)
+            m = M.RPN3D("Car")
+            m.load_state_dict(tr.make_state_dict("Car"))
+            m.feature_net._grid = grid
+            m = m.to(DEV).train()
+            prob, reg = m.detect(feats, coords)
+            ep, er = rel_err(prob, rp), rel_err(reg, rr)
+            print(f"dense config, batch 1, {mode} mode vs CPU oracle: K = {K}, prob {ep:.2e}, reg {er:.2e}")
+            assert ep < 1e-3 and er < 1e-3, (mode, ep, er)
+            torch.autograd.backward([prob, reg], [dp.to(DEV), dr.to(DEV)])
+            torch.cuda.synchronize()
+            worst = (None, 0.0)
+            for k, p in m.named_parameters():
+                if k.endswith("conv.bias") and "prob_conv" not in k and "reg_conv" not in k or k.endswith("deconv.bias"):
+                    continue
+                r = ref[k].double()
+                l2 = float((p.grad.double().cpu() - r).norm() / (r.norm() + 1e-30))
+                if k.startswith("feature_net") or "middle_layer" in k:
+                    print(f"   {mode} {k:50s} rel L2 {l2:.2e}")
+                if l2 > worst[1]:
+                    worst = (k, l2)
+            print(f"dense config, batch 1, {mode}: worst gradient", worst)
+            assert worst[1] < 0.1, (mode, worst)
+            del m, prob, reg
+            torch.cuda.empty_cache()
+    finally:
+        M.set_precision("bf16")
