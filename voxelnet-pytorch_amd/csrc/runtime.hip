@@ -329,9 +329,11 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
         }
         P->bslab[l] = (float *)A.take(bslab_floats * sizeof(float));
         P->dy[l] = rows_new(P->adt, P->odims[l], sp.cout);
-        // (fp32x3: dy of every layer whose two consumers — data gradient and weight gradient — are plain launches is stored
-        //  split by the BatchNorm backward apply; layers 0 and 1 have the sparse routes and box sums)
-        if (P->x3_store && l >= 2) P->dy[l].dtype = VN_F32X3S;
+        // (fp32x3: dy of every layer whose consumers read it as a convolution / weight-gradient operand is stored split by the
+        //  BatchNorm backward apply.  Layer 1 on its sparse route too: its data gradient is a row-list launch, its weight
+        //  gradient reads dy against the split-stored rows of vn_act_delta_rows, the box sums add hi + lo.  Not layer 0 (its
+        //  rows operand is the fp32 voxel features) and not layer 1 on the dense route (its source is layer 0's fp32 output))
+        if (P->x3_store && (l >= 2 || (l == 1 && P->sparse_w1))) P->dy[l].dtype = VN_F32X3S;
         // data gradient buffer of the layer's input (shared where two consumers accumulate)
         P->dx[l] = Rows{};
     }
@@ -994,7 +996,8 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
             const Rows &a0 = P.a[0];
             RTT(T_MISC, l, 0.0, 0.0, wstream,
                 vn_act_delta_rows(a0.ptr, (vnDtype)a0.dtype, sp.cin, P.odims[0][0], P.odims[0][1], P.odims[0][2], P.stats[0],
-                                  L[0].bias, (vnDtype)P.y[0].dtype, 1, P.alist, P.acount, P.acap, P.drows, (vnDtype)a0.dtype, wstream));
+                                  L[0].bias, (vnDtype)P.y[0].dtype, 1, P.alist, P.acount, P.acap, P.drows,
+                                  dy.dtype == VN_F32X3S ? VN_F32X3S : (vnDtype)a0.dtype, wstream));
             const int np[3] = {-sp.p[0], -sp.p[1], -sp.p[2]};
             const int64_t rs[4] = {0, 0, 0, sp.cin};
             vnConv gl = geom(dy, P.in_dims[l], C, sp.cin, sp.k, ONE, NEG, np, sp.s, rs);
