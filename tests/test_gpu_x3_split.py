@@ -219,9 +219,8 @@ def test_batchnorm_passes_write_split_storage():
 
 
 def test_executor_split_storage_matches_the_in_register_form(monkeypatch):
-    """The whole fp32x3 step with split storage against the same step with every split made in the kernels
-    (VN_X3_SPLIT_STORE is read once per process: the comparison runs the second form in a child-free way — through
-    vnNetConfig we cannot switch it, so this test only checks the split-storage step against the EXACT fp32 mode)."""
+    """The whole fp32x3 step (split storage) against the EXACT fp32 step at full size: maps within 5e-4 of each other
+    (the per-kernel checks above are the tight ones; round 4 measured 8.8e-5 / 6.7e-5 with the in-kernel splits)."""
     import bench
     from voxelnet_amd import model as M, synth
     from voxelnet_amd.config import grid_config

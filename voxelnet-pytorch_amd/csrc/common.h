@@ -15,12 +15,10 @@
 // else `default`; callers keep the result in a function-local static (read once per process).  vn_build_info() reports
 // every listed variable that is set, so a stray VN_* in the environment shows up in bench.py's JSON line.
 int vn_knob(const char *name, int dflt);
-// fp32x3: does a conv weight operand with rows of K channels hold hi / lo bf16 granules (vn_pack_weight, VN_F32X3)?  The
-// packer and the convolution entry points both ask here.  (tuning aid VN_X3_PRESPLIT=0: fp32 weights, split in registers)
-inline bool vn_x3_presplit(int K) {
-    static const int on = vn_knob("VN_X3_PRESPLIT", 1);
-    return on && K > 0 && K % 32 == 0;
-}
+// fp32x3: a conv weight operand with rows of K channels holds hi / lo bf16 granules (vn_pack_weight, VN_F32X3) when K is a
+// whole number of 32-channel chunks; other K (the heads' 16-column data-gradient operand) stay fp32 and are split in registers.
+// The packer and the convolution entry points both ask here.
+inline bool vn_x3_presplit(int K) { return K > 0 && K % 32 == 0; }
 
 static inline hipStream_t vn_stream(vnStream s) { return reinterpret_cast<hipStream_t>(s); }
 static inline int64_t vn_ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -89,7 +89,6 @@ struct Plan {
     Rows dy[NL], dx[NL];
     float *dwp[NL]; size_t dwp_bytes[NL];   // row-chunk partials of the weight gradient (vn_conv_wgrad_partials)
     // heads
-    void *x3_src, *x3_rows;   // fp32x3: [hi|lo] bf16 copies of middle_layer.2's input and dy (its weight gradient runs on the bf16 patch kernel)
     bool x3;          // cfg->mode == 2 ("fp32x3"): fp32 storage, the convolutions' and weight gradients' products as three bf16 MFMAs
     bool x3_store;    // fp32x3: activations / gradients that feed convolutions and weight gradients are stored split (VN_F32X3S)
     bool m2_passes;   // x3_store: middle_layer.2's weight gradient as three in-place bf16 passes of the nine-tap patch kernel
@@ -171,7 +170,6 @@ vnConv x3_wgrad_geom(const Plan &P, int l, void *src_hl, void *rows_hl, int src_
     return geom(xs, P.odims[l], sp.cin, sp.cout, sp.k, sp.s, ONE, sp.p, ONE, rs);
 }
 int m0_bn_knob();
-int x3_split_store_on();
 bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     // depth: every D whose three Conv3d layers (model.py:207-209: stride 2 / pad 1, stride 1 / no pad, stride 2 / pad 1)
     // end at depth 2, the BEV fold of model.py:262 — D = 9 ... 12 (the reference's grids are all D = 10; round 4 lifted the
@@ -183,7 +181,7 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
     layer_table(c->block1_stride, P->spec);
     const bool f32 = c->mode != 0;      // modes 1 (fp32) and 2 (fp32x3) store everything in fp32
     P->x3 = c->mode == 2;
-    P->x3_store = P->x3 && x3_split_store_on() && vn_x3_presplit(32);
+    P->x3_store = P->x3;      // (round 4's in-kernel splits of every operand left the library with their knob: DESIGN_HISTORY.md)
     P->m2_passes = false;     // (set below, once the dims are known)
     P->esz = f32 ? 4 : 2;
     P->adt = f32 ? VN_F32 : VN_BF16;
@@ -364,15 +362,10 @@ bool make_plan(const vnNetConfig *c, int64_t K, char *base, Plan *P) {
                 b = ask(P->in_dims[0], sp.cout, sp.cin, sp.k, K > 0 ? K : 1);
             } else if (l == 1 && P->sparse_w1) {
                 b = ask(P->in_dims[1], sp.cout, sp.cin, sp.k, P->acap);
-            } else if (l == L_M2 && P->x3 && !(P->x3_store && !P->m2_passes)) {
-                // three passes of the bf16 kernel: over the split-stored operands in place (x3_store; nine-tap patch form only)
-                // or over [hi|lo] copies (x3_wgrad_geom)
+            } else if (l == L_M2 && P->x3_store && P->m2_passes) {
+                // three passes of the bf16 nine-tap patch kernel over the split-stored operands in place
                 const vnConv gb = x3_wgrad_geom(*P, l, nullptr, nullptr, 0, 0);
                 b = 3 * vn_conv_wgrad_workspace_bytes(&gb, 0, 0);
-                if (!P->x3_store) {      // (split storage: the passes read the halves where the BatchNorm passes left them)
-                    P->x3_src = A.take((size_t)B * P->in_dims[l][0] * P->in_dims[l][1] * P->in_dims[l][2] * 2 * sp.cin * 2);
-                    P->x3_rows = A.take((size_t)B * P->odims[l][0] * P->odims[l][1] * P->odims[l][2] * 2 * sp.cout * 2);
-                }
             } else {   // the real launch geometry: the kernel variant (and its chunking) is chosen from it
                 const int src_l = l == 0 ? -1 : (l == L_D1 || l == L_B2) ? L_D1 - 1 : (l == L_D2 || l == L_B3) ? L_D2 - 1 : l - 1;
                 const Rows xin = dense_rows(nullptr, src_l < 0 ? P->adt : P->a[src_l].dtype, B, P->in_dims[l][0], P->in_dims[l][1],
@@ -605,11 +598,6 @@ int m0_bn_knob() {
     return v;
 }
 
-// tuning aid VN_X3_SPLIT_STORE=0: fp32x3 with every operand stored as plain fp32 and split by the kernels (round 4's form)
-int x3_split_store_on() {
-    static const int v = vn_knob("VN_X3_SPLIT_STORE", 1);
-    return v;
-}
 int heads_stream_on() {   // tuning aid VN_HEADS_STREAM=0: the heads through k_gather_gemm as before
     static const int v = vn_knob("VN_HEADS_STREAM", 1);
     return v;
@@ -1020,27 +1008,6 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
                 float *slabs = P.dwp[l] + (size_t)total * dw_elems;
                 RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B) / 3.0, (rows_bytes(x) + rows_bytes(dy)) / 3.0, wstream,
                     vn_conv_wgrad_partials_split_pass(x.ptr, dy.ptr, &gs, pass, slabs, pass_bytes, &ch, wstream));
-                total += ch;
-            }
-            unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, total, dw_elems};
-            return VN_OK;
-        }
-        if (l == L_M2 && P.x3 && !P.x3_store) {
-            RTT(T_MISC, l, 0.0, 2.0 * rows_bytes(x), wstream,
-                vn_cast_rows(x.ptr, (vnDtype)x.dtype, x.sW, x.M(), sp.cin, P.x3_src, VN_BF16, 2 * sp.cin, sp.cin, wstream));
-            RTT(T_MISC, l, 0.0, 2.0 * rows_bytes(dy), wstream,
-                vn_cast_rows(dy.ptr, (vnDtype)dy.dtype, dy.sW, dy.M(), C, P.x3_rows, VN_BF16, 2 * C, C, wstream));
-            const size_t pass_bytes = P.dwp_bytes[l] / 3;
-            int32_t total = 0;
-            for (int pass = 0; pass < 3; ++pass) {
-                vnConv gb = x3_wgrad_geom(P, l, P.x3_src, P.x3_rows, pass == 1, pass == 2);
-                const Rows xs = dense_rows(P.x3_src, VN_BF16, B, P.in_dims[l][0], P.in_dims[l][1], P.in_dims[l][2], sp.cin, 2 * sp.cin);
-                const Rows ds = dense_rows(P.x3_rows, VN_BF16, B, P.odims[l][0], P.odims[l][1], P.odims[l][2], C, 2 * C);
-                int32_t ch = 1;
-                float *slabs = P.dwp[l] + (size_t)total * dw_elems;
-                RTT(T_WGRAD, l, layer_flops(sp, P.in_dims[l], P.odims[l], B) / 3.0, (rows_bytes(x) + rows_bytes(dy)) / 3.0, wstream,
-                    vn_conv_wgrad_partials(xs.ptr + (size_t)(pass == 1 ? sp.cin : 0) * 2, ds.ptr + (size_t)(pass == 2 ? C : 0) * 2, &gb, 0,
-                                           nullptr, 0, slabs, pass_bytes, &ch, wstream));
                 total += ch;
             }
             unpack[nu++] = vnUnpackJob{P.dwp[l], G[l].weight, C, sp.cin, taps, 0, sp.cin_fold, total, dw_elems};
