@@ -38,7 +38,7 @@ def fov_crop_device(points, P, Tr_velo_to_cam, R_cam_to_rect, image_rows, image_
     if mats[0].shape != (3, 4) or mats[1].shape != (4, 4) or mats[2].shape != (4, 4):
         raise ValueError("calibration: P (3,4), Tr_velo_to_cam (4,4), R_cam_to_rect (4,4)")
     dev = points.device
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         out = torch.empty((max(n, 1), 4), dtype=torch.float32, device=dev)
         index = torch.empty(max(n, 1), dtype=torch.int32, device=dev) if return_index else None
         count = torch.empty(1, dtype=torch.int32, device=dev)

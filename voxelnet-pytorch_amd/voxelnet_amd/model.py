@@ -79,7 +79,7 @@ class _LayerFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, gamma, beta, spec, bn_mod, training):
         _need_cuda(x, weight)
         mode = _mode()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             xr = E.nchw_to_rows(x, mode)
             P = {"weight": weight.detach(), "bias": bias.detach(),
                  "gamma": gamma.detach() if gamma is not None else None,
@@ -98,7 +98,7 @@ class _LayerFn(torch.autograd.Function):
     def backward(ctx, dout):
         spec, mode = ctx.spec, ctx.mode
         _need_training(ctx.training)
-        with torch.cuda.device(dout.device):
+        with _lib.on_device(dout.device):
             if spec.bn:
                 da = E.nchw_to_plain_rows(dout, E.plain_dtype_of(mode))
             else:
@@ -185,7 +185,7 @@ class _VFELayerFn(torch.autograd.Function):
         x = inputs.detach().contiguous().float()
         mk = mask.detach().reshape(K, T).ne(0).to(torch.uint8).contiguous()
         w = weight.detach().contiguous()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             ws_bytes = _lib.load().vn_vfe_layer_workspace_bytes(K, T, cin, units)
             if ws_bytes == 0:
                 raise _lib.VoxelnetHipError(f"VFELayer({cin}, {2 * units}): cin and cout/2 must be <= 64 on the HIP path")
@@ -204,7 +204,7 @@ class _VFELayerFn(torch.autograd.Function):
         K, T, cin = x.shape
         units = w.shape[0]
         d_out = d_out.contiguous().float()
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             dx = torch.empty_like(x) if ctx.need_dx else None
             dw = torch.empty_like(w)
             db, dg, dbe = (torch.empty(units, dtype=torch.float32, device=x.device) for _ in range(3))
@@ -324,7 +324,7 @@ class _FeatureNetFn(torch.autograd.Function):
     def forward(ctx, feature, coord, B, dims, training, bufs, *params):
         _need_cuda(feature, coord)
         params = [p.detach() for p in params]
-        with torch.cuda.device(feature.device):
+        with _lib.on_device(feature.device):
             vw, stats, wst = featnet_forward(feature, params, bufs, training)
             D, H, W = dims
             dense = torch.empty((B, D, H, W, 128), dtype=torch.float32, device=feature.device)
@@ -338,7 +338,7 @@ class _FeatureNetFn(torch.autograd.Function):
     def backward(ctx, d_dense):
         _need_training(ctx.training)
         feature, coord, stats, wst, params = ctx.saved
-        with torch.cuda.device(d_dense.device):
+        with _lib.on_device(d_dense.device):
             d_vw = gather_rows(Rows(d_dense.contiguous(), 128), coord, feature.shape[0], 128)
             grads = featnet_backward(feature, wst, stats, d_vw, params, training=ctx.training)
         return (None, None, None, None, None, None) + tuple(grads)
@@ -419,7 +419,7 @@ class _MiddleFn(torch.autograd.Function):
         names, P, Bf, _ = _collect_middle(mod)
         P = _detached(P)
         P["heads"] = _heads_params([f.detach() for f in flat])
-        with torch.cuda.device(x.device):
+        with _lib.on_device(x.device):
             B, D, H, W, C = x.shape
             xc = x.contiguous().float()
             if E.is_f32_storage(mode):
@@ -437,7 +437,7 @@ class _MiddleFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_prob, d_reg):
         _need_training(ctx.training)
-        with torch.cuda.device(d_prob.device):
+        with _lib.on_device(d_prob.device):
             G, d_dense = N.middle_backward(ctx.st, d_prob.float(), d_reg.float(), ctx.P, need_dx=ctx.need_dx)
             dx = None
             if d_dense is not None:
@@ -608,7 +608,7 @@ class _DetectorFn(torch.autograd.Function):
             P = _detached(P)
             P["heads"] = _heads_params([f.detach() for f in flat[-4:]])
         if native:
-            with torch.cuda.device(feature.device):
+            with _lib.on_device(feature.device):
                 dev_ = feature.device
                 sparse = bool(rpn.sparse_first_layer)
                 D, H, W = fn._grid.dims
@@ -674,7 +674,7 @@ class _DetectorFn(torch.autograd.Function):
                 rpn._ws_release(ws)
             return prob, reg
         ctx.native = False
-        with torch.cuda.device(feature.device):
+        with _lib.on_device(feature.device):
             vw, stats, wst = featnet_forward(feature, vparams, fn._bufs(), training)
             dense = scatter_rows(vw, coord, B, fn._grid.dims, mode)
             sparse = None
@@ -714,7 +714,7 @@ class _DetectorFn(torch.autograd.Function):
                 red.grad_ready(f"middle_rpn.{name}.{cv}.bias", g["bias"])
                 red.grad_ready(f"middle_rpn.{name}.batch_norm.weight", g["gamma"])
                 red.grad_ready(f"middle_rpn.{name}.batch_norm.bias", g["beta"])
-        with torch.cuda.device(d_prob.device):
+        with _lib.on_device(d_prob.device):
             G, d_dense = N.middle_backward(st, d_prob.float(), d_reg.float(), P, need_dx=True, on_grads=on_grads)
             d_vw = d_dense if torch.is_tensor(d_dense) else gather_rows(d_dense, coord, feature.shape[0], 128)
             vg = featnet_backward(feature, wst, stats, d_vw, vparams, training=ctx.training)
@@ -793,7 +793,7 @@ def _detector_backward_native(ctx, d_prob, d_reg):
         raise _lib.VoxelnetHipError("gradient accumulation over several backward() calls is not supported with a "
                                     "grad_reducer attached: call zero_grad(set_to_none=True) after every step")
     views = _grad_views(rpn, fresh=accumulate)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         arr, garr = _native_layer_arrays(mid, views)
         fused_heads = HEADS_W in views          # flat buffer: the fused heads gradient is written in place
         dhw = views[HEADS_W] if fused_heads else torch.empty((16, 768, 1, 1), dtype=torch.float32, device=dev)
@@ -890,7 +890,7 @@ class _LossFn(torch.autograd.Function):
             raise ValueError(f"loss: shapes {tuple(prob.shape)} {tuple(delta.shape)} {tuple(pos.shape)} "
                              f"{tuple(neg.shape)} {tuple(tgt.shape)} do not belong together")
         prob, delta = prob.detach().contiguous().float(), delta.detach().contiguous().float()
-        with torch.cuda.device(prob.device):
+        with _lib.on_device(prob.device):
             ws_bytes = _lib.load().vn_rpn_loss_workspace_bytes(B, H, W)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=prob.device)
             out = torch.empty(5, dtype=torch.float32, device=prob.device)
@@ -905,7 +905,7 @@ class _LossFn(torch.autograd.Function):
     def backward(ctx, *gs):
         prob, delta, pos, neg, tgt, ws, (B, H, W, alpha, beta, sigma) = ctx.saved
         gs = [None if g is None else g.contiguous().float() for g in gs]
-        with torch.cuda.device(prob.device):
+        with _lib.on_device(prob.device):
             d_prob, d_delta = torch.empty_like(prob), torch.empty_like(delta)
             with E.section("loss_bwd", 4.0 * B * H * W * 50):
                 _lib.call("vn_rpn_loss_bwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(),
@@ -969,7 +969,7 @@ class RPN3D(nn.Module):
             if ctx is not None:
                 _lib.load().vn_net_destroy(ctx[1])
             h = ctypes.c_void_p()
-            with torch.cuda.device(device):
+            with _lib.on_device(device):
                 _lib.call("vn_net_create", ctypes.byref(h))
             ctx = (device, h)
             self.__dict__["_net_ctx"] = ctx

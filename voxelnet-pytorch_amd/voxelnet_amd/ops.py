@@ -39,7 +39,7 @@ class _ScatterDense(torch.autograd.Function):
         coord = coord.contiguous()
         ch = 3 * C if split3 else C
         dense = torch.empty((B, D, H, W, ch), dtype=out_dtype, device=voxelwise.device)
-        with torch.cuda.device(voxelwise.device):
+        with _lib.on_device(voxelwise.device):
             _lib.call("vn_scatter_dense_fwd", voxelwise.data_ptr(), coord.data_ptr(), K, C, B, D, H, W,
                       dense.data_ptr(), vn_dtype(dense), ch, int(split3), stream())
         ctx.save_for_backward(coord)
@@ -54,7 +54,7 @@ class _ScatterDense(torch.autograd.Function):
         if d_dense.shape[-1] != C:
             raise _lib.VoxelnetHipError("gradient of a split3 grid must be folded to C channels first")
         d_vw = torch.empty((K, C), dtype=torch.float32, device=d_dense.device)
-        with torch.cuda.device(d_dense.device):
+        with _lib.on_device(d_dense.device):
             _lib.call("vn_scatter_dense_bwd", d_dense.data_ptr(), vn_dtype(d_dense), coord.data_ptr(), K, C, B, D,
                       H, W, d_vw.data_ptr(), stream())
         return d_vw, None, None, None, None

@@ -100,7 +100,7 @@ class ClipSGD(torch.optim.Optimizer):
             # the same gradient tensors as in the previous step (the model's flat buffer / bucket views) and the same
             # parameter storage (a `p.data = ...` / `set_()` swap keeps the Parameter object but not its memory): the chunk
             # table of raw pointers is still valid, nothing to rebuild or re-check
-            with torch.cuda.device(self._table.device):
+            with _lib.on_device(self._table.device):
                 stream = _lib.raw_stream()
                 from . import engine as E
                 with E.section("clip_sgd", 16.0 * self._n_elems):
@@ -123,7 +123,7 @@ class ClipSGD(torch.optim.Optimizer):
         self._n_elems = sum(p.numel() for p, _ in pairs)
         self._last_grads = [p.grad for p in plist] if len(pairs) == len(plist) else None
         self._last_pptrs = [p.data_ptr() for p in plist]
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             stream = _lib.raw_stream()
             from . import engine as E
             with E.section("clip_sgd", 16.0 * sum(p.numel() for p, _ in pairs)):      # grad read twice, param read + written

@@ -157,7 +157,7 @@ class GradAllReducer:
             dist.broadcast_object_list(box, src=0, group=self.pg)
             ident = (ctypes.c_ubyte * 128).from_buffer_copy(box[0])
         h = ctypes.c_void_p()
-        with torch.cuda.device(self.buckets[0]["flat"].device):
+        with _lib.on_device(self.buckets[0]["flat"].device):
             _lib.call("vn_comm_create", ctypes.byref(h), ident, self.world, self.rank)
         self.comm = h
 

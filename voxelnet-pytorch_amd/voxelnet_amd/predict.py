@@ -38,7 +38,7 @@ class BoxDecoder:
         counts = torch.zeros(B, dtype=torch.int32, device=dev)
         nbytes = _lib.load().vn_rpn_predict_workspace_bytes(B, N)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("vn_rpn_predict", probs.data_ptr(), deltas.data_ptr(), self._anchors_dev.data_ptr(), B, N,
                       float(score_thres), float(nms_thres), int(top_k), self.anchor_h, boxes.data_ptr(), scores.data_ptr(),
                       counts.data_ptr(), ws.data_ptr(), nbytes, _lib.raw_stream())

@@ -159,7 +159,7 @@ class TargetGenerator:
         if nbytes == 0:
             raise _lib.VoxelnetHipError("vn_rpn_targets_workspace_bytes: unsupported sizes")
         ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             _lib.call("vn_rpn_targets", self._anchors_dev.data_ptr(), N, gt_d.data_ptr(), g2_d.data_ptr(), cnt_d.data_ptr(),
                       B, G, float(self.cfg["pos_iou"]), float(self.cfg["neg_iou"]), float(self.cfg["h"]), pos.data_ptr(),
                       neg.data_ptr(), tgt.data_ptr(), ws.data_ptr(), nbytes,

@@ -44,7 +44,7 @@ def voxelize_device(points, grid, batch_index=0, coord_cols=4):
     ws_bytes = lib.vn_voxelize_workspace_bytes(n, ctypes.byref(gs))
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     k_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         st = _stream()
         _lib.call("vn_voxelize_index", points.data_ptr(), n, ctypes.byref(gs), ws.data_ptr(), ws_bytes,
                   k_dev.data_ptr(), st)
@@ -104,7 +104,7 @@ def voxelize_device_async(points, grid, batch_index=0, coord_cols=4, buffers=Non
     lib = _lib.load()
     ws_bytes = lib.vn_voxelize_workspace_bytes(n, ctypes.byref(gs))
     cap = min(n, grid.cells)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         if buffers is not None:
             if buffers.n != n or buffers.cols != coord_cols:
                 raise ValueError("VoxelBuffers slot was sized for a different cloud")
