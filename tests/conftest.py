@@ -62,6 +62,13 @@ def pytest_sessionstart(session):
         DDP_REHEARSAL["error"] = repr(e)
 
 
+def pytest_collection_modifyitems(config, items):
+    """the tests that collect the side processes started above go last: those processes (two ranks, one bench.py) then
+    run BESIDE the other GPU tests instead of being waited for"""
+    late = ("test_gpu_bench_contract.py", "test_gpu_multiproc.py")
+    items.sort(key=lambda it: os.path.basename(str(it.fspath)) in late)          # (stable: the rest keep their order)
+
+
 def pytest_sessionfinish(session, exitstatus):
     for p in DDP_REHEARSAL.get("procs", []) + ([BENCH_RUN["proc"]] if "proc" in BENCH_RUN else []):
         if p.poll() is None:

@@ -167,11 +167,14 @@ def test_car_full_size_batch2_fp32_maps():
 def vfe_oracle_float64(feature, sd, chunk=4096):
     """model.py:93-100 (both VFELayers, model.py:74-82, and the voxel max) in float64, evaluated in three passes over
     chunks of voxels so that the (K,T,128) intermediates of K = 160k, T = 64 never exist at once (train-mode BatchNorm:
-    batch statistics over all K*T rows, padded slots included)."""
-    W1, b1 = sd["feature_net.vfe_1.fcn.0.weight"].double(), sd["feature_net.vfe_1.fcn.0.bias"].double()
-    g1, be1 = sd["feature_net.vfe_1.bn.weight"].double(), sd["feature_net.vfe_1.bn.bias"].double()
-    W2, b2 = sd["feature_net.vfe_2.fcn.0.weight"].double(), sd["feature_net.vfe_2.fcn.0.bias"].double()
-    g2, be2 = sd["feature_net.vfe_2.bn.weight"].double(), sd["feature_net.vfe_2.bn.bias"].double()
+    batch statistics over all K*T rows, padded slots included).  Plain torch float64 ops on `feature`'s device: on the
+    CPU for the pin below, on the GPU (torch's own float64 kernels, none of this library's) for the K = 160k case, where
+    the CPU takes 42 s; test_vfe_oracle_float64_same_on_both_devices ties the two."""
+    dev = feature.device
+    W1, b1 = sd["feature_net.vfe_1.fcn.0.weight"].double().to(dev), sd["feature_net.vfe_1.fcn.0.bias"].double().to(dev)
+    g1, be1 = sd["feature_net.vfe_1.bn.weight"].double().to(dev), sd["feature_net.vfe_1.bn.bias"].double().to(dev)
+    W2, b2 = sd["feature_net.vfe_2.fcn.0.weight"].double().to(dev), sd["feature_net.vfe_2.fcn.0.bias"].double().to(dev)
+    g2, be2 = sd["feature_net.vfe_2.bn.weight"].double().to(dev), sd["feature_net.vfe_2.bn.bias"].double().to(dev)
     K, T = feature.shape[0], feature.shape[1]
     n = float(K * T)
 
@@ -185,18 +188,18 @@ def vfe_oracle_float64(feature, sd, chunk=4096):
         agg = p.max(dim=1, keepdim=True)[0]
         return torch.cat([p, agg.expand(-1, T, -1)], dim=2) * mask
 
-    s1 = torch.zeros(16, dtype=torch.float64); q1 = torch.zeros(16, dtype=torch.float64)
+    s1 = torch.zeros(16, dtype=torch.float64, device=dev); q1 = torch.zeros(16, dtype=torch.float64, device=dev)
     for _, x, _m in chunks():
         h = F.relu(x @ W1.t() + b1)
         s1 += h.sum(dim=(0, 1)); q1 += (h * h).sum(dim=(0, 1))
     m1, v1 = s1 / n, q1 / n - (s1 / n) ** 2
-    s2 = torch.zeros(64, dtype=torch.float64); q2 = torch.zeros(64, dtype=torch.float64)
+    s2 = torch.zeros(64, dtype=torch.float64, device=dev); q2 = torch.zeros(64, dtype=torch.float64, device=dev)
     for _, x, mk in chunks():
         o1 = layer(F.relu(x @ W1.t() + b1), m1, v1, g1, be1, mk)
         h = F.relu(o1 @ W2.t() + b2)
         s2 += h.sum(dim=(0, 1)); q2 += (h * h).sum(dim=(0, 1))
     m2, v2 = s2 / n, q2 / n - (s2 / n) ** 2
-    out = torch.empty((K, 128), dtype=torch.float64)
+    out = torch.empty((K, 128), dtype=torch.float64, device=dev)
     for i, x, mk in chunks():
         o1 = layer(F.relu(x @ W1.t() + b1), m1, v1, g1, be1, mk)
         o2 = layer(F.relu(o1 @ W2.t() + b2), m2, v2, g2, be2, mk)
@@ -217,6 +220,21 @@ def test_vfe_oracle_float64_chunked_equals_the_pinned_oracle():
     ref = tr.voxel_features(x.double(), sd64, True)
     got, _ = vfe_oracle_float64(x, sd, chunk=64)
     assert float((got - ref).abs().max()) < 1e-10
+
+
+def test_vfe_oracle_float64_same_on_both_devices():
+    """the float64 evaluation gives the same numbers with torch's CPU and GPU float64 kernels (8000 voxels x 64 slots,
+    ragged occupancy): the full-K test below uses the GPU run of it as its reference"""
+    rng = np.random.default_rng(23)
+    K, T = 8000, 64
+    x = torch.from_numpy(rng.standard_normal((K, T, 7)).astype(np.float32))
+    npts = rng.integers(1, T + 1, size=K)
+    x = x * torch.from_numpy((np.arange(T)[None, :] < npts[:, None])[..., None])
+    sd = tr.make_state_dict("Car")
+    a, sa = vfe_oracle_float64(x, sd, chunk=1024)
+    b, sb = vfe_oracle_float64(x.to(DEV), sd, chunk=4096)
+    assert float((a - b.cpu()).abs().max()) < 1e-10
+    assert all(float((p - q.cpu()).abs().max()) < 1e-12 for p, q in zip(sa, sb))
 
 
 def test_dense_config_vfe_full_K_and_train_step():
@@ -241,7 +259,7 @@ def test_dense_config_vfe_full_K_and_train_step():
     feature = torch.cat(feats)
     fn = m.feature_net
     vw, _stats, _h = M.featnet_forward(feature, [p.detach() for p in M._vfe_weights(fn)], fn._bufs(), True)
-    ref, (m1, v1, m2, v2) = vfe_oracle_float64(feature.cpu(), sd)
+    ref, (m1, v1, m2, v2) = vfe_oracle_float64(feature, sd)
     e = rel_err(vw, ref)
     print(f"dense config: K = {K}, T = 64, voxel features vs float64 oracle {e:.2e}")
     assert e < 1e-4
