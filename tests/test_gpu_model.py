@@ -378,6 +378,71 @@ def test_native_executor_other_depths(D):
         M.set_precision("bf16")
 
 
+@pytest.mark.parametrize("B,empty", [(1, None), (3, 1), (5, 4)])
+def test_odd_batches_and_an_empty_frame(B, empty):
+    """Batch sizes the fixtures do not hold (1, 3, 5) with one frame of the batch EMPTY (every point outside the range
+    crop: utils.py:63-88 then returns K = 0 buffers, and model.py:102-106 leaves that sample's dense grid at zero): the
+    device voxelizer returns the same empty buffers as the oracle's, the fp32-mode maps meet the CPU oracle at 1e-3, and
+    a backward through every precision mode gives finite gradients for all 104 parameters."""
+    from oracle import voxelize as ov
+    from voxelnet_amd import model as M
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import grid_config
+    from voxelnet_amd.voxelize import voxelize_device
+    g = grid_config("Car", D=10, H=16, W=24, oy=1.6)
+    feats, coords = [], []
+    for i in range(B):
+        cloud = synth.synth_cloud("Car", k0=90 + 25 * i, seed=1300 + 7 * B + i, grid=g, overflow_frac=0.03)
+        if i == empty:
+            cloud = cloud.copy()
+            cloud[:, 0] = -500.0                                   # all behind the sensor: nothing survives the crop
+        v = ov.voxelize(cloud, "Car", D=10, H=16, W=24, oy=1.6)
+        fb, cb, _ = voxelize_device(torch.from_numpy(cloud).to(DEV), g, i, coord_cols=4)
+        assert fb.shape[0] == v["feature_buffer"].shape[0] and (i != empty or fb.shape[0] == 0)
+        feats.append(torch.from_numpy(v["feature_buffer"]))
+        coords.append(torch.from_numpy(np.pad(v["coordinate_buffer"], ((0, 0), (1, 0)), constant_values=i)))
+    with torch.no_grad():
+        sd = tr.make_state_dict("Car")
+        rp, rr = tr.middle_rpn(tr.feature_net(feats, coords, sd, (10, 16, 24), True), sd, "Car", True)
+    assert rp.shape[0] == B
+    fd, cd = [f.to(DEV) for f in feats], [c.to(DEV) for c in coords]
+    up = (torch.full((B, 2, 8, 12), 0.05, device=DEV), torch.full((B, 14, 8, 12), -0.03, device=DEV))
+    try:
+        for mode, tol in (("fp32", 1e-3), ("fp32x3", 1e-3), ("bf16", 0.25)):
+            M.set_precision(mode)
+            m = M.RPN3D("Car")
+            m.load_state_dict(tr.make_state_dict("Car"))
+            m.feature_net._grid = g
+            m = m.to(DEV).train()
+            assert m._native_ok(mode)
+            prob, reg = m.detect(fd, cd)
+            torch.autograd.backward([prob, reg], list(up))
+            e = (rel_err(prob, rp.numpy()), rel_err(reg, rr.numpy()))
+            print(f"B = {B}, empty frame {empty}, {mode}: maps vs CPU oracle {e[0]:.1e} / {e[1]:.1e}")
+            assert e[0] < tol and e[1] < tol, (mode, e)
+            grads = [p.grad for p in m.parameters()]
+            assert len(grads) == 104 and all(g_ is not None and torch.isfinite(g_).all() for g_ in grads)
+            assert sum(float(g_.abs().sum()) for g_ in grads) > 0
+    finally:
+        M.set_precision("bf16")
+
+
+def test_a_batch_without_any_voxel_is_refused():
+    """K = 0 over the whole batch: the reference cannot run it either (train-mode BatchNorm1d over zero rows raises
+    "Expected more than 1 value per channel", model.py:76); here the executor refuses the call with an error, it does not
+    launch over empty row sets."""
+    from voxelnet_amd import _lib
+    from voxelnet_amd import model as M
+    from voxelnet_amd.config import grid_config
+    m = M.RPN3D("Car")
+    m.load_state_dict(tr.make_state_dict("Car"))
+    m.feature_net._grid = grid_config("Car", D=10, H=16, W=24, oy=1.6)
+    m = m.to(DEV).train()
+    with pytest.raises(_lib.VoxelnetHipError):
+        m.detect([torch.zeros((0, 35, 7), device=DEV)], [torch.zeros((0, 4), dtype=torch.int64, device=DEV)])
+    torch.cuda.synchronize()
+
+
 def _hip_masks(st):
     """ReLU decisions of the HIP forward, per layer, in the oracle's NC(D)HW output shapes: mask = (a > 0) of the stored
     activation (per-layer orchestration state, voxelnet_amd/net.py)"""
