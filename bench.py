@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--torch-optim", action="store_true",
                     help="torch's clip_grad_norm_ + SGD instead of the fused vn_clip_sgd tail (same arithmetic)")
     ap.add_argument("--timer-steps", type=int, default=3)
+    ap.add_argument("--separate-calls", action="store_true",
+                    help="issue the step as forward / loss.backward() / optimizer.step() (rounds 1-5) instead of ONE library "
+                         "call (RPN3D.train_step -> vn_net_step): same kernels, same results, more host work")
     ap.add_argument("--force-reducer", action="store_true",
                     help="diagnostic: run the DDP bucket path (flat buckets, bucket events) on one GPU")
     ap.add_argument("--static-voxels", action="store_true",
@@ -337,7 +340,15 @@ def main():
             g0 = torch.cuda.Event(enable_timing=True)
             g0.record()
         feats, coords = voxelize_batch()
-        loss = fwd_bwd(feats, coords)
+        one_call = (with_loss and not args.separate_calls and not args.torch_optim and state.get("exposed") is None)
+        if one_call:
+            # model.py:298-362 + train.py:151-154 as ONE library call (reducer exchange and ClipSGD included)
+            m = state["model"]
+            out = m.train_step((None, labels if mode["gen"] else None, feats, None, coords, None, None), dev, state["opt"],
+                               targets=None if mode["gen"] else targets)
+            loss = out[2]
+        else:
+            loss = fwd_bwd(feats, coords)
         if not args.static_voxels:         # this step's slot may be re-used once the backward (queued above) is done
             si = ring["use"] % 3
             ring["use"] += 1
@@ -345,6 +356,13 @@ def main():
             ev.record()
             slot_free[si] = ev
         m = state["model"]
+        if one_call:
+            state["opt"].zero_grad(set_to_none=True)                       # train.py:155
+            if gap_events is not None:
+                g1 = torch.cuda.Event(enable_timing=True)
+                g1.record()
+                gap_events.append((g0, g1))
+            return loss
         if m.grad_reducer is not None:
             if state.get("exposed") is not None:       # (N > 1 diagnostic steps only: how long the main stream waits for the reducer)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -573,7 +591,9 @@ def main():
                                % (("RPN targets from the label lines (device) + loss" if gen_targets else "loss on precomputed target maps")
                                   if with_loss else "seeded upstream gradient (the reference's loss is undefined for this class)"),
                        "with_target_generation": bool(gen_targets),
-                       "launch_mode": "eager" + ("+native-executor" if model.native_executor else "")},
+                       "launch_mode": "eager" + ("+native-executor" if model.native_executor else "")
+                                      + ("+one-call-step" if (with_loss and not args.separate_calls and not args.torch_optim
+                                                              and model._step_fused_ok(args.precision, opt)) else "")},
             # un-throttled: one step enqueued into an empty queue (what the host needs); in_loop: the timed loop's enqueue
             # time, which the GPU paces through queue back-pressure
             "host_enqueue_ms_per_step": host_free, "host_enqueue_in_loop_ms_per_step": 1e3 * t_enq / args.steps,

@@ -468,6 +468,56 @@ int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *lay
                     vnStream stream, vnStream side_stream /* NULL, or a second stream the weight-gradient
                     launches run on beside the data-gradient ones; joined back before the call returns */);
 
+/* ONE call per train step (voxelnet/model.py:298-362 + voxelnet/train.py:151-154): the voxel feature encoder, the
+ * middle layers + RPN, the loss, the whole backward and (n_chunks > 0) clip_grad_norm_ + SGD, issued in the order and on
+ * the streams the separate calls are issued by a host that overlaps them by hand:
+ *   side:  [wait stream]  counters += 1 | vn_net_prepare phase 1 | heads' parameters -> heads_w / heads_b | vn_net_prepare phase 2
+ *   main:  vn_vfe_fwd | (bf16 mode) vn_cast_rows -> vw_rows | vn_net_forward | [wait targets_stream] vn_rpn_loss_fwd |
+ *          vn_rpn_loss_bwd (g_loss) | vn_net_backward(0..24, defer_join) | vn_vfe_bwd | [wait side] | vn_clip_sgd
+ * Same kernels, same order, same results as those calls (tests/test_gpu_step.py: bit-identical); what it saves is the
+ * host's work between them.  Every buffer is the caller's; scratch ones (voxelwise, vfe_stats, vw_rows, d_voxelwise,
+ * heads_w / heads_b, d_prob / d_reg, the three workspaces) need only live until the step has run.
+ * Requires cfg->sparse_first, cfg->training and a side stream (VN_EUNSUPPORTED / VN_EINVAL otherwise).
+ * cfg->bucket_events is honoured (vn_net_wait_bucket after the call; pass n_chunks = 0 and update after the exchange). */
+struct vnParamChunk;
+typedef struct {
+    const float *feature;          /* (K,T,7) */
+    const int64_t *coord;          /* (K,4) */
+    int64_t K;
+    int32_t T;
+    float bn_momentum, bn_eps;     /* the VFE's BatchNorm1d (the executor's layers use 0.1 / 1e-5 as vn_net_forward does) */
+    vnVfeWeights vfe;
+    vnVfeGrads vfe_grads;
+    void *vfe_ws; size_t vfe_ws_bytes;            /* vn_vfe_workspace_bytes(K, T) */
+    float *voxelwise;              /* (K,128) */
+    float *vfe_stats;              /* 320 */
+    void *vw_rows;                 /* (K,128) in the operand dtype: bf16 mode = a bf16 scratch buffer; fp32 / fp32x3 = voxelwise itself */
+    float *d_voxelwise;            /* (K,128) */
+    const float *prob_w, *prob_b, *reg_w, *reg_b;   /* prob_conv / reg_conv parameters: (2,768) (2) (14,768) (14) */
+    float *heads_w, *heads_b;      /* scratch (16,768) (16): their concatenation, prob rows first */
+    float *d_heads_w, *d_heads_b;  /* gradients of the concatenation (16,768) (16) */
+    const vnLayerParams *layers;   /* [23] */
+    const vnLayerGrads *grads;     /* [23] */
+    void *ws; size_t ws_bytes;     /* vn_net_workspace_bytes */
+    float *prob, *reg;             /* outputs (B,2,h,w) (B,14,h,w) */
+    float *d_prob, *d_reg;         /* scratch, same shapes */
+    const float *pos, *neg, *targets;   /* (B,h,w,2) (B,h,w,2) (B,h,w,14) */
+    vnStream targets_stream;       /* NULL, or the stream those three are produced on: the loss waits for what is queued there now */
+    float alpha, beta, sigma;
+    void *loss_ws; size_t loss_ws_bytes;          /* vn_rpn_loss_workspace_bytes */
+    float *loss5;                  /* output: loss, cls_loss, reg_loss, cls_pos_loss_rec, cls_neg_loss_rec */
+    const float *g_loss;           /* device scalar: d(objective) / d(loss), normally 1 */
+    const struct vnParamChunk *chunks; int32_t n_chunks;   /* vn_clip_sgd's table; n_chunks = 0: no parameter update */
+    float max_norm, lr;
+    int32_t scale_grads;
+    void *opt_ws; size_t opt_ws_bytes;
+    float *total_norm;             /* may be NULL */
+    int64_t *const *bn_counters;   /* NULL, or a DEVICE array of n_bn_counters pointers: every BatchNorm's num_batches_tracked, */
+    int32_t n_bn_counters;         /* += 1 each (nn.BatchNorm*.forward in train mode) — one launch on the side stream */
+    vnStream stream, side_stream;
+} vnStep;
+int vn_net_step(vnNet *net, const vnNetConfig *cfg, const vnStep *step);
+
 /* ------------------------------------------------------------------------
  * Data-parallel gradient exchange over RCCL / xGMI (the reference has no distributed code):
  * thin wrappers, RCCL bound at run time (dlopen; inside a PyTorch process torch's own librccl is reused).

@@ -2,6 +2,7 @@
 // voxelnet_amd/model.py makes per train step, train.py:148-151) with fake device pointers, under the stub HIP layer of
 // stub_hip.c.  Prints "<launches per step> <microseconds per step>" (median of 5 blocks).  Test infrastructure.
 //   drive_executor <libvoxelnet_hip.so> <steps> [bucket_events [mode [H W [K]]]]   (mode 0 bf16, 1 fp32, 2 fp32x3)
+// bucket_events = 2: the whole train step as ONE call (vn_net_step: + voxel feature encoder, loss, clip + SGD); -1: control.
 #include <algorithm>
 #include <chrono>
 #include <cstdio>
@@ -42,6 +43,7 @@ int main(int argc, char **argv) {
         return 0;
     }
     SYM(vn_net_workspace_bytes) SYM(vn_net_create) SYM(vn_net_destroy) SYM(vn_net_prepare) SYM(vn_net_forward) SYM(vn_net_backward)
+    SYM(vn_net_step) SYM(vn_vfe_workspace_bytes) SYM(vn_rpn_loss_workspace_bytes) SYM(vn_clip_sgd_workspace_bytes)
     vnNetConfig cfg;
     memset(&cfg, 0, sizeof(cfg));
     cfg.B = 2; cfg.D = 10; cfg.H = 400; cfg.W = 352; cfg.block1_stride = 2; cfg.mode = 0; cfg.training = 1; cfg.sparse_first = 1;
@@ -69,8 +71,40 @@ int main(int argc, char **argv) {
     vnNet *net = nullptr;
     if (p_vn_net_create(&net)) return 4;
     vnStream main_s = reinterpret_cast<vnStream>(0x10), side_s = reinterpret_cast<vnStream>(0x20);
+    vnStep st;
+    memset(&st, 0, sizeof(st));
+    {
+        float *q = par + (10 << 22);
+        auto take = [&](size_t floats) { float *r = q; q += (floats + 63) / 64 * 64; return r; };
+        st.feature = take(K * 35 * 7); st.coord = coord; st.K = K; st.T = 35; st.bn_momentum = 0.1f; st.bn_eps = 1e-5f;
+        st.vfe = vnVfeWeights{take(112), take(16), take(16), take(16), take(16), take(16), take(2048), take(64), take(64), take(64), take(64), take(64)};
+        st.vfe_grads = vnVfeGrads{take(112), take(16), take(16), take(16), take(2048), take(64), take(64), take(64)};
+        st.vfe_ws_bytes = p_vn_vfe_workspace_bytes(K, 35); st.vfe_ws = take(st.vfe_ws_bytes / 4 + 1);
+        st.voxelwise = take(K * 128); st.vfe_stats = take(320);
+        st.vw_rows = cfg.mode == 0 ? (void *)take(K * 64) : (void *)st.voxelwise;
+        st.d_voxelwise = take(K * 128);
+        st.prob_w = take(2 * 768); st.prob_b = take(2); st.reg_w = take(14 * 768); st.reg_b = take(14);
+        st.heads_w = heads_w; st.heads_b = heads_b; st.d_heads_w = dhw; st.d_heads_b = dhb;
+        st.layers = L; st.grads = G; st.ws = ws; st.ws_bytes = ws_bytes;
+        st.prob = prob; st.reg = reg; st.d_prob = dprob; st.d_reg = dreg;
+        const int hf = cfg.H / cfg.block1_stride, wf = cfg.W / cfg.block1_stride;
+        st.pos = take((size_t)cfg.B * hf * wf * 2); st.neg = take((size_t)cfg.B * hf * wf * 2); st.targets = take((size_t)cfg.B * hf * wf * 14);
+        st.targets_stream = reinterpret_cast<vnStream>(0x30);
+        st.alpha = 1.5f; st.beta = 1.f; st.sigma = 3.f;
+        st.loss_ws_bytes = p_vn_rpn_loss_workspace_bytes(cfg.B, hf, wf); st.loss_ws = take(st.loss_ws_bytes / 4 + 1);
+        st.loss5 = take(5); st.g_loss = take(1);
+        st.n_chunks = 2000; st.chunks = reinterpret_cast<const vnParamChunk *>(take(2000 * sizeof(vnParamChunk) / 4));
+        st.max_norm = 5.f; st.lr = 0.01f; st.opt_ws_bytes = p_vn_clip_sgd_workspace_bytes(2000); st.opt_ws = take(st.opt_ws_bytes / 4 + 1);
+        st.total_norm = take(1);
+        st.bn_counters = reinterpret_cast<int64_t *const *>(take(64)); st.n_bn_counters = 25;
+        st.stream = reinterpret_cast<vnStream>(0x10); st.side_stream = reinterpret_cast<vnStream>(0x20);
+    }
     auto one_step = [&]() -> int {
         int rc;
+        if (buckets == 2) {
+            cfg.bucket_events = 0; cfg.defer_join = 0; cfg.prepared = 0;
+            return p_vn_net_step(net, &cfg, &st);
+        }
         cfg.bucket_events = 0; cfg.defer_join = 0;
         cfg.prepared = 1;
         if ((rc = p_vn_net_prepare(net, &cfg, L, nullptr, coord, K, ws, ws_bytes, side_s))) return rc;

@@ -107,3 +107,36 @@ def test_build_id_names_the_sources_the_library_was_built_from():
     lib = _lib.load()
     assert lib.vn_build_id().decode() == h.hexdigest()[:12]
     assert ("build " + h.hexdigest()[:12]) in lib.vn_build_info().decode()
+
+
+def test_ctypes_structures_match_the_header_layout(tmp_path):
+    """every struct the Python side hands to the library by value or by pointer has the size and the field offsets the C
+    header gives it (gcc on include/voxelnet_hip.h): a drifted field in vnStep / vnConv would pass garbage pointers"""
+    import ctypes
+    import subprocess
+    from voxelnet_amd import _lib
+    pairs = [("vnGrid", _lib.VnGrid), ("vnConv", _lib.VnConv), ("vnVfeWeights", _lib.VnVfeWeights), ("vnVfeGrads", _lib.VnVfeGrads),
+             ("vnNetConfig", _lib.VnNetConfig), ("vnTimingRecord", _lib.VnTimingRecord), ("vnLayerParams", _lib.VnLayerParams),
+             ("vnLayerGrads", _lib.VnLayerGrads), ("vnPackJob", _lib.VnPackJob), ("vnUnpackJob", _lib.VnUnpackJob),
+             ("vnParamChunk", _lib.VnParamChunk), ("vnStep", _lib.VnStep)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "voxelnet_hip.h"', 'int main(void) {']
+    for cname, st in pairs:
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in st._fields_:
+            if fname.endswith("_") and fname.startswith("pad"):
+                continue
+            lines.append(f'  printf(" %zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert len(out) == len(pairs)
+    for line, (cname, st) in zip(out, pairs):
+        parts = line.split()
+        assert parts[0] == cname
+        want = [int(v) for v in parts[1:]]
+        got = [ctypes.sizeof(st)] + [getattr(st, f).offset for f, _ in st._fields_ if not (f.endswith("_") and f.startswith("pad"))]
+        assert got == want, (cname, got, want)

@@ -57,6 +57,18 @@ def test_executor_host_work_per_step_is_small(stub):
     assert lb >= launches and usb < 300.0, (lb, usb)
 
 
+def test_one_call_step_host_work(stub):
+    """vn_net_step (voxel feature encoder + network + loss + backward + clip/SGD as one call) under the stub: every argument
+    check passes for the three modes, it issues the executor's launches plus the encoder's, the loss's and the optimizer's,
+    and its own host work stays tens of microseconds"""
+    base, _ = result(run(stub))
+    for mode in (0, 1, 2):
+        launches, us = result(run(stub, buckets=2, extra=(mode,)))
+        assert launches >= 150 and us < 300.0, (mode, launches, us)
+        if mode == 0:
+            assert base + 15 <= launches <= base + 45, (base, launches)      # + VFE 3+1 fwd, 3+ bwd, finalizes, loss 2, cast, tick, cat, clip 2
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2], ids=["bf16", "fp32", "fp32x3"])
 @pytest.mark.parametrize("grid", [(400, 352, 12345), (16, 24, 300), (200, 240, 9000), (400, 352, 160000)],
                          ids=["car", "tiny", "ped-sized", "dense"])

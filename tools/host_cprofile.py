@@ -1,5 +1,8 @@
 """cProfile of the host side of bench.py's step (un-throttled: the queue is drained every 10 steps): where the ~1.8 ms of
-host time per step go that are not hipLaunchKernel itself.  usage: python tools/host_cprofile.py [steps]"""
+host time per step go that are not hipLaunchKernel itself.
+usage: python tools/host_cprofile.py [steps] [separate]   (default: the one-call step, RPN3D.train_step; "separate": forward /
+backward / optimizer.step as separate calls — there the backward runs on autograd's device thread, which cProfile does not see:
+its whole time shows up as run_backward)"""
 import cProfile
 import io
 import os
@@ -17,6 +20,7 @@ from voxelnet_amd.optim import ClipSGD  # noqa: E402
 from voxelnet_amd.voxelize import VoxelBatch, VoxelBuffers, pipeline_stream, voxelize_device_async  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+SEPARATE = "separate" in sys.argv[2:]
 dev = torch.device("cuda:0")
 M.set_precision("bf16")
 torch.manual_seed(0)
@@ -41,9 +45,12 @@ def step():
     torch.cuda.current_stream().wait_event(hs[-1].event)
     feats = VoxelBatch.ahead([x[0] for x in fc], vs, torch.float32)
     coords = VoxelBatch.ahead([x[1] for x in fc], vs, torch.int64)
-    out = model((None, labels, feats, None, coords, None, None), dev)
-    out[2].backward()
-    opt.step()
+    if SEPARATE:
+        out = model((None, labels, feats, None, coords, None, None), dev)
+        out[2].backward()
+        opt.step()
+    else:
+        model.train_step((None, labels, feats, None, coords, None, None), dev, opt)
     opt.zero_grad(set_to_none=True)
 
 

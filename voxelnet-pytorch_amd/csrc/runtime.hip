@@ -1296,3 +1296,79 @@ extern "C" int vn_net_wait_bucket(vnNet *net, int32_t bucket, vnStream stream) {
     VN_HIP(hipStreamWaitEvent(vn_stream(stream), net->bucket_ev[bucket][1], 0));
     return VN_OK;
 }
+
+// ---- one call per train step ------------------------------------------------------------------------------------------
+namespace {
+// heads_w (16,768) / heads_b (16) <- prob_conv (2 rows) then reg_conv (14 rows): what the two torch.cat of the host path do
+__global__ void __launch_bounds__(256) k_heads_cat(const float *__restrict__ pw, const float *__restrict__ rw,
+                                                   const float *__restrict__ pb, const float *__restrict__ rb,
+                                                   float *__restrict__ w, float *__restrict__ b) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < 16 * 768) w[i] = i < 2 * 768 ? pw[i] : rw[i - 2 * 768];
+    if (i < 16) b[i] = i < 2 ? pb[i] : rb[i - 2];
+}
+__global__ void __launch_bounds__(64) k_tick(int64_t *const *__restrict__ ctrs, int n) {
+    if ((int)threadIdx.x < n) *ctrs[threadIdx.x] += 1;
+}
+}  // namespace
+
+extern "C" int vn_net_step(vnNet *net, const vnNetConfig *cfg, const vnStep *s) {
+    VN_CHECK_ARG(net && cfg && s);
+    VN_CHECK_ARG(s->feature && s->coord && s->K > 0 && s->T > 0 && s->vfe_ws && s->voxelwise && s->vfe_stats && s->vw_rows &&
+                 s->d_voxelwise);
+    VN_CHECK_ARG(s->prob_w && s->prob_b && s->reg_w && s->reg_b && s->heads_w && s->heads_b && s->d_heads_w && s->d_heads_b);
+    VN_CHECK_ARG(s->layers && s->grads && s->ws && s->prob && s->reg && s->d_prob && s->d_reg);
+    VN_CHECK_ARG(s->pos && s->neg && s->targets && s->loss_ws && s->loss5 && s->g_loss);
+    VN_CHECK_ARG(s->n_chunks >= 0 && (s->n_chunks == 0 || (s->chunks && s->opt_ws)));
+    VN_CHECK_ARG(s->side_stream && s->side_stream != s->stream);
+    VN_CHECK_ARG(s->n_bn_counters >= 0 && s->n_bn_counters <= 64);
+    if (!cfg->sparse_first || !cfg->training || (cfg->grad_storage & 16)) return VN_EUNSUPPORTED;
+    if (cfg->mode == 0 ? s->vw_rows == (void *)s->voxelwise : s->vw_rows != (void *)s->voxelwise) return VN_EINVAL;
+    hipStream_t hs = vn_stream(s->stream), ss = vn_stream(s->side_stream);
+    const int32_t hf = cfg->H / cfg->block1_stride, wf = cfg->W / cfg->block1_stride;
+    vnNetConfig c = *cfg;
+    // side stream: what does not depend on the voxel features, the first layer's needs first
+    hipEvent_t ev = net->next_event();
+    VN_HIP(hipEventRecord(ev, hs));
+    VN_HIP(hipStreamWaitEvent(ss, ev, 0));
+    if (s->bn_counters && s->n_bn_counters > 0) {       // nothing in the step reads them
+        k_tick<<<1, 64, 0, ss>>>(s->bn_counters, s->n_bn_counters);
+        VN_HIP(hipGetLastError());
+    }
+    c.prepared = 1;
+    RT(vn_net_prepare(net, &c, s->layers, nullptr, s->coord, s->K, s->ws, s->ws_bytes, s->side_stream));
+    k_heads_cat<<<(16 * 768 + 255) / 256, 256, 0, ss>>>(s->prob_w, s->reg_w, s->prob_b, s->reg_b, s->heads_w, s->heads_b);
+    VN_HIP(hipGetLastError());
+    c.prepared = 2;
+    RT(vn_net_prepare(net, &c, s->layers, s->heads_w, s->coord, s->K, s->ws, s->ws_bytes, s->side_stream));
+    // main stream: encoder, network, loss
+    RT(vn_vfe_fwd(s->feature, s->K, s->T, &s->vfe, 1, s->bn_momentum, s->bn_eps, s->voxelwise, s->vfe_stats, s->vfe_ws,
+                  s->vfe_ws_bytes, s->stream));
+    if (cfg->mode == 0)
+        RT(vn_cast_rows(s->voxelwise, VN_F32, 128, s->K, 128, s->vw_rows, VN_BF16, 128, 0, s->stream));
+    c.prepared = 1;
+    RT(vn_net_forward(net, &c, s->layers, s->heads_w, s->heads_b, nullptr, s->coord, s->vw_rows, s->K, s->ws, s->ws_bytes,
+                      s->prob, s->reg, s->stream, s->side_stream));
+    if (s->targets_stream && s->targets_stream != s->stream) {
+        ev = net->next_event();
+        VN_HIP(hipEventRecord(ev, vn_stream(s->targets_stream)));
+        VN_HIP(hipStreamWaitEvent(hs, ev, 0));
+    }
+    RT(vn_rpn_loss_fwd(s->prob, s->reg, s->pos, s->neg, s->targets, cfg->B, hf, wf, s->alpha, s->beta, s->sigma, s->loss_ws,
+                       s->loss_ws_bytes, s->loss5, s->stream));
+    RT(vn_rpn_loss_bwd(s->prob, s->reg, s->pos, s->neg, s->targets, cfg->B, hf, wf, s->alpha, s->beta, s->sigma, s->loss_ws,
+                       s->g_loss, nullptr, nullptr, nullptr, nullptr, s->d_prob, s->d_reg, s->stream));
+    // backward: the last weight gradients and their unpack run on the side stream beside the encoder's backward
+    c.defer_join = 1;
+    RT(vn_net_backward(net, &c, s->layers, s->heads_w, s->d_prob, s->d_reg, s->prob, nullptr, s->coord, s->vw_rows, s->K, s->ws,
+                       s->ws_bytes, s->grads, s->d_heads_w, s->d_heads_b, s->d_voxelwise, 0, 24, s->stream, s->side_stream));
+    RT(vn_vfe_bwd(s->feature, s->K, s->T, &s->vfe, s->vfe_stats, s->d_voxelwise, &s->vfe_grads, s->vfe_ws, s->vfe_ws_bytes, 1,
+                  s->stream));
+    ev = net->next_event();
+    VN_HIP(hipEventRecord(ev, ss));
+    VN_HIP(hipStreamWaitEvent(hs, ev, 0));
+    if (s->n_chunks > 0)
+        RT(vn_clip_sgd(s->chunks, s->n_chunks, s->max_norm, s->lr, s->scale_grads, s->opt_ws, s->opt_ws_bytes, s->total_norm,
+                       s->stream));
+    return VN_OK;
+}

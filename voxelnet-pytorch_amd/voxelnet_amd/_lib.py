@@ -75,6 +75,20 @@ class VnParamChunk(ctypes.Structure):
     _fields_ = [("param", c_vp), ("grad", c_vp), ("n", c_i32), ("reserved", c_i32)]
 
 
+class VnStep(ctypes.Structure):       # vnStep (vn_net_step): field for field
+    _fields_ = [("feature", c_vp), ("coord", c_vp), ("K", c_i64), ("T", c_i32), ("bn_momentum", c_f32), ("bn_eps", c_f32),
+                ("vfe", VnVfeWeights), ("vfe_grads", VnVfeGrads), ("vfe_ws", c_vp), ("vfe_ws_bytes", c_sz),
+                ("voxelwise", c_vp), ("vfe_stats", c_vp), ("vw_rows", c_vp), ("d_voxelwise", c_vp),
+                ("prob_w", c_vp), ("prob_b", c_vp), ("reg_w", c_vp), ("reg_b", c_vp), ("heads_w", c_vp), ("heads_b", c_vp),
+                ("d_heads_w", c_vp), ("d_heads_b", c_vp), ("layers", c_vp), ("grads", c_vp), ("ws", c_vp), ("ws_bytes", c_sz),
+                ("prob", c_vp), ("reg", c_vp), ("d_prob", c_vp), ("d_reg", c_vp), ("pos", c_vp), ("neg", c_vp),
+                ("targets", c_vp), ("targets_stream", c_vp), ("alpha", c_f32), ("beta", c_f32), ("sigma", c_f32),
+                ("loss_ws", c_vp), ("loss_ws_bytes", c_sz), ("loss5", c_vp), ("g_loss", c_vp), ("chunks", c_vp),
+                ("n_chunks", c_i32), ("max_norm", c_f32), ("lr", c_f32), ("scale_grads", c_i32), ("opt_ws", c_vp),
+                ("opt_ws_bytes", c_sz), ("total_norm", c_vp), ("bn_counters", c_vp), ("n_bn_counters", c_i32), ("stream", c_vp),
+                ("side_stream", c_vp)]
+
+
 # name -> (restype, argtypes); mirrors include/voxelnet_hip.h one to one
 _P = ctypes.POINTER
 SIGNATURES = {
@@ -111,6 +125,7 @@ SIGNATURES = {
     "vn_net_workspace_bytes": (c_sz, [_P(VnNetConfig), c_i64]),
     "vn_net_create": (c_i32, [_P(c_vp)]),
     "vn_net_destroy": (c_i32, [c_vp]),
+    "vn_net_step": (c_i32, [c_vp, _P(VnNetConfig), _P(VnStep)]),
     "vn_net_timing_begin": (c_i32, [c_vp, c_i32]),
     "vn_net_timing_read": (c_i32, [c_vp, c_vp, c_i32, _P(c_i32)]),
     "vn_net_forward": (c_i32, [c_vp, _P(VnNetConfig), _P(VnLayerParams), c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_sz, c_vp,
@@ -278,3 +293,20 @@ def on_device(device):
     if idx is None or idx == torch._C._cuda_getDevice():
         return _HERE
     return torch.cuda.device(device)
+
+
+_STREAM_OBJS = {}
+
+
+def current_stream(device=None):
+    """torch.cuda.current_stream(device) without building a new Stream object per call (~6 us through three Python layers):
+    the (stream id, device index, device type) triple of torch's C accessor keys a cache of Stream objects"""
+    import torch
+    idx = getattr(device, "index", device)
+    if idx is None:
+        idx = torch._C._cuda_getDevice()
+    key = torch._C._cuda_getCurrentStream(idx)
+    st = _STREAM_OBJS.get(key)
+    if st is None:
+        st = _STREAM_OBJS[key] = torch.cuda.current_stream(idx)
+    return st

@@ -550,6 +550,7 @@ def _grad_views(rpn, fresh=False):
             out = {}
             for b in rpn.grad_reducer.buckets:
                 out.update(b["views"])
+            out.update(getattr(rpn.grad_reducer, "fused_views", {}))
             hit = (rpn.grad_reducer, out)
             rpn.__dict__["_bucket_views"] = hit
         return hit[1]
@@ -628,7 +629,7 @@ class _DetectorFn(torch.autograd.Function):
                     # form), then the (16,768) / (16,) concatenations of the two heads' parameters — two small launches the
                     # weight packing reads — and the rest of the packing
                     side_t = rpn.__dict__["_side"]
-                    side_t.wait_stream(torch.cuda.current_stream())
+                    side_t.wait_stream(_lib.current_stream(dev_))
                     two_phase = not _PREP_JOIN      # ("1": the round-2 schedule, one call, for A/B runs)
                     if two_phase:
                         cfg.prepared = 1                       # phase 1: the first layer's needs only
@@ -637,7 +638,7 @@ class _DetectorFn(torch.autograd.Function):
                     with torch.cuda.stream(side_t):
                         heads = _heads_params([f.detach() for f in flat[-4:]])
                     for t_ in heads.values():
-                        t_.record_stream(torch.cuda.current_stream())
+                        t_.record_stream(_lib.current_stream(dev_))
                     cfg.prepared = 2 if two_phase else 0       # phase 2: the rest (0: everything in this one call)
                     _lib.call("vn_net_prepare", rpn._net_handle(dev_), ctypes.byref(cfg), arr, heads["weight"].data_ptr(), coord.data_ptr(), K,
                               ws.data_ptr(), ws_bytes, side)
@@ -952,7 +953,7 @@ class RPN3D(nn.Module):
     # gradient buffer, device-side target / decode helpers).  They are rebuilt on demand and must not travel with
     # `torch.save(model)` (the reference's checkpoint format, train.py:24/27) or `copy.deepcopy(model)`.
     _RUNTIME_KEYS = ("_side", "_tgt_stream", "_ws_pool", "_flat_grads", "_targets", "_decoder", "_nbt", "_flat_param_list", "_net_ctx",
-                     "_named_param_list", "_anchor_t", "_bucket_views", "_mg_cache")
+                     "_named_param_list", "_anchor_t", "_bucket_views", "_mg_cache", "_step_sc", "_nbt_table")
 
     def __getstate__(self):
         d = self.__dict__.copy()
@@ -1121,6 +1122,197 @@ class RPN3D(nn.Module):
         return _LossFn.apply(prob_out, delta_out, f32(pos_equal_one), f32(neg_equal_one), f32(targets),
                              float(self.alpha), float(self.beta), float(self.sigma))
 
+    # ---- one library call per train step (vn_net_step) ------------------------------------------------------------------
+    def _step_scratch(self, dev, K, T, B, mode, ws_bytes):
+        """scratch buffers of vn_net_step, kept on the module and grown with K (nothing here is seen by the caller; the
+        step's streams are joined at its end, so the next step may overwrite them)"""
+        sc = self.__dict__.get("_step_sc")
+        cap = (K + 4095) // 4096 * 4096
+        lib = _lib.load()
+        hf, wf = self.rpn_output_shape
+        key = (dev, T, B, mode, hf, wf)
+        if sc is None or sc["key"] != key or sc["cap"] < K:
+            cap = max(cap, sc["cap"] if sc is not None and sc["key"] == key else 0)
+            sc = {"key": key, "cap": cap}
+            sc["vfe_ws_bytes"] = lib.vn_vfe_workspace_bytes(cap, T)
+            sc["vfe_ws"] = torch.empty(sc["vfe_ws_bytes"], dtype=torch.uint8, device=dev)
+            sc["vw"] = torch.empty((cap, 128), dtype=torch.float32, device=dev)
+            sc["vw_rows"] = torch.empty((cap, 128), dtype=torch.bfloat16, device=dev) if mode == "bf16" else sc["vw"]
+            sc["d_vw"] = torch.empty((cap, 128), dtype=torch.float32, device=dev)
+            sc["stats"] = torch.empty(320, dtype=torch.float32, device=dev)
+            sc["heads_w"] = torch.empty((16, 768), dtype=torch.float32, device=dev)
+            sc["heads_b"] = torch.empty(16, dtype=torch.float32, device=dev)
+            sc["d_prob"] = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=dev)
+            sc["d_reg"] = torch.empty((B, 14, hf, wf), dtype=torch.float32, device=dev)
+            sc["loss_ws_bytes"] = lib.vn_rpn_loss_workspace_bytes(B, hf, wf)
+            sc["loss_ws"] = torch.empty(sc["loss_ws_bytes"], dtype=torch.uint8, device=dev)
+            sc["one"] = torch.ones(1, dtype=torch.float32, device=dev)
+            sc["args"] = _lib.VnStep()
+            self.__dict__["_step_sc"] = sc
+        return sc
+
+    def _step_fused_ok(self, mode, optimizer):
+        from .optim import ClipSGD
+        red = self.grad_reducer
+        return (self._native_ok(mode) and self.training and self.direct_grads and self.overlap_wgrad and self.sparse_first_layer
+                and torch.is_grad_enabled() and self.target_fn is None and E.SECTIONS is None
+                and not (int(self.grad_storage) & 16)
+                and (red is None or (red.comm_stream is not None and HEADS_W in _grad_views(self)))
+                and (optimizer is None or isinstance(optimizer, ClipSGD)))
+
+    def train_step(self, x, device, optimizer=None, targets=None):
+        """One training step — `out = model(x, device); out[2].backward(); clip_grad_norm_; optimizer.step()`
+        (model.py:298-362 and train.py:148-154) — as ONE library call (vn_net_step, csrc/runtime.hip): same kernels, same
+        order, same streams, bit-identical results; what goes is the host's work between the calls (two autograd Functions,
+        the engine's hand-over to its device thread, ~15 tensor allocations, ~12 ctypes calls).
+        Returns the tuple forward() returns (tensors without an autograd graph: the backward has already run); the
+        parameters' .grad are set as backward() leaves them.  optimizer: a ClipSGD (its update runs inside the call when no
+        gradient reducer is attached, after the reducer's exchange otherwise) or None (no update).
+        Whatever the fused call does not cover — per-layer orchestration, eval mode, target_fn, gradient accumulation, a
+        reducer without a communication stream, bench.py's per-section timer — takes the separate calls, same results."""
+        mode = _mode()
+        fused = self._step_fused_ok(mode, optimizer)
+        plist = self._flat_params() if fused else None
+        if fused and (not self._all_need_grad(plist) or any(p.grad is not None for p in plist)):
+            fused = False            # (frozen parameters / accumulation into existing .grad: autograd's business)
+        label, voxel_features, voxel_coordinates = x[1], x[2], x[4]
+        if fused and not (targets is not None or label is not None):
+            fused = False
+        if not fused:
+            out = self(x, device, targets=targets)
+            out[2].backward()
+            if self.grad_reducer is not None:
+                self.grad_reducer.finish(self._named_params())
+            if optimizer is not None:
+                optimizer.step()
+            return out
+        voxel_features = _parts_to(voxel_features, device)
+        voxel_coordinates = _parts_to(voxel_coordinates, device)
+        dev = voxel_features[0].device
+        if not voxel_features[0].is_cuda:
+            raise _lib.VoxelnetHipError("RPN3D.train_step: the voxel buffers must live on a HIP device (no CPU path)")
+        red = self.grad_reducer
+        with _lib.on_device(dev):
+            ts = None
+            if targets is None:
+                ts = self.__dict__.get("_tgt_stream")
+                if ts is None or ts.device != dev:
+                    from .voxelize import pipeline_stream
+                    ts = self.__dict__["_tgt_stream"] = pipeline_stream(dev)
+                with torch.cuda.stream(ts):
+                    targets = self._target_generator(dev)(label)
+            else:
+                def f32(a):
+                    if torch.is_tensor(a) and a.dtype == torch.float32 and a.device == dev and a.is_contiguous():
+                        return a
+                    return (a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))).to(dev).float().contiguous()
+                targets = tuple(f32(a) for a in targets)
+            pos, neg, tgt = targets
+            B = len(voxel_features)
+            feature, coord = _batch_cat(voxel_features, torch.float32), _batch_cat(voxel_coordinates, torch.int64)
+            K, T = feature.shape[0], feature.shape[1]
+            fn, mid = self.feature_net, self.middle_rpn
+            D, H, W = fn._grid.dims
+            hf, wf = H // mid._block1_stride, W // mid._block1_stride
+            if tuple(pos.shape) != (B, hf, wf, 2) or tuple(neg.shape) != (B, hf, wf, 2) or tuple(tgt.shape) != (B, hf, wf, 14):
+                raise ValueError(f"train_step: target shapes {tuple(pos.shape)} {tuple(neg.shape)} {tuple(tgt.shape)} do not "
+                                 f"belong to a batch of {B} on a {hf} x {wf} map")
+            cfg = _lib.VnNetConfig(B, D, H, W, mid._block1_stride, {"bf16": 0, "fp32": 1, "fp32x3": 2}[mode], 1, 1, 0, 0, 0, 0)
+            cfg.grad_storage = int(self.grad_storage) & (16 if E.is_f32_storage(mode) else 15)
+            cfg.bucket_events = int(red is not None)
+            lib = _lib.load()
+            ws_bytes = lib.vn_net_workspace_bytes(ctypes.byref(cfg), K)
+            if ws_bytes == 0:
+                raise _lib.VoxelnetHipError("vn_net_workspace_bytes: unsupported network configuration")
+            ws = self._ws_acquire(ws_bytes, dev)
+            sc = self._step_scratch(dev, K, T, B, mode, ws_bytes)
+            views = _grad_views(self)
+            arr, garr = _native_layer_arrays(mid, views)
+            vp = [p for p in plist[:8]]
+            bufs = fn._bufs()
+            hp = plist[-4:]
+            prob = torch.empty((B, 2, hf, wf), dtype=torch.float32, device=dev)
+            reg = torch.empty((B, 14, hf, wf), dtype=torch.float32, device=dev)
+            loss5 = torch.empty(5, dtype=torch.float32, device=dev)
+            a = sc["args"]
+            a.feature, a.coord, a.K, a.T = feature.data_ptr(), coord.data_ptr(), K, T
+            a.bn_momentum, a.bn_eps = E.BN_MOMENTUM, E.BN_EPS
+            a.vfe = _lib.VnVfeWeights(vp[0].data_ptr(), vp[1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(), bufs[0].data_ptr(),
+                                      bufs[1].data_ptr(), vp[4].data_ptr(), vp[5].data_ptr(), vp[6].data_ptr(), vp[7].data_ptr(),
+                                      bufs[2].data_ptr(), bufs[3].data_ptr())
+            a.vfe_grads = _lib.VnVfeGrads(*[views[k].data_ptr() for k in VFE_KEYS])
+            a.vfe_ws, a.vfe_ws_bytes = sc["vfe_ws"].data_ptr(), sc["vfe_ws_bytes"]
+            a.voxelwise, a.vfe_stats, a.vw_rows, a.d_voxelwise = (sc["vw"].data_ptr(), sc["stats"].data_ptr(),
+                                                                  sc["vw_rows"].data_ptr(), sc["d_vw"].data_ptr())
+            a.prob_w, a.prob_b, a.reg_w, a.reg_b = (t.data_ptr() for t in hp)
+            a.heads_w, a.heads_b = sc["heads_w"].data_ptr(), sc["heads_b"].data_ptr()
+            a.d_heads_w, a.d_heads_b = views[HEADS_W].data_ptr(), views[HEADS_B].data_ptr()
+            a.layers, a.grads = ctypes.addressof(arr), ctypes.addressof(garr)
+            a.ws, a.ws_bytes = ws.data_ptr(), ws_bytes
+            a.prob, a.reg, a.d_prob, a.d_reg = prob.data_ptr(), reg.data_ptr(), sc["d_prob"].data_ptr(), sc["d_reg"].data_ptr()
+            a.pos, a.neg, a.targets = pos.data_ptr(), neg.data_ptr(), tgt.data_ptr()
+            a.targets_stream = ts.cuda_stream if ts is not None else None
+            a.alpha, a.beta, a.sigma = float(self.alpha), float(self.beta), float(self.sigma)
+            a.loss_ws, a.loss_ws_bytes, a.loss5, a.g_loss = sc["loss_ws"].data_ptr(), sc["loss_ws_bytes"], loss5.data_ptr(), sc["one"].data_ptr()
+            grads = self.__dict__.get("_mg_cache")
+            if grads is None or grads[0] is not views:
+                grads = (views, [views[n] for n, _ in self._named_params_in_flat_order()])
+                self.__dict__["_mg_cache"] = grads
+            out_grads = grads[1]
+            inside = optimizer is not None and red is None and optimizer._step_table(plist, out_grads)
+            if inside:
+                a.chunks, a.n_chunks = optimizer._table.data_ptr(), optimizer._n_chunks
+                a.max_norm, a.lr, a.scale_grads = optimizer.max_norm, optimizer.lr, int(optimizer.scale_grads)
+                a.opt_ws, a.opt_ws_bytes, a.total_norm = optimizer._ws.data_ptr(), optimizer._ws.numel(), optimizer._norm.data_ptr()
+            else:
+                a.chunks, a.n_chunks, a.opt_ws, a.opt_ws_bytes, a.total_norm = None, 0, None, 0, None
+            a.stream, a.side_stream = _lib.raw_stream(), self._side_stream(dev)
+            a.bn_counters, a.n_bn_counters = self._counter_table(dev)
+            _lib.call("vn_net_step", self._net_handle(dev), ctypes.byref(cfg), ctypes.byref(a))
+            if ts is not None:
+                cur = _lib.current_stream(dev)
+                for t_ in targets:
+                    t_.record_stream(cur)         # (allocated on the target stream, read by the loss kernels on this one)
+            if red is not None:
+                def waiter(bi):
+                    return lambda st: _lib.call("vn_net_wait_bucket", self._net_handle(dev), bi, ctypes.c_void_p(st.cuda_stream))
+                for bi in range(4):
+                    red.launch_bucket(bi, wait_fn=waiter(bi))
+                vfe_done = torch.cuda.Event()
+                vfe_done.record()
+                red.launch_bucket(4, after_event=vfe_done)
+            self._ws_release(ws)
+            for p_, g_ in zip(plist, out_grads):
+                p_.grad = g_
+            if red is not None:
+                red.finish(self._named_params())
+            if optimizer is not None and not inside:
+                optimizer.step()
+        return (prob, reg) + tuple(loss5[i] for i in range(5))
+
+    def _named_params_in_flat_order(self):
+        """(name, parameter) in _flat_params order"""
+        byid = {id(p): n for n, p in self._named_params()}
+        return [(byid[id(p)], p) for p in self._flat_params()]
+
+    def _counter_table(self, dev):
+        """device table of pointers to the 25 num_batches_tracked counters (vnStep.bn_counters): _tick as one launch inside
+        the step call"""
+        hit = self.__dict__.get("_nbt_table")
+        ctrs = self.__dict__.get("_nbt")
+        if ctrs is None or ctrs[0].device != dev:
+            ctrs = [m.num_batches_tracked for m in self.modules()
+                    if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d))]
+            self.__dict__["_nbt"] = ctrs
+        key = (dev, ctrs[0].data_ptr(), ctrs[-1].data_ptr())
+        if hit is None or hit[0] != key:
+            if any(c.dtype != torch.int64 or c.device != dev for c in ctrs):
+                raise _lib.VoxelnetHipError("num_batches_tracked: int64 counters on the step's device expected")
+            tab = torch.tensor([c.data_ptr() for c in ctrs], dtype=torch.int64).to(dev)
+            hit = (key, tab, len(ctrs))
+            self.__dict__["_nbt_table"] = hit
+        return hit[1].data_ptr(), hit[2]
+
     def forward(self, x, device, targets=None):
         label, voxel_features, voxel_coordinates = x[1], x[2], x[4]
         voxel_features = _parts_to(voxel_features, device)               # model.py:302-303
@@ -1139,7 +1331,7 @@ class RPN3D(nn.Module):
                 early = self._target_generator(dev_)(label)
         prob_out, delta_out = self.detect(voxel_features, voxel_coordinates)
         if early is not None:
-            cur = torch.cuda.current_stream(prob_out.device)
+            cur = _lib.current_stream(prob_out.device)
             cur.wait_stream(self.__dict__["_tgt_stream"])
             for t_ in early:
                 t_.record_stream(cur)         # (allocated on the target stream, read by the loss kernels on this one)

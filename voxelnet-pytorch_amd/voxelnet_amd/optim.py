@@ -33,7 +33,7 @@ class ClipSGD(torch.optim.Optimizer):
         self._key = None
         self._table = self._ws = self._norm = None
         self._n_chunks = 0
-        self._plist = self._last_grads = self._last_pptrs = None
+        self._plist = self._last_grads = self._last_pptrs = self._fused_key = None
 
     # (kept for callers of the round-1 class)
     @property
@@ -57,7 +57,7 @@ class ClipSGD(torch.optim.Optimizer):
         self._key = None                  # device chunk table / workspace: rebuilt on the first step
         self._table = self._ws = self._norm = None
         self._n_chunks = 0
-        self._plist = self._last_grads = self._last_pptrs = None
+        self._plist = self._last_grads = self._last_pptrs = self._fused_key = None
 
     def zero_grad(self, set_to_none=True):
         """torch.optim.Optimizer.zero_grad without its per-parameter foreach bookkeeping (104 small tensors)"""
@@ -68,7 +68,7 @@ class ClipSGD(torch.optim.Optimizer):
 
     def add_param_group(self, group):
         super().add_param_group(group)
-        self._plist = self._last_grads = self._last_pptrs = None
+        self._plist = self._last_grads = self._last_pptrs = self._fused_key = None
 
     def _build(self, pairs, dev):
         rows = []
@@ -83,6 +83,39 @@ class ClipSGD(torch.optim.Optimizer):
         nbytes = _lib.load().vn_clip_sgd_workspace_bytes(self._n_chunks)
         self._ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
+
+    def _step_table(self, params, grads):
+        """RPN3D.train_step (vn_net_step): make sure the device chunk table covers exactly the pairs (params[i], grads[i]) —
+        the gradients are not attached to the parameters yet, the update runs inside the library call — and that this
+        optimizer's parameters are those.  -> True: _table / _ws / _norm are valid for the call; False: use step()."""
+        for g in self.param_groups[1:]:
+            if g["lr"] != self.param_groups[0]["lr"] or g["max_norm"] != self.param_groups[0]["max_norm"]:
+                return False
+        plist = self.__dict__.get("_plist")
+        if plist is None:
+            plist = self._plist = self.params
+        pptrs = [p.data_ptr() for p in params]
+        hit = self.__dict__.get("_fused_key")
+        if hit is not None and hit[0] is params and hit[1] is grads and hit[2] == pptrs and self._table is not None:
+            return True
+        if len(plist) != len(params) or {id(p) for p in plist} != {id(p) for p in params}:
+            return False
+        dev = params[0].device
+        for p, g in zip(params, grads):
+            if not (p.is_cuda and g.is_cuda and p.device == dev and g.device == dev and p.dtype == torch.float32
+                    and g.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous() and p.numel() == g.numel()):
+                return False
+        gmap = {id(p): g for p, g in zip(params, grads)}
+        pairs = [(p, gmap[id(p)]) for p in plist]
+        key = tuple((p.data_ptr(), g.data_ptr(), p.numel()) for p, g in pairs)
+        if key != self._key:
+            self._build(pairs, dev)
+            self._key = key
+        self._n_elems = sum(p.numel() for p in plist)
+        self._last_grads = [gmap[id(p)] for p in plist]      # (step() right after the call would see the same tensors)
+        self._last_pptrs = [p.data_ptr() for p in plist]
+        self._fused_key = (params, grads, pptrs)
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):

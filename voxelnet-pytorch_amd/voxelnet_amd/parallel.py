@@ -45,6 +45,10 @@ _COMM_ASYNC = os.environ.get("VN_COMM_ASYNC")
 MERGE_PLANS = {"5": [(0,), (1,), (2,), (3,), (4,)], "2": [(0, 1, 2), (3, 4)], "1": [(0, 1, 2, 3, 4)]}
 
 
+_HEADS_W = ["middle_rpn.prob_conv.conv.weight", "middle_rpn.reg_conv.conv.weight"]
+_HEADS_B = ["middle_rpn.prob_conv.conv.bias", "middle_rpn.reg_conv.conv.bias"]
+
+
 def group_of(param_name):
     """state_dict key -> bucket group name"""
     if param_name.startswith("feature_net."):
@@ -81,6 +85,7 @@ class GradAllReducer:
         dev0, dt0 = named_params[0][1].device, named_params[0][1].dtype
         self.flat_all = torch.zeros(max(tot, 1), dtype=dt0, device=dev0)
         self._span = []            # per bucket: (start, end) in flat_all
+        self.fused_views = {}      # model.HEADS_W / HEADS_B -> the (16,768) / (16,) views over both heads' gradients
         for bi, groups in enumerate(plan):
             members = [(n, p) for n, p in named_params if group_of(n) in groups]
             if not members:
@@ -88,11 +93,21 @@ class GradAllReducer:
             total = sum(p.numel() for _, p in members)
             flat = self.flat_all[starts[bi]:starts[bi] + total]
             self._span.append((starts[bi], starts[bi] + total))
-            views, off = {}, 0
+            # the two heads' weights (and biases) back to back at the bucket's end: the executor's fused (16,768) heads
+            # gradient then IS the two parameters' gradients (model._grad_views does the same in its own flat buffer)
+            names_here = [n for n, _ in members]
+            if all(h in names_here for h in _HEADS_W + _HEADS_B):
+                members = [(n, p) for n, p in members if n not in _HEADS_W + _HEADS_B] + \
+                          [(n, dict(members)[n]) for n in _HEADS_W + _HEADS_B]
+            views, off, start = {}, 0, {}
             for n, p in members:
                 views[n] = flat[off:off + p.numel()].view_as(p)
+                start[n] = off
                 off += p.numel()
                 self.where[n] = len(self.buckets)
+            if all(h in start for h in _HEADS_W + _HEADS_B) and views[_HEADS_W[0]].numel() + views[_HEADS_W[1]].numel() == 16 * 768:
+                self.fused_views["__heads_weight_fused__"] = flat[start[_HEADS_W[0]]:start[_HEADS_W[0]] + 16 * 768].view(16, 768, 1, 1)
+                self.fused_views["__heads_bias_fused__"] = flat[start[_HEADS_B[0]]:start[_HEADS_B[0]] + 16]
             self.buckets.append({"flat": flat, "views": views, "pending": set(), "handle": None, "names": list(views),
                                  "index": len(self.buckets)})
         missing = [n for n, _ in named_params if n not in self.where]

@@ -67,7 +67,8 @@ class AsyncVoxels:
         self._f, self._c, self._n, self._k, self._ev = feature, coord, number, k_host, event
 
     def result(self):
-        self._ev.synchronize()
+        if not self._ev.query():          # (normally long finished: a query costs ~1 us, a synchronize ~35)
+            self._ev.synchronize()
         K = int(self._k[0])
         return self._f[:K], self._c[:K], self._n[:K]
 
@@ -126,7 +127,7 @@ def voxelize_device_async(points, grid, batch_index=0, coord_cols=4, buffers=Non
         k_host = buffers.k_host if buffers is not None else torch.empty(1, dtype=torch.int32, pin_memory=True)
         k_host.copy_(k_dev, non_blocking=True)
         ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream())
+        ev.record()
     return AsyncVoxels(feature, coord, number, k_host, ev)
 
 
@@ -172,7 +173,7 @@ class VoxelBatch(list):
         """the concatenation, ordered into the current stream (or None: the caller concatenates)"""
         if self.cat is None:
             return None
-        cur = torch.cuda.current_stream(self.cat.device)
+        cur = _lib.current_stream(self.cat.device)
         cur.wait_event(self.cat_event)
         self.cat.record_stream(cur)
         return self.cat
