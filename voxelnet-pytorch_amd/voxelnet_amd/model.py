@@ -1123,13 +1123,12 @@ class RPN3D(nn.Module):
                              float(self.alpha), float(self.beta), float(self.sigma))
 
     # ---- one library call per train step (vn_net_step) ------------------------------------------------------------------
-    def _step_scratch(self, dev, K, T, B, mode, ws_bytes):
+    def _step_scratch(self, dev, K, T, B, mode, hf, wf):
         """scratch buffers of vn_net_step, kept on the module and grown with K (nothing here is seen by the caller; the
         step's streams are joined at its end, so the next step may overwrite them)"""
         sc = self.__dict__.get("_step_sc")
         cap = (K + 4095) // 4096 * 4096
         lib = _lib.load()
-        hf, wf = self.rpn_output_shape
         key = (dev, T, B, mode, hf, wf)
         if sc is None or sc["key"] != key or sc["cap"] < K:
             cap = max(cap, sc["cap"] if sc is not None and sc["key"] == key else 0)
@@ -1225,7 +1224,7 @@ class RPN3D(nn.Module):
             if ws_bytes == 0:
                 raise _lib.VoxelnetHipError("vn_net_workspace_bytes: unsupported network configuration")
             ws = self._ws_acquire(ws_bytes, dev)
-            sc = self._step_scratch(dev, K, T, B, mode, ws_bytes)
+            sc = self._step_scratch(dev, K, T, B, mode, hf, wf)
             views = _grad_views(self)
             arr, garr = _native_layer_arrays(mid, views)
             vp = [p for p in plist[:8]]
