@@ -135,3 +135,60 @@ def test_what_the_one_call_step_does_not_cover_takes_the_separate_calls():
         assert all(torch.equal(p, q) for p, q in zip(m.parameters(), m2.parameters()))
     finally:
         M.set_precision("bf16")
+
+
+def test_one_call_step_on_another_grid_with_ragged_batches():
+    """a 10 x 16 x 24 grid (8 x 12 map: not the class default the scratch buffers could be mis-sized for), batch 3 with an
+    EMPTY frame, K changing from step to step (the scratch grows), fp32 mode: bit-identical to the separate calls"""
+    from voxelnet_amd import model as M
+    from voxelnet_amd import synth
+    from voxelnet_amd.config import GRADIENT_CLIP, LR, grid_config
+    from voxelnet_amd.optim import ClipSGD
+    from voxelnet_amd.voxelize import voxelize_device
+    g = grid_config("Car", D=10, H=16, W=24, oy=1.6)
+    rng = np.random.default_rng(11)
+    batches = []
+    for step, k0 in enumerate((60, 400, 150)):
+        feats, coords = [], []
+        for i in range(3):
+            cloud = synth.synth_cloud("Car", k0=k0 + 20 * i, seed=2100 + 10 * step + i, grid=g, overflow_frac=0.03)
+            if i == step % 3:
+                cloud = cloud.copy()
+                cloud[:, 0] = -500.0
+            fb, cb, _ = voxelize_device(torch.from_numpy(cloud).to(DEV), g, i, coord_cols=4)
+            feats.append(fb)
+            coords.append(cb)
+        pos = (rng.random((3, 8, 12, 2)) < 0.05).astype(np.float32)
+        neg = ((rng.random((3, 8, 12, 2)) < 0.9) & (pos == 0)).astype(np.float32)
+        tgt = (rng.standard_normal((3, 8, 12, 14)) * 0.1).astype(np.float32)
+        batches.append(((None, None, feats, None, coords, None, None), (pos, neg, tgt)))
+    assert len({sum(f.shape[0] for f in b[0][2]) for b in batches}) == 3
+    res = []
+    try:
+        M.set_precision("fp32")
+        for fused in (False, True):
+            torch.manual_seed(99)
+            m = M.RPN3D("Car")
+            m.feature_net._grid = g
+            m = m.to(DEV).train()
+            opt = ClipSGD(list(m.parameters()), LR, GRADIENT_CLIP)
+            outs = []
+            for x, t in batches:
+                if fused:
+                    assert m._step_fused_ok("fp32", opt)
+                    out = m.train_step(x, DEV, opt, targets=t)
+                else:
+                    out = m(x, DEV, targets=t)
+                    out[2].backward()
+                    opt.step()
+                outs.append([o.detach().clone() for o in out])
+                opt.zero_grad(set_to_none=True)
+            torch.cuda.synchronize()
+            res.append((outs, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    finally:
+        M.set_precision("bf16")
+    (oa, sa), (ob, sb) = res
+    assert oa[0][0].shape == (3, 2, 8, 12)
+    for step in range(3):
+        assert all(torch.equal(a, b) for a, b in zip(oa[step], ob[step])), step
+    assert all(torch.equal(sa[k], sb[k]) for k in sa)
