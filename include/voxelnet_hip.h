@@ -471,11 +471,13 @@ int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *lay
 /* ONE call per train step (voxelnet/model.py:298-362 + voxelnet/train.py:151-154): the voxel feature encoder, the
  * middle layers + RPN, the loss, the whole backward and (n_chunks > 0) clip_grad_norm_ + SGD, issued in the order and on
  * the streams the separate calls are issued by a host that overlaps them by hand:
- *   side:  [wait stream]  counters += 1 | vn_net_prepare phase 1 | heads' parameters -> heads_w / heads_b | vn_net_prepare phase 2
- *   main:  vn_vfe_fwd | (bf16 mode) vn_cast_rows -> vw_rows | vn_net_forward | [wait targets_stream] vn_rpn_loss_fwd |
- *          vn_rpn_loss_bwd (g_loss) | vn_net_backward(0..24, defer_join) | vn_vfe_bwd | [wait side] | vn_clip_sgd
- * Same kernels, same order, same results as those calls (tests/test_gpu_step.py: bit-identical); what it saves is the
- * host's work between them.  Every buffer is the caller's; scratch ones (voxelwise, vfe_stats, vw_rows, d_voxelwise,
+ *   side:  [wait stream]  counters += 1 | vn_net_prepare phase 1 | heads' parameters -> heads_w / heads_b | vn_net_prepare phase 2 |
+ *          [wait targets_stream] vn_rpn_loss_norm | ... | [wait the pass] vn_rpn_loss_finalize -> loss5
+ *   main:  vn_vfe_fwd | (bf16 mode) vn_cast_rows -> vw_rows | vn_net_forward | [wait the normalisers] vn_rpn_loss_fwd_bwd
+ *          (g_loss): ONE launch between the heads and their backward | vn_net_backward(0..24, defer_join) | vn_vfe_bwd |
+ *          [wait side] | vn_clip_sgd
+ * Same arithmetic and same results as those calls (tests/test_gpu_step.py: bit-identical); what it saves is the host's
+ * work between them and four of the five loss launches on the chain between the network's forward and backward.  Every buffer is the caller's; scratch ones (voxelwise, vfe_stats, vw_rows, d_voxelwise,
  * heads_w / heads_b, d_prob / d_reg, the three workspaces) need only live until the step has run.
  * Requires cfg->sparse_first, cfg->training and a side stream (VN_EUNSUPPORTED / VN_EINVAL otherwise).
  * cfg->bucket_events is honoured (vn_net_wait_bucket after the call; pass n_chunks = 0 and update after the exchange). */
@@ -718,6 +720,21 @@ int vn_rpn_loss_bwd(const float *prob, const float *delta, const float *pos, con
                     const void *workspace, const float *g_loss, const float *g_cls, const float *g_reg,
                     const float *g_cls_pos, const float *g_cls_neg, float *d_prob, float *d_delta,
                     vnStream stream);
+
+/* The same loss in three pieces for a caller that schedules them itself (vn_net_step does): the normalisers depend on
+ * the target maps only (vn_rpn_loss_norm: any stream, any time before the pass); vn_rpn_loss_fwd_bwd is ONE pass over the
+ * sites that leaves the forward partial sums in the workspace AND writes both gradients; vn_rpn_loss_finalize turns the
+ * partial sums into out5 (nobody's input in a train step: it need not sit between the network's forward and backward).
+ * Same workspace throughout; results bit-identical to vn_rpn_loss_fwd + vn_rpn_loss_bwd. */
+int vn_rpn_loss_norm(const float *pos, const float *neg, int32_t B, int32_t H, int32_t W, void *workspace,
+                     size_t workspace_bytes, vnStream stream);
+int vn_rpn_loss_fwd_bwd(const float *prob, const float *delta, const float *pos, const float *neg,
+                        const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
+                        void *workspace, size_t workspace_bytes, const float *g_loss, const float *g_cls,
+                        const float *g_reg, const float *g_cls_pos, const float *g_cls_neg, float *d_prob,
+                        float *d_delta, vnStream stream);
+int vn_rpn_loss_finalize(const void *workspace, size_t workspace_bytes, int32_t B, int32_t H, int32_t W, float alpha,
+                         float beta, float *out5, vnStream stream);
 
 /* ---- optimizer tail (voxelnet/train.py:153-154 with the optimizer of train.py:130-132) ---------------------
  * torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by SGD(lr) without momentum / weight decay:

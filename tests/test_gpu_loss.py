@@ -68,3 +68,36 @@ def test_loss_rejects_bad_shapes():
     prob, delta, pos, neg, tgt = [t.to(DEV) for t in _case(2, 8, 8, 3)]
     with pytest.raises(ValueError):
         M._LossFn.apply(prob, delta[:, :7], pos, neg, tgt, 1.5, 1.0, 3.0)
+
+
+@pytest.mark.parametrize("B,H,W,empty", [(2, 16, 24, False), (3, 7, 5, True), (2, 200, 176, False)])
+def test_loss_in_three_pieces_equals_the_two_passes_bit_for_bit(B, H, W, empty):
+    """vn_rpn_loss_norm + vn_rpn_loss_fwd_bwd (ONE pass: sums and gradients) + vn_rpn_loss_finalize — the form vn_net_step
+    schedules — against vn_rpn_loss_fwd + vn_rpn_loss_bwd: the five scalars and both gradients bit-identical, with all five
+    upstream gradients set and with only g_loss (NULL for the others)"""
+    from voxelnet_amd import _lib
+    prob, delta, pos, neg, tgt = (t.to(DEV).contiguous() for t in _case(B, H, W, 21 + B, empty))
+    lib = _lib.load()
+    wsb = lib.vn_rpn_loss_workspace_bytes(B, H, W)
+    st = _lib.raw_stream()
+    gw = [torch.tensor([v], device=DEV) for v in (1.0, 0.3, -0.7, 0.11, 2.0)]
+    for ups in (gw, [gw[0], None, None, None, None]):
+        gp = [None if g is None else g.data_ptr() for g in ups]
+        ws_a = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+        out_a = torch.empty(5, device=DEV)
+        dp_a, dd_a = torch.empty_like(prob), torch.empty_like(delta)
+        _lib.call("vn_rpn_loss_fwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(), B, H, W,
+                  1.5, 1.0, 3.0, ws_a.data_ptr(), wsb, out_a.data_ptr(), st)
+        _lib.call("vn_rpn_loss_bwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(), B, H, W,
+                  1.5, 1.0, 3.0, ws_a.data_ptr(), *gp, dp_a.data_ptr(), dd_a.data_ptr(), st)
+        ws_b = torch.full((wsb,), 255, dtype=torch.uint8, device=DEV)
+        out_b = torch.empty(5, device=DEV)
+        dp_b, dd_b = torch.empty_like(prob), torch.empty_like(delta)
+        _lib.call("vn_rpn_loss_norm", pos.data_ptr(), neg.data_ptr(), B, H, W, ws_b.data_ptr(), wsb, st)
+        _lib.call("vn_rpn_loss_fwd_bwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(), B, H, W,
+                  1.5, 1.0, 3.0, ws_b.data_ptr(), wsb, *gp, dp_b.data_ptr(), dd_b.data_ptr(), st)
+        _lib.call("vn_rpn_loss_finalize", ws_b.data_ptr(), wsb, B, H, W, 1.5, 1.0, out_b.data_ptr(), st)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, out_b), (out_a, out_b)
+        assert torch.equal(dp_a, dp_b) and torch.equal(dd_a, dd_b)
+        assert torch.isfinite(out_a).all()

@@ -71,7 +71,9 @@ struct LossGrads {
     const float *g[5];
 };
 
-template <bool BWD>
+// MODE 0: the forward sums; 1: the gradients; 2: both in ONE pass over the sites (vn_rpn_loss_fwd_bwd: the same arithmetic in
+// the same order per thread, so sums and gradients are bit-identical to the two separate passes)
+template <int MODE>
 __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__ prob, const float *__restrict__ reg,
                                                        const float *__restrict__ pos, const float *__restrict__ neg,
                                                        const float *__restrict__ tgt, const float *__restrict__ norm,
@@ -79,6 +81,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
                                                        LossGrads gout /* bwd: five device scalars, NULL = 0 */,
                                                        float *__restrict__ d_prob, float *__restrict__ d_reg) {
     VN_PRIO_MAIN();
+    constexpr bool BWD = MODE != 0, FWD = MODE != 1;
     const int64_t hw = (int64_t)g.H * g.W, sites = hw * g.B;
     const int64_t site = (int64_t)blockIdx.x * LOSS_THREADS + threadIdx.x;
     float s_pos = 0.f, s_neg = 0.f, s_reg = 0.f;
@@ -101,9 +104,8 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
         for (int a = 0; a < 2; ++a) {
             const int64_t pi = ((int64_t)b * 2 + a) * hw + yx;
             const float p = prob[pi];
-            if (BWD) {
-                d_prob[pi] = -kp * pa[a] * inv_p / (p + 1e-6f) + kn * na[a] * inv_n / (1.f - p + 1e-6f);
-            } else {
+            if (BWD) d_prob[pi] = -kp * pa[a] * inv_p / (p + 1e-6f) + kn * na[a] * inv_n / (1.f - p + 1e-6f);
+            if (FWD) {
                 s_pos += -pa[a] * logf(p + 1e-6f) * inv_p;
                 s_neg += -na[a] * logf(1.f - p + 1e-6f) * inv_n;
             }
@@ -115,11 +117,11 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
                 float dd;
                 const float l = smooth_l1(diff, g.sigma2, &dd);
                 if (BWD) d_reg[ri] = kr * dd * pa[a] * inv_p;
-                else s_reg += l * inv_p;
+                if (FWD) s_reg += l * inv_p;
             }
         }
     }
-    if (!BWD) {
+    if (FWD) {
         __shared__ float red[3][LOSS_THREADS / 64];
         s_pos = vn_wave_sum(s_pos); s_neg = vn_wave_sum(s_neg); s_reg = vn_wave_sum(s_reg);
         if ((threadIdx.x & 63) == 0) {
@@ -184,7 +186,7 @@ extern "C" int vn_rpn_loss_fwd(const float *prob, const float *delta, const floa
     k_loss_norm_final<<<B, 64, 0, st>>>(slab, norm, B);
     VN_LAUNCH_STATUS();
     const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
-    k_loss<false><<<blocks, LOSS_THREADS, 0, st>>>(prob, delta, pos, neg, targets, norm, g, slab, LossGrads{}, nullptr, nullptr);
+    k_loss<0><<<blocks, LOSS_THREADS, 0, st>>>(prob, delta, pos, neg, targets, norm, g, slab, LossGrads{}, nullptr, nullptr);
     VN_LAUNCH_STATUS();
     k_loss_finalize<<<1, LOSS_THREADS, 0, st>>>(slab, blocks, alpha, beta, out5);
     VN_LAUNCH_STATUS();
@@ -201,9 +203,57 @@ extern "C" int vn_rpn_loss_bwd(const float *prob, const float *delta, const floa
     const float *norm = static_cast<const float *>(workspace);   // written by vn_rpn_loss_fwd
     const int blocks = (int)vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
     const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
-    k_loss<true><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, nullptr,
+    k_loss<1><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, nullptr,
                                                                   LossGrads{{g_loss, g_cls, g_reg, g_cls_pos, g_cls_neg}},
                                                                   d_prob, d_delta);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+// ---- the same loss in three pieces, for a caller that schedules them itself (vn_net_step): the normalisers depend on the
+// target maps only (any stream, any time before the pass), ONE pass over the sites gives the forward sums AND the
+// gradients, and the five output scalars — nobody's input in a train step — are finished wherever there is room.
+// Bit-identical to vn_rpn_loss_fwd + vn_rpn_loss_bwd (tests/test_gpu_loss.py).
+extern "C" int vn_rpn_loss_norm(const float *pos, const float *neg, int32_t B, int32_t H, int32_t W, void *workspace,
+                                size_t workspace_bytes, vnStream stream) {
+    VN_CHECK_ARG(pos && neg && workspace && loss_args_ok(B, H, W));
+    if (workspace_bytes < vn_rpn_loss_workspace_bytes(B, H, W)) return VN_EWORKSPACE;
+    hipStream_t st = vn_stream(stream);
+    float *norm = static_cast<float *>(workspace);
+    float *slab = reinterpret_cast<float *>(static_cast<char *>(workspace) + vn_align(sizeof(float) * 2 * (size_t)B));
+    k_loss_norm<<<B * NORM_CHUNKS, LOSS_THREADS, 0, st>>>(pos, neg, (int64_t)H * W * 2, slab);   // slab: scratch here
+    VN_LAUNCH_STATUS();
+    k_loss_norm_final<<<B, 64, 0, st>>>(slab, norm, B);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_rpn_loss_fwd_bwd(const float *prob, const float *delta, const float *pos, const float *neg,
+                                   const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
+                                   void *workspace, size_t workspace_bytes, const float *g_loss, const float *g_cls,
+                                   const float *g_reg, const float *g_cls_pos, const float *g_cls_neg, float *d_prob,
+                                   float *d_delta, vnStream stream) {
+    VN_CHECK_ARG(prob && delta && pos && neg && targets && workspace && d_prob && d_delta && loss_args_ok(B, H, W) &&
+                 sigma > 0.f);
+    if (workspace_bytes < vn_rpn_loss_workspace_bytes(B, H, W)) return VN_EWORKSPACE;
+    const float *norm = static_cast<const float *>(workspace);   // written by vn_rpn_loss_norm
+    float *slab = reinterpret_cast<float *>(static_cast<char *>(workspace) + vn_align(sizeof(float) * 2 * (size_t)B));
+    const int blocks = (int)vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
+    const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
+    k_loss<2><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, slab,
+                                                               LossGrads{{g_loss, g_cls, g_reg, g_cls_pos, g_cls_neg}}, d_prob,
+                                                               d_delta);
+    VN_LAUNCH_STATUS();
+    return VN_OK;
+}
+
+extern "C" int vn_rpn_loss_finalize(const void *workspace, size_t workspace_bytes, int32_t B, int32_t H, int32_t W, float alpha,
+                                    float beta, float *out5, vnStream stream) {
+    VN_CHECK_ARG(workspace && out5 && loss_args_ok(B, H, W));
+    if (workspace_bytes < vn_rpn_loss_workspace_bytes(B, H, W)) return VN_EWORKSPACE;
+    const float *slab = reinterpret_cast<const float *>(static_cast<const char *>(workspace) + vn_align(sizeof(float) * 2 * (size_t)B));
+    const int blocks = (int)vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
+    k_loss_finalize<<<1, LOSS_THREADS, 0, vn_stream(stream)>>>(slab, blocks, alpha, beta, out5);
     VN_LAUNCH_STATUS();
     return VN_OK;
 }

@@ -1341,6 +1341,16 @@ extern "C" int vn_net_step(vnNet *net, const vnNetConfig *cfg, const vnStep *s) 
     VN_HIP(hipGetLastError());
     c.prepared = 2;
     RT(vn_net_prepare(net, &c, s->layers, s->heads_w, s->coord, s->K, s->ws, s->ws_bytes, s->side_stream));
+    // the loss's per-sample normalisers depend on the target maps only: here, beside the encoder, not between the heads and
+    // their backward
+    if (s->targets_stream && s->targets_stream != s->side_stream) {
+        ev = net->next_event();
+        VN_HIP(hipEventRecord(ev, vn_stream(s->targets_stream)));
+        VN_HIP(hipStreamWaitEvent(ss, ev, 0));
+    }
+    RT(vn_rpn_loss_norm(s->pos, s->neg, cfg->B, hf, wf, s->loss_ws, s->loss_ws_bytes, s->side_stream));
+    hipEvent_t ev_norm = net->next_event();
+    VN_HIP(hipEventRecord(ev_norm, ss));
     // main stream: encoder, network, loss
     RT(vn_vfe_fwd(s->feature, s->K, s->T, &s->vfe, 1, s->bn_momentum, s->bn_eps, s->voxelwise, s->vfe_stats, s->vfe_ws,
                   s->vfe_ws_bytes, s->stream));
@@ -1349,15 +1359,15 @@ extern "C" int vn_net_step(vnNet *net, const vnNetConfig *cfg, const vnStep *s) 
     c.prepared = 1;
     RT(vn_net_forward(net, &c, s->layers, s->heads_w, s->heads_b, nullptr, s->coord, s->vw_rows, s->K, s->ws, s->ws_bytes,
                       s->prob, s->reg, s->stream, s->side_stream));
-    if (s->targets_stream && s->targets_stream != s->stream) {
-        ev = net->next_event();
-        VN_HIP(hipEventRecord(ev, vn_stream(s->targets_stream)));
-        VN_HIP(hipStreamWaitEvent(hs, ev, 0));
-    }
-    RT(vn_rpn_loss_fwd(s->prob, s->reg, s->pos, s->neg, s->targets, cfg->B, hf, wf, s->alpha, s->beta, s->sigma, s->loss_ws,
-                       s->loss_ws_bytes, s->loss5, s->stream));
-    RT(vn_rpn_loss_bwd(s->prob, s->reg, s->pos, s->neg, s->targets, cfg->B, hf, wf, s->alpha, s->beta, s->sigma, s->loss_ws,
-                       s->g_loss, nullptr, nullptr, nullptr, nullptr, s->d_prob, s->d_reg, s->stream));
+    // the loss: ONE launch between the heads and their backward (sums and gradients in one pass); its five output scalars are
+    // finished on the side stream (nobody's input)
+    VN_HIP(hipStreamWaitEvent(hs, ev_norm, 0));
+    RT(vn_rpn_loss_fwd_bwd(s->prob, s->reg, s->pos, s->neg, s->targets, cfg->B, hf, wf, s->alpha, s->beta, s->sigma, s->loss_ws,
+                           s->loss_ws_bytes, s->g_loss, nullptr, nullptr, nullptr, nullptr, s->d_prob, s->d_reg, s->stream));
+    ev = net->next_event();
+    VN_HIP(hipEventRecord(ev, hs));
+    VN_HIP(hipStreamWaitEvent(ss, ev, 0));
+    RT(vn_rpn_loss_finalize(s->loss_ws, s->loss_ws_bytes, cfg->B, hf, wf, s->alpha, s->beta, s->loss5, s->side_stream));
     // backward: the last weight gradients and their unpack run on the side stream beside the encoder's backward
     c.defer_join = 1;
     RT(vn_net_backward(net, &c, s->layers, s->heads_w, s->d_prob, s->d_reg, s->prob, nullptr, s->coord, s->vw_rows, s->K, s->ws,
