@@ -1,0 +1,13 @@
+#!/bin/bash
+# the working tree's library against the previous commit's (tools/ubench/bin/libprev.so, built from `git archive HEAD`):
+# a test subset under the new library, then interleaved step A/Bs.  usage: exp_ab_prev.sh "<pytest args>" <tag> <rounds> [configs...]
+cd $GRAFT_REPO_ROOT
+mkdir -p gpurun_out
+PREV=$GRAFT_REPO_ROOT/tools/ubench/bin/libprev.so
+tests=$1; tag=$2; rounds=$3; shift 3
+timeout -k 10 600 python -m pytest $tests -m gpu -x -q > gpurun_out/${tag}_tests.log 2>&1 || { tail -30 gpurun_out/${tag}_tests.log; exit 1; }
+tail -2 gpurun_out/${tag}_tests.log
+for cfg in "$@"; do
+  if [ "$cfg" = car ]; then extra=""; else extra="--config $cfg"; fi
+  bash tools/abn_bench.sh ${tag}_$cfg $rounds "VN_LIB_PATH=$PREV" "-" -- $extra || exit 1
+done
