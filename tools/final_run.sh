@@ -46,4 +46,7 @@ python tools/pmc_counters.py k_vfe 3 gpurun_out/fpmc_vfe_a gpurun_out/fpmc_vfe_b
 python tools/pmc_mfma.py gpurun_out/fpmc_mfma 3 gpurun_out/${R}_pmc_mfma_per_kernel.txt | head -40
 python tools/trace_summary.py $(ls gpurun_out/fstats/*/*kernel_trace.csv gpurun_out/fstats/*kernel_trace.csv 2>/dev/null | head -1) 10 > gpurun_out/${R}_bench_per_step.txt 2>&1 || true
 cp $(ls gpurun_out/fstats/*/*kernel_stats.csv gpurun_out/fstats/*kernel_stats.csv 2>/dev/null | head -1) gpurun_out/${R}_bench_kernel_stats.csv || true
+# two-stream timelines of one executor step (the executor's own event brackets): car and dense
+python tools/step_timeline.py > gpurun_out/${R}_car_timeline.txt 2>&1 || true
+python tools/step_timeline.py --dense > gpurun_out/${R}_dense_timeline.txt 2>&1 || true
 ls gpurun_out/fstats gpurun_out/fpmc_fetch gpurun_out/fpmc_write gpurun_out/fpmc_mfma
