@@ -22,9 +22,9 @@ print("K", K, "T", T)
 bits = feat.view(torch.int32)
 diff = (bits != bits[:, T - 1:T, :]).any(-1)                   # (K, T)
 r = 1 + torch.where(diff.any(1), (diff.int() * torch.arange(1, T + 1, device=dev)).max(1).values, torch.zeros(K, dtype=torch.int64, device=dev))
-nA, nB, nC = int((r <= 8).sum()), int(((r > 8) & (r <= 16)).sum()), int((r > 16).sum())
-print(f"rows: mean {float(r.float().mean()):.2f}  classes r<=8 {nA}  r<=16 {nB}  r<=64 {nC}  -> wave items {(nA + 7) // 8} + {(nB + 3) // 4} + {nC}"
-      f" = {(nA + 7) // 8 + (nB + 3) // 4 + nC}; effective rows {int(r.sum())} of {K * T}")
+nA, nB, nC, nD = int((r <= 8).sum()), int(((r > 8) & (r <= 16)).sum()), int(((r > 16) & (r <= 32)).sum()), int((r > 32).sum())
+print(f"rows: mean {float(r.float().mean()):.2f}  classes r<=8 {nA}  r<=16 {nB}  r<=32 {nC}  r<=64 {nD}  -> wave items {(nA + 7) // 8} + {(nB + 3) // 4}"
+      f" + {(nC + 1) // 2} + {nD} = {(nA + 7) // 8 + (nB + 3) // 4 + (nC + 1) // 2 + nD}; effective rows {int(r.sum())} of {K * T}")
 m = M.RPN3D("Car").to(dev).train()
 params = [p.detach() for p in M._vfe_weights(m.feature_net)]
 bufs = m.feature_net._bufs()

@@ -11,3 +11,10 @@ for cfg in "$@"; do
   if [ "$cfg" = car ]; then extra=""; else extra="--config $cfg"; fi
   bash tools/abn_bench.sh ${tag}_$cfg $rounds "VN_LIB_PATH=$PREV" "-" -- $extra || exit 1
 done
+# VFE alone (both builds), when asked for: VFE_ALONE=1
+if [ -n "$VFE_ALONE" ]; then
+  for i in 1 2 3; do for w in car dense; do
+    echo "prev $w: $(VN_LIB_PATH=$PREV timeout -k 10 120 python tools/bench_vfe.py $w 2>&1 | grep ' ms' | tr '\n' ' ')"
+    echo "new  $w: $(timeout -k 10 120 python tools/bench_vfe.py $w 2>&1 | grep ' ms\|rows:' | tr '\n' ' ')"
+  done; done | tee gpurun_out/${tag}_vfe_alone.txt
+fi
