@@ -735,6 +735,14 @@ int vn_rpn_loss_fwd_bwd(const float *prob, const float *delta, const float *pos,
                         float *d_delta, vnStream stream);
 int vn_rpn_loss_finalize(const void *workspace, size_t workspace_bytes, int32_t B, int32_t H, int32_t W, float alpha,
                          float beta, float *out5, vnStream stream);
+/* vn_rpn_loss_fwd_bwd with the loss's own upstream gradient only, which ALSO writes the (B*H*W, 16) gradient rows the heads'
+ * backward reads — d_logit = d_prob * p * (1 - p) for the two probability columns, then the 14 regression gradients: what
+ * vn_heads_bwd makes of d_prob / d_delta / prob, bit for bit (a thread of the pass holds exactly one such row).  vn_net_step
+ * uses it: the heads_bwd launch leaves the chain between the loss and the heads' data gradient (model.py:303-304 backward). */
+int vn_rpn_loss_fwd_bwd_rows(const float *prob, const float *delta, const float *pos, const float *neg,
+                             const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
+                             void *workspace, size_t workspace_bytes, const float *g_loss, float *d_prob, float *d_delta,
+                             void *d_rows, vnDtype d_dtype, int64_t d_stride, int32_t split, vnStream stream);
 
 /* ---- optimizer tail (voxelnet/train.py:153-154 with the optimizer of train.py:130-132) ---------------------
  * torch.nn.utils.clip_grad_norm_(parameters, max_norm) followed by SGD(lr) without momentum / weight decay:

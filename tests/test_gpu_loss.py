@@ -101,3 +101,38 @@ def test_loss_in_three_pieces_equals_the_two_passes_bit_for_bit(B, H, W, empty):
         assert torch.equal(out_a, out_b), (out_a, out_b)
         assert torch.equal(dp_a, dp_b) and torch.equal(dd_a, dd_b)
         assert torch.isfinite(out_a).all()
+
+
+@pytest.mark.parametrize("B,H,W,empty,f32", [(2, 16, 24, False, False), (3, 7, 5, True, True), (2, 200, 176, False, False),
+                                              (2, 200, 176, False, True)])
+def test_loss_pass_writes_the_heads_gradient_rows_bit_for_bit(B, H, W, empty, f32):
+    """vn_rpn_loss_fwd_bwd_rows (what vn_net_step launches between the heads and their backward) against
+    vn_rpn_loss_fwd_bwd followed by vn_heads_bwd: d_prob, d_delta, the partial sums and the (B*H*W, 16) gradient rows of the
+    heads' backward — d_logit = d_prob * p * (1 - p), then the 14 regression gradients (model.py:303-304 backward) —
+    bit-identical, as bf16 rows (the bf16 mode) and as fp32 rows (the fp32 / fp32x3 modes)"""
+    from voxelnet_amd import _lib
+    prob, delta, pos, neg, tgt = (t.to(DEV).contiguous() for t in _case(B, H, W, 33 + B, empty))
+    lib = _lib.load()
+    wsb = lib.vn_rpn_loss_workspace_bytes(B, H, W)
+    st = _lib.raw_stream()
+    g = torch.tensor([0.7], device=DEV)
+    S = H * W
+    rdt, cdt = (torch.float32, _lib.VN_F32) if f32 else (torch.bfloat16, _lib.VN_BF16)
+    ws_a = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    dp_a, dd_a = torch.empty_like(prob), torch.empty_like(delta)
+    rows_a = torch.full((B * S, 16), float("nan"), dtype=rdt, device=DEV)
+    _lib.call("vn_rpn_loss_norm", pos.data_ptr(), neg.data_ptr(), B, H, W, ws_a.data_ptr(), wsb, st)
+    _lib.call("vn_rpn_loss_fwd_bwd", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(), B, H, W,
+              1.5, 1.0, 3.0, ws_a.data_ptr(), wsb, g.data_ptr(), None, None, None, None, dp_a.data_ptr(), dd_a.data_ptr(), st)
+    _lib.call("vn_heads_bwd", dp_a.data_ptr(), dd_a.data_ptr(), prob.data_ptr(), B, S, rows_a.data_ptr(), cdt, 16, 0, st)
+    ws_b = torch.zeros(wsb, dtype=torch.uint8, device=DEV)
+    dp_b, dd_b = torch.empty_like(prob), torch.empty_like(delta)
+    rows_b = torch.full((B * S, 16), float("nan"), dtype=rdt, device=DEV)
+    _lib.call("vn_rpn_loss_norm", pos.data_ptr(), neg.data_ptr(), B, H, W, ws_b.data_ptr(), wsb, st)
+    _lib.call("vn_rpn_loss_fwd_bwd_rows", prob.data_ptr(), delta.data_ptr(), pos.data_ptr(), neg.data_ptr(), tgt.data_ptr(), B, H, W,
+              1.5, 1.0, 3.0, ws_b.data_ptr(), wsb, g.data_ptr(), dp_b.data_ptr(), dd_b.data_ptr(), rows_b.data_ptr(), cdt, 16, 0, st)
+    torch.cuda.synchronize()
+    assert torch.equal(dp_a, dp_b) and torch.equal(dd_a, dd_b)
+    assert torch.equal(ws_a, ws_b)
+    assert torch.isfinite(rows_a.float()).all()
+    assert torch.equal(rows_a.view(torch.int16 if not f32 else torch.int32), rows_b.view(torch.int16 if not f32 else torch.int32))

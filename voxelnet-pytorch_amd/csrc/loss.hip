@@ -73,13 +73,22 @@ struct LossGrads {
 
 // MODE 0: the forward sums; 1: the gradients; 2: both in ONE pass over the sites (vn_rpn_loss_fwd_bwd: the same arithmetic in
 // the same order per thread, so sums and gradients are bit-identical to the two separate passes)
+// HeadRows (vn_rpn_loss_fwd_bwd_rows): a thread holds the 2 + 14 gradients of its site — exactly one row of the (B*S, 16)
+// gradient the heads' backward reads (vn_heads_bwd: d_logit = d_prob * p * (1 - p), then the 14 regression gradients) — so
+// it writes that row as well and the heads_bwd launch leaves the chain between the loss and the heads' data gradient.
+struct HeadRows {
+    void *rows;        // NULL: none
+    int64_t stride;    // elements per row
+    int f32, split;    // fp32 rows | bf16 rows (split: the lo parts at [16 + c], vn_heads_bwd's form)
+};
+
 template <int MODE>
 __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__ prob, const float *__restrict__ reg,
                                                        const float *__restrict__ pos, const float *__restrict__ neg,
                                                        const float *__restrict__ tgt, const float *__restrict__ norm,
                                                        LossGeom g, float *__restrict__ slab /* fwd: [blocks][3] */,
                                                        LossGrads gout /* bwd: five device scalars, NULL = 0 */,
-                                                       float *__restrict__ d_prob, float *__restrict__ d_reg) {
+                                                       float *__restrict__ d_prob, float *__restrict__ d_reg, HeadRows hr) {
     VN_PRIO_MAIN();
     constexpr bool BWD = MODE != 0, FWD = MODE != 1;
     const int64_t hw = (int64_t)g.H * g.W, sites = hw * g.B;
@@ -93,6 +102,7 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
         const float2 ng = *reinterpret_cast<const float2 *>(neg + site * 2);
         const float pa[2] = {ps.x, ps.y}, na[2] = {ng.x, ng.y};
         float kp = 0.f, kn = 0.f, kr = 0.f;
+        float row[16];
         if (BWD) {
             const float gl = gout.g[0] ? *gout.g[0] : 0.f, gc = gout.g[1] ? *gout.g[1] : 0.f, gr = gout.g[2] ? *gout.g[2] : 0.f,
                         gp = gout.g[3] ? *gout.g[3] : 0.f, gn = gout.g[4] ? *gout.g[4] : 0.f;
@@ -104,7 +114,11 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
         for (int a = 0; a < 2; ++a) {
             const int64_t pi = ((int64_t)b * 2 + a) * hw + yx;
             const float p = prob[pi];
-            if (BWD) d_prob[pi] = -kp * pa[a] * inv_p / (p + 1e-6f) + kn * na[a] * inv_n / (1.f - p + 1e-6f);
+            if (BWD) {
+                const float dp = -kp * pa[a] * inv_p / (p + 1e-6f) + kn * na[a] * inv_n / (1.f - p + 1e-6f);
+                d_prob[pi] = dp;
+                row[a] = dp * p * (1.0f - p);      // (vn_heads_bwd's expression on the stored values)
+            }
             if (FWD) {
                 s_pos += -pa[a] * logf(p + 1e-6f) * inv_p;
                 s_neg += -na[a] * logf(1.f - p + 1e-6f) * inv_n;
@@ -116,8 +130,28 @@ __global__ void __launch_bounds__(LOSS_THREADS) k_loss(const float *__restrict__
                 const float diff = reg[ri] * pa[a] - tgt[site * 14 + c] * pa[a];
                 float dd;
                 const float l = smooth_l1(diff, g.sigma2, &dd);
-                if (BWD) d_reg[ri] = kr * dd * pa[a] * inv_p;
+                if (BWD) {
+                    const float dr = kr * dd * pa[a] * inv_p;
+                    d_reg[ri] = dr;
+                    row[2 + c] = dr;
+                }
                 if (FWD) s_reg += l * inv_p;
+            }
+        }
+        if (BWD && hr.rows) {
+            if (hr.f32) {
+                float *d = static_cast<float *>(hr.rows) + site * hr.stride;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) d[c] = row[c];
+            } else {
+                bf16_t *d = static_cast<bf16_t *>(hr.rows) + site * hr.stride;
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    bf16_t h, l;
+                    vn_split_bf16(row[c], h, l);
+                    d[c] = h;
+                    if (hr.split) d[16 + c] = l;
+                }
             }
         }
     }
@@ -186,7 +220,8 @@ extern "C" int vn_rpn_loss_fwd(const float *prob, const float *delta, const floa
     k_loss_norm_final<<<B, 64, 0, st>>>(slab, norm, B);
     VN_LAUNCH_STATUS();
     const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
-    k_loss<0><<<blocks, LOSS_THREADS, 0, st>>>(prob, delta, pos, neg, targets, norm, g, slab, LossGrads{}, nullptr, nullptr);
+    k_loss<0><<<blocks, LOSS_THREADS, 0, st>>>(prob, delta, pos, neg, targets, norm, g, slab, LossGrads{}, nullptr, nullptr,
+                                               HeadRows{});
     VN_LAUNCH_STATUS();
     k_loss_finalize<<<1, LOSS_THREADS, 0, st>>>(slab, blocks, alpha, beta, out5);
     VN_LAUNCH_STATUS();
@@ -205,7 +240,7 @@ extern "C" int vn_rpn_loss_bwd(const float *prob, const float *delta, const floa
     const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
     k_loss<1><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, nullptr,
                                                                   LossGrads{{g_loss, g_cls, g_reg, g_cls_pos, g_cls_neg}},
-                                                                  d_prob, d_delta);
+                                                                  d_prob, d_delta, HeadRows{});
     VN_LAUNCH_STATUS();
     return VN_OK;
 }
@@ -228,11 +263,10 @@ extern "C" int vn_rpn_loss_norm(const float *pos, const float *neg, int32_t B, i
     return VN_OK;
 }
 
-extern "C" int vn_rpn_loss_fwd_bwd(const float *prob, const float *delta, const float *pos, const float *neg,
-                                   const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
-                                   void *workspace, size_t workspace_bytes, const float *g_loss, const float *g_cls,
-                                   const float *g_reg, const float *g_cls_pos, const float *g_cls_neg, float *d_prob,
-                                   float *d_delta, vnStream stream) {
+static int loss_fwd_bwd(const float *prob, const float *delta, const float *pos, const float *neg, const float *targets,
+                        int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma, void *workspace,
+                        size_t workspace_bytes, const LossGrads &up, float *d_prob, float *d_delta, const HeadRows &hr,
+                        vnStream stream) {
     VN_CHECK_ARG(prob && delta && pos && neg && targets && workspace && d_prob && d_delta && loss_args_ok(B, H, W) &&
                  sigma > 0.f);
     if (workspace_bytes < vn_rpn_loss_workspace_bytes(B, H, W)) return VN_EWORKSPACE;
@@ -240,11 +274,31 @@ extern "C" int vn_rpn_loss_fwd_bwd(const float *prob, const float *delta, const 
     float *slab = reinterpret_cast<float *>(static_cast<char *>(workspace) + vn_align(sizeof(float) * 2 * (size_t)B));
     const int blocks = (int)vn_ceil_div((int64_t)B * H * W, LOSS_THREADS);
     const LossGeom g{B, H, W, alpha, beta, sigma * sigma};
-    k_loss<2><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, slab,
-                                                               LossGrads{{g_loss, g_cls, g_reg, g_cls_pos, g_cls_neg}}, d_prob,
-                                                               d_delta);
+    k_loss<2><<<blocks, LOSS_THREADS, 0, vn_stream(stream)>>>(prob, delta, pos, neg, targets, norm, g, slab, up, d_prob, d_delta,
+                                                               hr);
     VN_LAUNCH_STATUS();
     return VN_OK;
+}
+
+extern "C" int vn_rpn_loss_fwd_bwd(const float *prob, const float *delta, const float *pos, const float *neg,
+                                   const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta, float sigma,
+                                   void *workspace, size_t workspace_bytes, const float *g_loss, const float *g_cls,
+                                   const float *g_reg, const float *g_cls_pos, const float *g_cls_neg, float *d_prob,
+                                   float *d_delta, vnStream stream) {
+    return loss_fwd_bwd(prob, delta, pos, neg, targets, B, H, W, alpha, beta, sigma, workspace, workspace_bytes,
+                        LossGrads{{g_loss, g_cls, g_reg, g_cls_pos, g_cls_neg}}, d_prob, d_delta, HeadRows{}, stream);
+}
+
+extern "C" int vn_rpn_loss_fwd_bwd_rows(const float *prob, const float *delta, const float *pos, const float *neg,
+                                        const float *targets, int32_t B, int32_t H, int32_t W, float alpha, float beta,
+                                        float sigma, void *workspace, size_t workspace_bytes, const float *g_loss,
+                                        float *d_prob, float *d_delta, void *d_rows, vnDtype d_dtype, int64_t d_stride,
+                                        int32_t split, vnStream stream) {
+    VN_CHECK_ARG(d_rows && d_stride >= (split ? 32 : 16));
+    VN_CHECK_ARG(d_dtype == VN_BF16 || (d_dtype == VN_F32 && !split));
+    return loss_fwd_bwd(prob, delta, pos, neg, targets, B, H, W, alpha, beta, sigma, workspace, workspace_bytes,
+                        LossGrads{{g_loss, nullptr, nullptr, nullptr, nullptr}}, d_prob, d_delta,
+                        HeadRows{d_rows, d_stride, d_dtype == VN_F32, split}, stream);
 }
 
 extern "C" int vn_rpn_loss_finalize(const void *workspace, size_t workspace_bytes, int32_t B, int32_t H, int32_t W, float alpha,

@@ -474,6 +474,9 @@ struct vnNet {
     // instead of beside the first layers (where the launch cost 0.03 ms of step time)
     vnPackJob deferred_pack[NL + 1];
     int n_deferred;
+    // vn_net_step's loss pass has already written the heads' gradient rows (vn_rpn_loss_fwd_bwd_rows) into this arena's
+    // d_rows: the vn_net_backward that follows skips its vn_heads_bwd launch (consumed there)
+    const void *heads_rows_ready;
     hipEvent_t ring[64];
     unsigned next;
     hipEvent_t next_event() { return ring[next++ & 63]; }
@@ -748,6 +751,7 @@ extern "C" int vn_net_forward(vnNet *net, const vnNetConfig *cfg, const vnLayerP
         }
     }
     net->prep_recorded = false;     // consumed: a later forward needs its own vn_net_prepare
+    net->heads_rows_ready = nullptr;   // (only vn_net_step, behind THIS forward, may announce rows for the backward)
     if (prep_wait) VN_HIP(hipStreamWaitEvent(hs, net->prep_ev[0], 0));
     Rows x = dense_rows(const_cast<void *>(dense), P.adt, cfg->B, cfg->D, cfg->H, cfg->W, 128);
     Rows x1{}, x2{};
@@ -912,7 +916,9 @@ extern "C" int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayer
     // ---- heads
     if (seg_begin == 0) {
         Spec hs16{2, 768, 16, {1, 1, 1}, {1, 1, 1}, {0, 0, 0}, false, 1};
-        RTT(T_MISC, NL, 0.0, 0.0, stream, vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows.ptr, (vnDtype)P.adt, 16, 0, stream));
+        if (net->heads_rows_ready != P.d_rows.ptr)
+            RTT(T_MISC, NL, 0.0, 0.0, stream, vn_heads_bwd(d_prob, d_reg, prob, B, S, P.d_rows.ptr, (vnDtype)P.adt, 16, 0, stream));
+        net->heads_rows_ready = nullptr;
         const int od[3] = {1, P.hf, P.wf};
         const int64_t rs[4] = {P.d_rows.sB, P.d_rows.sD, P.d_rows.sH, P.d_rows.sW};
         vnConv gw = geom(P.cat, od, 768, 16, hs16.k, ONE, ONE, hs16.p, ONE, rs);
@@ -1362,8 +1368,15 @@ extern "C" int vn_net_step(vnNet *net, const vnNetConfig *cfg, const vnStep *s) 
     // the loss: ONE launch between the heads and their backward (sums and gradients in one pass); its five output scalars are
     // finished on the side stream (nobody's input)
     VN_HIP(hipStreamWaitEvent(hs, ev_norm, 0));
-    RT(vn_rpn_loss_fwd_bwd(s->prob, s->reg, s->pos, s->neg, s->targets, cfg->B, hf, wf, s->alpha, s->beta, s->sigma, s->loss_ws,
-                           s->loss_ws_bytes, s->g_loss, nullptr, nullptr, nullptr, nullptr, s->d_prob, s->d_reg, s->stream));
+    {   // ... and the same pass leaves the heads' gradient rows (what vn_heads_bwd makes of d_prob / d_reg / prob) in the arena
+        Plan P;
+        if (!make_plan(&c, s->K, static_cast<char *>(s->ws), &P)) return VN_EUNSUPPORTED;
+        if (s->ws_bytes < P.bytes) return VN_EWORKSPACE;
+        RT(vn_rpn_loss_fwd_bwd_rows(s->prob, s->reg, s->pos, s->neg, s->targets, cfg->B, hf, wf, s->alpha, s->beta, s->sigma,
+                                    s->loss_ws, s->loss_ws_bytes, s->g_loss, s->d_prob, s->d_reg, P.d_rows.ptr, (vnDtype)P.adt, 16, 0,
+                                    s->stream));
+        net->heads_rows_ready = P.d_rows.ptr;
+    }
     ev = net->next_event();
     VN_HIP(hipEventRecord(ev, hs));
     VN_HIP(hipStreamWaitEvent(ss, ev, 0));

@@ -176,33 +176,34 @@ __global__ void __launch_bounds__(256) k_rulebook_combine(const float *__restric
     const int64_t n = count[0];
     const float bv = bias ? bias[lane] : 0.f;
     float s1 = 0.f, s2 = 0.f;
-    for (int64_t blk = blockIdx.x; blk * RB_ROWS < n; blk += gridDim.x)
-    for (int r = wave; r < RB_ROWS; r += 4) {
-        const int64_t m = blk * RB_ROWS + r;
-        if (m >= n) break;
-        const int64_t *rc = list + m * 4;
-        const int b = (int)rc[0], od = (int)rc[1], oh = (int)rc[2], ow = (int)rc[3];
-        // lane t < taps: voxel index of tap t's source cell (or -1)
-        int idx = -1;
-        if (lane < taps) {
-            const int kd = lane / (g.kH * g.kW), kh = (lane / g.kW) % g.kH, kw = lane % g.kW;
-            const int sd = od * g.sD + kd - g.pD, sh = oh * g.sH + kh - g.pH, sw = ow * g.sW + kw - g.pW;
-            if ((unsigned)sd < (unsigned)Di && (unsigned)sh < (unsigned)Hi && (unsigned)sw < (unsigned)Wi)
-                idx = grid[(((int64_t)b * Di + sd) * Hi + sh) * Wi + sw];
+    for (int64_t blk = blockIdx.x; blk * RB_ROWS < n; blk += gridDim.x) {
+        for (int r = wave; r < RB_ROWS; r += 4) {
+            const int64_t m = blk * RB_ROWS + r;
+            if (m >= n) break;
+            const int64_t *rc = list + m * 4;
+            const int b = (int)rc[0], od = (int)rc[1], oh = (int)rc[2], ow = (int)rc[3];
+            // lane t < taps: voxel index of tap t's source cell (or -1)
+            int idx = -1;
+            if (lane < taps) {
+                const int kd = lane / (g.kH * g.kW), kh = (lane / g.kW) % g.kH, kw = lane % g.kW;
+                const int sd = od * g.sD + kd - g.pD, sh = oh * g.sH + kh - g.pH, sw = ow * g.sW + kw - g.pW;
+                if ((unsigned)sd < (unsigned)Di && (unsigned)sh < (unsigned)Hi && (unsigned)sw < (unsigned)Wi)
+                    idx = grid[(((int64_t)b * Di + sd) * Hi + sh) * Wi + sw];
+            }
+            uint64_t live = __builtin_amdgcn_ballot_w64(idx >= 0);
+            float acc = 0.f;
+            while (live) {                       // ascending tap order: a fixed summation order
+                const int t = __builtin_ctzll(live);
+                live &= live - 1;
+                const int v = __builtin_amdgcn_readlane(idx, t);
+                acc += P[((int64_t)v * taps + t) * C + lane];
+            }
+            s1 += acc;
+            s2 += acc * acc;
+            const int64_t o = ((((int64_t)b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * C + lane;
+            if (OUT_F32) static_cast<float *>(y)[o] = acc + bv;
+            else static_cast<bf16_t *>(y)[o] = (bf16_t)(acc + bv);
         }
-        uint64_t live = __builtin_amdgcn_ballot_w64(idx >= 0);
-        float acc = 0.f;
-        while (live) {                       // ascending tap order: a fixed summation order
-            const int t = __builtin_ctzll(live);
-            live &= live - 1;
-            const int v = __builtin_amdgcn_readlane(idx, t);
-            acc += P[((int64_t)v * taps + t) * C + lane];
-        }
-        s1 += acc;
-        s2 += acc * acc;
-        const int64_t o = ((((int64_t)b * g.Do + od) * g.Ho + oh) * g.Wo + ow) * C + lane;
-        if (OUT_F32) static_cast<float *>(y)[o] = acc + bv;
-        else static_cast<bf16_t *>(y)[o] = (bf16_t)(acc + bv);
     }
     if (slab) {
         __shared__ float red[2][4][64];

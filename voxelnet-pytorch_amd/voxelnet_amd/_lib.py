@@ -206,6 +206,8 @@ SIGNATURES = {
     "vn_rpn_loss_fwd_bwd": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp,
                                     c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "vn_rpn_loss_finalize": (c_i32, [c_vp, c_sz, c_i32, c_i32, c_i32, c_f32, c_f32, c_vp, c_vp]),
+    "vn_rpn_loss_fwd_bwd_rows": (c_i32, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_f32, c_f32, c_f32, c_vp, c_sz, c_vp, c_vp,
+                                         c_vp, c_vp, c_i32, c_i64, c_i32, c_vp]),
     "vn_rpn_targets_workspace_bytes": (c_sz, [c_i32, c_i32, c_i32]),
     "vn_rpn_targets": (c_i32, [c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_f32, c_f32, ctypes.c_double, c_vp, c_vp, c_vp,
                                c_vp, c_sz, c_vp]),
