@@ -130,6 +130,12 @@ size_t vn_vfe_workspace_bytes(int64_t K, int32_t T);
 int vn_vfe_fwd(const float *feature /*[K,T,7]*/, int64_t K, int32_t T, const vnVfeWeights *w,
                int32_t training, float momentum, float eps, float *voxelwise /*[K,128]*/,
                float *stats /*[320]*/, void *workspace, size_t workspace_bytes, vnStream stream);
+/* vn_vfe_fwd that ALSO writes the voxel features as bf16 rows (K, 128) — bf16(x) of every element of `voxelwise`, what
+ * vn_cast_rows makes of it — for a caller whose next consumer reads bf16 (vn_net_step in the bf16 mode: the first Conv3d's
+ * rulebook GEMM; one launch less at the start of the step's dependency chain). */
+int vn_vfe_fwd_rows(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, int32_t training, float momentum,
+                    float eps, float *voxelwise, void *rows_bf16, float *stats, void *workspace, size_t workspace_bytes,
+                    vnStream stream);
 /* gradients of all eight parameter tensors for upstream d_voxelwise (K,128); the input
  * features are leaf data (no d_feature).  `workspace` need not be the forward's; when it IS — the buffer vn_vfe_fwd
  * was given for the same feature / K / T, untouched since — pass workspace_is_forwards = 1 (bit 0) and the effective-row

@@ -158,3 +158,38 @@ def test_vfe_backward_at_the_benchmarked_size_vs_float64():
         r = leaves[k].grad
         l2 = float((g.double().cpu() - r).norm() / r.norm().clamp(min=1e-30))
         assert rel_err(g, r) < 1e-3 and l2 < 1e-3, (k, rel_err(g, r), l2)
+
+
+@pytest.mark.parametrize("T", [35, 64])
+def test_vfe_fwd_rows_are_the_cast_of_the_voxel_features(T):
+    """vn_vfe_fwd_rows (vn_net_step in the bf16 mode: the encoder's last pass also writes the bf16 rows the first Conv3d's
+    rulebook GEMM reads) against vn_vfe_fwd + vn_cast_rows: the fp32 voxel features, the statistics and the bf16 rows
+    bit-identical, on the mixed-class voxels of this file"""
+    import ctypes
+
+    from voxelnet_amd import _lib
+    from voxelnet_amd import engine as E
+    from voxelnet_amd import model as M
+    feat = torch.from_numpy(_features(T, 300 + T)).to(DEV)
+    K = feat.shape[0]
+    sd = tr.make_state_dict("Car")
+    bufk = ["feature_net.vfe_1.bn.running_mean", "feature_net.vfe_1.bn.running_var",
+            "feature_net.vfe_2.bn.running_mean", "feature_net.vfe_2.bn.running_var"]
+    params = [sd[k].clone().to(DEV) for k in M.VFE_KEYS]
+    vw_a, stats_a, _ = M.featnet_forward(feat, params, [sd[k].clone().to(DEV) for k in bufk], True)
+    rows_a = torch.empty((K, 128), dtype=torch.bfloat16, device=DEV)
+    _lib.call("vn_cast_rows", vw_a.data_ptr(), _lib.VN_F32, 128, K, 128, rows_a.data_ptr(), _lib.VN_BF16, 128, 0, E.stream())
+    bufs = [sd[k].clone().to(DEV) for k in bufk]
+    w = _lib.VnVfeWeights(params[0].data_ptr(), params[1].data_ptr(), params[2].data_ptr(), params[3].data_ptr(),
+                          bufs[0].data_ptr(), bufs[1].data_ptr(), params[4].data_ptr(), params[5].data_ptr(),
+                          params[6].data_ptr(), params[7].data_ptr(), bufs[2].data_ptr(), bufs[3].data_ptr())
+    wsb = _lib.load().vn_vfe_workspace_bytes(K, T)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=DEV)
+    vw_b = torch.empty((K, 128), dtype=torch.float32, device=DEV)
+    rows_b = torch.full((K, 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    stats_b = torch.empty(320, dtype=torch.float32, device=DEV)
+    _lib.call("vn_vfe_fwd_rows", feat.data_ptr(), K, T, ctypes.byref(w), 1, E.BN_MOMENTUM, E.BN_EPS, vw_b.data_ptr(),
+              rows_b.data_ptr(), stats_b.data_ptr(), ws.data_ptr(), wsb, E.stream())
+    torch.cuda.synchronize()
+    assert torch.equal(vw_a, vw_b) and torch.equal(stats_a, stats_b)
+    assert torch.equal(rows_a.view(torch.int16), rows_b.view(torch.int16))

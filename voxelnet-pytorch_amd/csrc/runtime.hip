@@ -1358,10 +1358,12 @@ extern "C" int vn_net_step(vnNet *net, const vnNetConfig *cfg, const vnStep *s) 
     hipEvent_t ev_norm = net->next_event();
     VN_HIP(hipEventRecord(ev_norm, ss));
     // main stream: encoder, network, loss
-    RT(vn_vfe_fwd(s->feature, s->K, s->T, &s->vfe, 1, s->bn_momentum, s->bn_eps, s->voxelwise, s->vfe_stats, s->vfe_ws,
-                  s->vfe_ws_bytes, s->stream));
-    if (cfg->mode == 0)
-        RT(vn_cast_rows(s->voxelwise, VN_F32, 128, s->K, 128, s->vw_rows, VN_BF16, 128, 0, s->stream));
+    if (cfg->mode == 0)   // bf16 mode: the encoder's last pass writes the bf16 rows too (no cast launch in front of the network)
+        RT(vn_vfe_fwd_rows(s->feature, s->K, s->T, &s->vfe, 1, s->bn_momentum, s->bn_eps, s->voxelwise, s->vw_rows, s->vfe_stats,
+                           s->vfe_ws, s->vfe_ws_bytes, s->stream));
+    else
+        RT(vn_vfe_fwd(s->feature, s->K, s->T, &s->vfe, 1, s->bn_momentum, s->bn_eps, s->voxelwise, s->vfe_stats, s->vfe_ws,
+                      s->vfe_ws_bytes, s->stream));
     c.prepared = 1;
     RT(vn_net_forward(net, &c, s->layers, s->heads_w, s->heads_b, nullptr, s->coord, s->vw_rows, s->K, s->ws, s->ws_bytes,
                       s->prob, s->reg, s->stream, s->side_stream));

@@ -576,7 +576,7 @@ template <int G>
 __device__ __forceinline__ void p3_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
                                         int item, const float *wl, const float *stats, const WaveLds &L, int lane,
                                         const FwdRegs &F, float mean2, float S2, float be2,
-                                        float *__restrict__ voxelwise) {
+                                        float *__restrict__ voxelwise, bf16_t *__restrict__ rows16) {
     constexpr int R = 64 / G;
     int v, r, s, j; float wgt;
     item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);
@@ -600,12 +600,17 @@ __device__ __forceinline__ void p3_item(const float *__restrict__ feature, int T
         if (anym != allm) vhi = fmaxf(agg, 0.f);      // both 0 and 1 present
         voxelwise[(int64_t)tv * 128 + lane] = vlo;
         voxelwise[(int64_t)tv * 128 + 64 + lane] = vhi;
+        if (rows16) {   // the bf16 rows the first Conv3d's rulebook GEMM reads (vn_vfe_fwd_rows: no cast launch behind this one)
+            rows16[(int64_t)tv * 128 + lane] = (bf16_t)vlo;
+            rows16[(int64_t)tv * 128 + 64 + lane] = (bf16_t)vhi;
+        }
     }
     __builtin_amdgcn_wave_barrier();
 }
 
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) k_vfe_p3(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
-                                               const float *__restrict__ stats, float *__restrict__ voxelwise) {
+                                               const float *__restrict__ stats, float *__restrict__ voxelwise,
+                                               bf16_t *__restrict__ rows16) {
     VN_PRIO_MAIN();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -618,7 +623,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2)))
     load_fwd_regs(P, smem + WL_SIZE, lane, F);
     __syncthreads();   // the staged W2 is overwritten by the per-wave areas from here on
     const float mean2 = stats[ST2 + lane], S2 = stats[ST2 + 2 * C2 + lane], be2 = stats[ST2 + 3 * C2 + lane];
-#define BODY_P3(G, first, n, item) p3_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, F, mean2, S2, be2, voxelwise);
+#define BODY_P3(G, first, n, item) p3_item<G>(feature, T, wk, first, n, item, wl, stats, L, lane, F, mean2, S2, be2, voxelwise, rows16);
     VFE_FOR_ITEMS(it, BODY_P3)
 #undef BODY_P3
 }
@@ -1187,9 +1192,9 @@ extern "C" size_t vn_vfe_workspace_bytes(int64_t K, int32_t T) {
     return make_plan(K, T).bytes;
 }
 
-extern "C" int vn_vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, int32_t training,
-                          float momentum, float eps, float *voxelwise, float *stats, void *workspace,
-                          size_t workspace_bytes, vnStream stream) {
+static int vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, int32_t training, float momentum,
+                   float eps, float *voxelwise, void *rows_bf16, float *stats, void *workspace, size_t workspace_bytes,
+                   vnStream stream) {
     VN_CHECK_ARG(w && stats && workspace && K >= 0 && K < (1ll << 31) / 64 && T > 0 && T <= 64);
     VN_CHECK_ARG(w->w1 && w->b1 && w->g1 && w->be1 && w->rm1 && w->rv1 && w->w2 && w->b2 && w->g2 && w->be2 && w->rm2 &&
                  w->rv2);
@@ -1225,9 +1230,22 @@ extern "C" int vn_vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVf
         VN_LAUNCH_STATUS();
     }
     if (K == 0) return VN_OK;
-    k_vfe_p3<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, voxelwise);
+    k_vfe_p3<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, voxelwise, static_cast<bf16_t *>(rows_bf16));
     VN_LAUNCH_STATUS();
     return VN_OK;
+}
+
+extern "C" int vn_vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, int32_t training,
+                          float momentum, float eps, float *voxelwise, float *stats, void *workspace,
+                          size_t workspace_bytes, vnStream stream) {
+    return vfe_fwd(feature, K, T, w, training, momentum, eps, voxelwise, nullptr, stats, workspace, workspace_bytes, stream);
+}
+
+extern "C" int vn_vfe_fwd_rows(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, int32_t training,
+                               float momentum, float eps, float *voxelwise, void *rows_bf16, float *stats, void *workspace,
+                               size_t workspace_bytes, vnStream stream) {
+    VN_CHECK_ARG(rows_bf16 || K == 0);
+    return vfe_fwd(feature, K, T, w, training, momentum, eps, voxelwise, rows_bf16, stats, workspace, workspace_bytes, stream);
 }
 
 extern "C" int vn_vfe_bwd(const float *feature, int64_t K, int32_t T, const vnVfeWeights *w, const float *stats,

@@ -115,6 +115,7 @@ SIGNATURES = {
     "vn_allreduce_bucket": (c_i32, [c_vp, c_vp, c_i64, c_f32, c_vp]),
     "vn_vfe_workspace_bytes": (c_sz, [c_i64, c_i32]),
     "vn_vfe_fwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_sz, c_vp]),
+    "vn_vfe_fwd_rows": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_i32, c_f32, c_f32, c_vp, c_vp, c_vp, c_vp, c_sz, c_vp]),
     "vn_vfe_bwd": (c_i32, [c_vp, c_i64, c_i32, _P(VnVfeWeights), c_vp, c_vp, _P(VnVfeGrads), c_vp, c_sz, c_i32, c_vp]),
     "vn_scatter_dense_fwd": (c_i32, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32,
                                      c_i32, c_vp]),
