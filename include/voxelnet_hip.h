@@ -479,9 +479,10 @@ int vn_net_backward(vnNet *net, const vnNetConfig *cfg, const vnLayerParams *lay
  * the streams the separate calls are issued by a host that overlaps them by hand:
  *   side:  [wait stream]  counters += 1 | vn_net_prepare phase 1 | heads' parameters -> heads_w / heads_b | vn_net_prepare phase 2 |
  *          [wait targets_stream] vn_rpn_loss_norm | ... | [wait the pass] vn_rpn_loss_finalize -> loss5
- *   main:  vn_vfe_fwd | (bf16 mode) vn_cast_rows -> vw_rows | vn_net_forward | [wait the normalisers] vn_rpn_loss_fwd_bwd
- *          (g_loss): ONE launch between the heads and their backward | vn_net_backward(0..24, defer_join) | vn_vfe_bwd |
- *          [wait side] | vn_clip_sgd
+ *   main:  vn_vfe_fwd (bf16 mode: vn_vfe_fwd_rows, whose last pass writes vw_rows too: no vn_cast_rows launch) |
+ *          vn_net_forward | [wait the normalisers] vn_rpn_loss_fwd_bwd_rows (g_loss): ONE launch between the heads and their
+ *          backward, which also leaves the heads' gradient rows in the arena (no vn_heads_bwd launch) |
+ *          vn_net_backward(0..24, defer_join) | vn_vfe_bwd | [wait side] | vn_clip_sgd
  * Same arithmetic and same results as those calls (tests/test_gpu_step.py: bit-identical); what it saves is the host's
  * work between them and four of the five loss launches on the chain between the network's forward and backward.  Every buffer is the caller's; scratch ones (voxelwise, vfe_stats, vw_rows, d_voxelwise,
  * heads_w / heads_b, d_prob / d_reg, the three workspaces) need only live until the step has run.
