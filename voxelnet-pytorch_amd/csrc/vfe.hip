@@ -15,7 +15,7 @@
 // (loads -> layer 1 -> per-voxel max -> layer 2 -> per-voxel analysis), and the lever is
 // how many waves a SIMD holds (LDS per wave, VGPRs), not bytes.
 // Train-mode BatchNorm statistics are global over all K*T rows (padded slots
-// included), so the forward is 3 passes (stats1, stats2, output) and the backward
+// included), so the forward is 3 passes (stats1 — inside the pre-pass that finds the effective rows —, stats2, output) and the backward
 // 3 passes (BN2 sums, BN1 sums + layer-2 grads, layer-1 grads) with tiny finalize
 // kernels between them.
 //
@@ -411,6 +411,76 @@ __global__ void __launch_bounds__(256) k_vfe_rows(const float *__restrict__ feat
     if (lane == 0) rows[v] = (uint8_t)(last + 1);       // <= T
 }
 
+// The same pre-pass with the forward's pass 1 inside (train mode): the wave that finds a voxel's r already holds the 7 values
+// of every slot, so it also evaluates h1 = relu(W1 x + b1) on its r effective rows and adds the weighted sums for the first
+// BatchNorm's statistics — slab[b] = [sum(16) | sumsq(16) | 0(32)] — instead of a second pass (the former k_vfe_p1) over the
+// (packed) rows behind the partition: one launch less on the head of the step's dependency chain.  One voxel per wave
+// iteration (lanes >= r idle: the kernel is bound by the latency of its loads, the next voxel's are requested before this
+// one's arithmetic), at most 1024 workgroups of 4 waves, one slab row each.
+constexpr int RP_WAVES = 4;
+__global__ void __launch_bounds__(64 * RP_WAVES) k_vfe_rows_p1(const float *__restrict__ feature, int64_t K, int T,
+                                                              uint8_t *__restrict__ rows, VfeParams P,
+                                                              float *__restrict__ slabs) {
+    VN_PRIO_MAIN();
+    __shared__ float red[RP_WAVES][2 * C1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t nwaves = (int64_t)gridDim.x * RP_WAVES;
+    float acc[2 * C1];
+#pragma unroll
+    for (int o = 0; o < 2 * C1; ++o) acc[o] = 0.f;
+    auto load = [&](int64_t v, uint32_t x[CIN], uint32_t ref[CIN]) {
+        const uint32_t *f = reinterpret_cast<const uint32_t *>(feature) + v * T * CIN;
+        const int j = lane < T ? lane : T - 1;
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) { x[i] = f[j * CIN + i]; ref[i] = f[(T - 1) * CIN + i]; }
+    };
+    int64_t v = (int64_t)blockIdx.x * RP_WAVES + wave;
+    uint32_t xn[CIN], rn[CIN];
+    if (v < K) load(v, xn, rn);
+    for (; v < K; v += nwaves) {
+        uint32_t xb[CIN], rb[CIN];
+#pragma unroll
+        for (int i = 0; i < CIN; ++i) { xb[i] = xn[i]; rb[i] = rn[i]; }
+        if (v + nwaves < K) load(v + nwaves, xn, rn);
+        bool differs = false;
+        if (lane < T - 1) {
+#pragma unroll
+            for (int i = 0; i < CIN; ++i) differs |= xb[i] != rb[i];
+        }
+        const unsigned long long mask = __ballot(differs);
+        const int last = mask ? 64 - __clzll(mask) : 0;     // slots 0..last-1 are individual
+        const int r = last + 1;                             // <= T
+        if (lane == 0) rows[v] = (uint8_t)r;
+        if (lane < r) {                                     // effective rows; row r-1 stands for T-r+1 identical slots
+            float x[CIN], h1[C1];
+#pragma unroll
+            for (int i = 0; i < CIN; ++i) x[i] = __uint_as_float(xb[i]);
+            layer1(P, x, h1);
+            const float wgt = lane == r - 1 ? (float)(T - r + 1) : 1.f;
+#pragma unroll
+            for (int o = 0; o < C1; ++o) {
+                const float wh = wgt * h1[o];
+                acc[o] += wh;
+                acc[C1 + o] = fmaf(wh, h1[o], acc[C1 + o]);
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 2 * C1; ++o) {
+        const float t = vn_wave_sum(acc[o]);
+        if (lane == 0) red[wave][o] = t;
+    }
+    __syncthreads();
+    float *slab = slabs + (size_t)blockIdx.x * SLAB_P1;
+    if (threadIdx.x < 2 * C1) {
+        float a = 0.f;
+        for (int w = 0; w < RP_WAVES; ++w) a += red[w][threadIdx.x];
+        slab[threadIdx.x] = a;
+    } else if (threadIdx.x < SLAB_P1) {
+        slab[threadIdx.x] = 0.f;
+    }
+}
+
 // stable partition of the voxel ids by class: list = [A.. | B.. | C.. | D..].  Workgroup b owns voxels [4096 b, 4096 b + 4096), 16
 // per thread.  There is no cross-workgroup hand-off: every workgroup counts the classes of ALL K row counts itself (K bytes,
 // 16 per load, L2-resident: ~40 loads per thread at K = 160k) to get the class totals and the counts in front of its chunk,
@@ -498,37 +568,7 @@ __global__ void __launch_bounds__(256) k_vfe_partition(const uint8_t *__restrict
 }
 
 // ---- forward passes ---------------------------------------------------------------------
-// pass 1: weighted sums of h1 ; slab[b] = [sum(16) | sumsq(16) | 0(32)]
-__global__ void __launch_bounds__(NT) k_vfe_p1(const float *__restrict__ feature, int T, VfeParams P, WorkList wk,
-                                               float *__restrict__ slabs) {
-    VN_PRIO_MAIN();
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    VFE_TR_KERNEL(-1)
-    const Items it = load_items(wk);
-    float acc[2 * C1];
-#pragma unroll
-    for (int o = 0; o < 2 * C1; ++o) acc[o] = 0.f;
-#define BODY_P1(G, first, n, item)                                                     \
-    {                                                                                  \
-        int v, r, s, j; float wgt;                                                     \
-        item_lane<G>(wk, first, n, item, T, lane, v, r, s, j, wgt);                    \
-        float x[CIN], m, h1[C1];                                                       \
-        load_row(feature, v, T, j, j < r, x, m);                                       \
-        layer1(P, x, h1);                                                              \
-        _Pragma("unroll") for (int o = 0; o < C1; ++o) {                               \
-            const float wh = wgt * h1[o];                                              \
-            acc[o] += wh;                                                              \
-            acc[C1 + o] = fmaf(wh, h1[o], acc[C1 + o]);                                \
-        }                                                                              \
-    }
-    VFE_FOR_ITEMS(it, BODY_P1)
-#undef BODY_P1
-    float *slab = slabs + (size_t)blockIdx.x * SLAB_P1;
-    lane_sums_to_slab(acc, smem, lane, wave, slab);
-    if (threadIdx.x >= 32 && threadIdx.x < 64) slab[threadIdx.x] = 0.f;
-}
-
+// (pass 1 — the weighted sums of h1 for the first BatchNorm — runs inside the pre-pass: k_vfe_rows_p1)
 // pass 2: weighted sums of h2 ; slab[b] = [sum(64) | sumsq(64)]
 template <int G>
 __device__ __forceinline__ void p2_item(const float *__restrict__ feature, int T, const WorkList &wk, int first, int n,
@@ -1155,7 +1195,7 @@ Plan make_plan(int64_t K, int T) {
 
 int set_lds_attrs() {
     static const hipError_t st = [] {
-        const void *fns[] = {reinterpret_cast<const void *>(&k_vfe_p1), reinterpret_cast<const void *>(&k_vfe_p2),
+        const void *fns[] = {reinterpret_cast<const void *>(&k_vfe_p2),
                              reinterpret_cast<const void *>(&k_vfe_p3), reinterpret_cast<const void *>(&k_vfe_b1),
                              reinterpret_cast<const void *>(&k_vfe_b2), reinterpret_cast<const void *>(&k_vfe_b3)};
         for (const void *f : fns) {
@@ -1173,11 +1213,20 @@ int set_lds_attrs() {
 }
 
 // effective rows per voxel + the class lists (2 small launches)
-int build_worklist(const float *feature, int64_t K, int T, char *ws, const Plan &pl, hipStream_t st, WorkList *wk) {
+// (p1_slabs: train-mode forward — the pre-pass also leaves pass 1's slabs, *p1_blocks of them)
+int build_worklist(const float *feature, int64_t K, int T, char *ws, const Plan &pl, hipStream_t st, WorkList *wk,
+                   const VfeParams *P = nullptr, float *p1_slabs = nullptr, int *p1_blocks = nullptr) {
     uint8_t *rows = reinterpret_cast<uint8_t *>(ws + pl.off_rows);
     int32_t *list = reinterpret_cast<int32_t *>(ws + pl.off_list);
     int32_t *counts = reinterpret_cast<int32_t *>(ws + pl.off_counts);
-    k_vfe_rows<<<(unsigned)vn_ceil_div(K, 4), 256, 0, st>>>(feature, K, T, rows);
+    if (p1_slabs) {
+        int64_t b = vn_ceil_div(K, 4 * RP_WAVES);
+        if (b > VFE_BLOCKS_MAX) b = VFE_BLOCKS_MAX;
+        *p1_blocks = (int)b;
+        k_vfe_rows_p1<<<(unsigned)b, 64 * RP_WAVES, 0, st>>>(feature, K, T, rows, *P, p1_slabs);
+    } else {
+        k_vfe_rows<<<(unsigned)vn_ceil_div(K, 4), 256, 0, st>>>(feature, K, T, rows);
+    }
     VN_LAUNCH_STATUS();
     k_vfe_partition<<<(unsigned)vn_ceil_div(K, PART_CHUNK), 256, 0, st>>>(rows, K, list, counts);
     VN_LAUNCH_STATUS();
@@ -1215,15 +1264,17 @@ static int vfe_fwd(const float *feature, int64_t K, int32_t T, const vnVfeWeight
     if (const int e = set_lds_attrs()) return e;
     const int64_t rows = K * T;
     WorkList wk{};
+    int p1_blocks = 0;
     if (K > 0) {
         VN_CHECK_ARG(feature && voxelwise);
-        if (const int e = build_worklist(feature, K, T, ws, pl, st, &wk)) return e;
+        if (const int e = training ? build_worklist(feature, K, T, ws, pl, st, &wk, &P, slabs, &p1_blocks)
+                                   : build_worklist(feature, K, T, ws, pl, st, &wk))
+            return e;
     }
     if (training) {
         VN_CHECK_ARG(K > 0);
-        k_vfe_p1<<<pl.blocks, NT, pl.lds_small, st>>>(feature, T, P, wk, slabs);
-        VN_LAUNCH_STATUS();
-        k_vfe_finalize<<<C1, 256, 0, st>>>(slabs, pl.blocks, SLAB_P1, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 1, momentum,
+        // (pass 1 — the first BatchNorm's sums — ran inside the pre-pass: k_vfe_rows_p1)
+        k_vfe_finalize<<<C1, 256, 0, st>>>(slabs, p1_blocks, SLAB_P1, C1, rows, w->g1, w->be1, w->rm1, w->rv1, 1, momentum,
                                          eps, stats + ST1);
         VN_LAUNCH_STATUS();
         k_vfe_p2<<<pl.blocks, NT, pl.lds_full, st>>>(feature, T, P, wk, stats, slabs);
