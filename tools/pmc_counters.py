@@ -5,7 +5,7 @@ for the kernels whose name contains a given substring — e.g. what bounds the V
     rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_WAIT_ANY -d gpurun_out/pmc_vfe_b ... bench.py
     python tools/pmc_counters.py k_vfe 3 gpurun_out/pmc_vfe_a gpurun_out/pmc_vfe_b > profiles/r03_pmc_vfe.txt
 
-Counters are summed over the dispatches of the last <steps> steps (delimited by k_vfe_p1, one per step) and printed per
+Counters are summed over the dispatches of the last <steps> steps (delimited by k_vfe_rows, one per step) and printed per
 kernel and per step, with the ratios that say what a wave spends its cycles on:
   valu_busy  = SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES   (x4: SQ_ACTIVE_INST_* count quad-cycles on gfx9)
   lds_wait   = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES
@@ -29,7 +29,7 @@ for d in dirs:
         if r["Counter_Name"] not in names:
             names.append(r["Counter_Name"])
     order = sorted(disp.values(), key=lambda e: e["t0"])
-    marks = [i for i, e in enumerate(order) if "k_vfe_p1" in e["name"]]
+    marks = [i for i, e in enumerate(order) if "k_vfe_rows" in e["name"]]
     sel = order[marks[-steps - 1]:marks[-1]] if len(marks) > steps else order
     first = d == dirs[0]
     for e in sel:

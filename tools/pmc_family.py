@@ -19,8 +19,8 @@ def family(name):
 fe, wr = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 steps = int(sys.argv[3])
 def per_step(rows, fam="conv"):
-    # last `steps` steps: delimit by k_vfe_p1 launches
-    idx = [i for i, r in enumerate(rows) if "k_vfe_p1" in r["Kernel_Name"]]
+    # last `steps` steps: delimit by k_vfe_rows launches
+    idx = [i for i, r in enumerate(rows) if "k_vfe_rows" in r["Kernel_Name"]]
     sel = rows[idx[-steps - 1]:idx[-1]] if len(idx) > steps else rows
     tot, n = 0.0, 0
     for r in sel:

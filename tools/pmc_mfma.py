@@ -13,14 +13,14 @@ import collections, csv, glob, sys
 d, steps = sys.argv[1], int(sys.argv[2])
 f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
 rows = list(csv.DictReader(open(f)))
-# delimit the last `steps` steps by the first VFE kernel of each step (k_vfe_rows or k_vfe_p1)
+# delimit the last `steps` steps by the first VFE kernel of each step (k_vfe_rows_p1 in a train step, k_vfe_rows otherwise)
 disp = collections.OrderedDict()
 for r in rows:
     key = int(r["Dispatch_Id"])
     e = disp.setdefault(key, {"name": r["Kernel_Name"], "t0": int(r["Start_Timestamp"]), "t1": int(r["End_Timestamp"])})
     e[r["Counter_Name"]] = float(r["Counter_Value"])
 order = sorted(disp.values(), key=lambda e: e["t0"])
-marks = [i for i, e in enumerate(order) if "k_vfe_p1" in e["name"]]
+marks = [i for i, e in enumerate(order) if "k_vfe_rows" in e["name"]]
 sel = order[marks[-steps - 1]:marks[-1]] if len(marks) > steps else order
 
 

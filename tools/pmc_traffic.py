@@ -2,7 +2,7 @@
 gfx950: FETCH_SIZE counts 128-B requests as 64 B -> doubled (MI355X_MICROARCH.md, HBM section).
 
 usage: python tools/pmc_traffic.py <fetch pass dir> <write pass dir> [steps]
-The table covers the LAST `steps` steps of each profiled run, delimited by the step's first VFE kernel (k_vfe_p1, one per
+The table covers the LAST `steps` steps of each profiled run, delimited by the step's first VFE kernel (k_vfe_rows, one per
 step) — the profiled bench.py command also runs warm-up, host-enqueue and window steps, so dividing every launch of the
 trace by the `--steps` argument (what this script did in round 3) over-counts the per-step columns."""
 import collections
@@ -15,7 +15,7 @@ def load(d, counter, steps):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(rows) if "k_vfe_p1" in r["Kernel_Name"]]
+    marks = [i for i, r in enumerate(rows) if "k_vfe_rows" in r["Kernel_Name"]]
     if len(marks) > steps:
         rows, used = rows[marks[-steps - 1]:marks[-1]], steps
     else:                       # fewer step markers than asked for: everything, normalised by the steps that ARE there

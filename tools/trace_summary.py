@@ -1,9 +1,9 @@
-"""Summarise a rocprofv3 kernel_trace.csv: per-kernel ms/step over the last N steps (steps found by k_vfe_p1)."""
+"""Summarise a rocprofv3 kernel_trace.csv: per-kernel ms/step over the last N steps (steps found by k_vfe_rows)."""
 import csv, sys, collections
 path, nsteps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_vfe_p1' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_vfe_rows' in r['Kernel_Name']]
 start = idx[-nsteps - 1]; end = idx[-1]
 sel = rows[start:end]
 span = (int(sel[-1]['End_Timestamp']) - int(sel[0]['Start_Timestamp'])) / 1e6 / nsteps
