@@ -5,7 +5,7 @@ path = sys.argv[1]
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 rows = list(csv.DictReader(open(path)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-idx = [i for i, r in enumerate(rows) if 'k_vfe_p1' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'k_vfe_rows' in r['Kernel_Name']]
 sel = rows[idx[-back - 1]:idx[-back]]
 t0 = int(sel[0]['Start_Timestamp'])
 last = {}
