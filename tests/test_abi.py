@@ -140,3 +140,23 @@ def test_ctypes_structures_match_the_header_layout(tmp_path):
         want = [int(v) for v in parts[1:]]
         got = [ctypes.sizeof(st)] + [getattr(st, f).offset for f, _ in st._fields_ if not (f.endswith("_") and f.startswith("pad"))]
         assert got == want, (cname, got, want)
+
+
+def test_profile_tools_delimit_steps_by_a_kernel_the_library_has():
+    """tools/trace_summary.py, trace_order.py and the pmc_*.py post-processors find the train steps of a rocprofv3 run by
+    the first kernel of the voxel feature encoder.  Round 5 removed k_vfe_p1 — the marker they used — from the library, and
+    the per-step summaries of that run silently covered the warm-up steps too: the marker every tool names must be the
+    prefix of a __global__ kernel in csrc/vfe.hip, launched once per train step (the encoder's pre-pass)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "voxelnet-pytorch_amd", "csrc", "vfe.hip")).read()
+    kernels = {m for line in src.splitlines() if line.startswith("__global__")
+               for m in re.findall(r"\b(k_vfe_[a-z0-9_]+)\(", line)}
+    assert "k_vfe_rows_p1" in kernels and "k_vfe_rows" in kernels
+    tools = ["trace_summary.py", "trace_order.py", "pmc_counters.py", "pmc_family.py", "pmc_mfma.py", "pmc_traffic.py"]
+    for t in tools:
+        text = open(os.path.join(root, "tools", t)).read()
+        marks = set(re.findall(r"""["'](k_vfe_[a-z0-9_]+)["'] in """, text))
+        assert marks, f"tools/{t}: no step marker found"
+        for m in marks:
+            assert any(k.startswith(m) for k in kernels), f"tools/{t} delimits steps by {m}, which csrc/vfe.hip no longer has"
