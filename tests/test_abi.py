@@ -47,6 +47,13 @@ def test_argument_checks_return_status_codes():
     assert lib.vn_bn_apply(None, 0, 64, 0, 64, None, 1, None, 1, 64, 0, None) == 0          # M == 0: no-op
     assert lib.vn_bn_apply(None, 0, 64, 10, 64, None, 1, None, 1, 64, 0, None) == -1
     assert lib.vn_scatter_dense_fwd(None, None, 0, 128, 1, 10, 16, 24, None, 0, 128, 0, None) == -1
+    # round 5's two fused entry points: the extra output is mandatory (there is no "maybe fused" call), the rest is checked
+    # like the calls they extend
+    assert lib.vn_vfe_fwd_rows(None, 10, 35, None, 1, 0.1, 1e-5, None, None, None, None, 0, None) == -1
+    assert lib.vn_rpn_loss_fwd_bwd_rows(None, None, None, None, None, 2, 8, 8, 1.5, 1.0, 3.0, None, 0, None, None, None, None, 1, 16,
+                                        0, None) == -1
+    assert lib.vn_rulebook_slab_rows(0) == 0 and lib.vn_rulebook_slab_rows(64 * 100) == 100
+    assert lib.vn_rulebook_slab_rows(1 << 30) == 2048          # one statistics row per persistent workgroup, at most 2048
 
 
 def test_modules_refuse_cpu_tensors():
