@@ -165,15 +165,16 @@ constexpr int RB_MAX_BLOCKS = 2048;
 template <bool OUT_F32>
 __global__ void __launch_bounds__(256) k_rulebook_combine(const float *__restrict__ P, const int32_t *__restrict__ grid,
                                                           const int64_t *__restrict__ list,
-                                                          const int32_t *__restrict__ count, ASGeom g, int Di, int Hi,
-                                                          int Wi, int C, const float *__restrict__ bias,
+                                                          const int32_t *__restrict__ count, int64_t cap, ASGeom g, int Di,
+                                                          int Hi, int Wi, int C, const float *__restrict__ bias,
                                                           void *__restrict__ y, float *__restrict__ slab) {
     VN_PRIO_MAIN();
     // block = RB_ROWS list rows; wave w takes rows w, w+4, ...; lane = output channel (C == 64).  One slab row per
     // workgroup.  The per-site chain (coordinates -> 27 index lookups -> P rows) is latency-bound: every wave slot busy.
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int taps = g.kD * g.kH * g.kW;
-    const int64_t n = count[0];
+    const int64_t cnt = count[0];
+    const int64_t n = cnt < cap ? cnt : cap;     // (the persistent loop is bounded by the count: never past the list's capacity)
     const float bv = bias ? bias[lane] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     for (int64_t blk = blockIdx.x; blk * RB_ROWS < n; blk += gridDim.x) {
@@ -305,10 +306,10 @@ extern "C" int vn_rulebook_combine(const float *P, const int32_t *index_grid, co
                    geom->mulD, geom->mulH, geom->mulW, geom->padD, geom->padH, geom->padW};
     const unsigned blocks = (unsigned)vn_rulebook_slab_rows(cap);
     if (y_dtype == VN_F32)
-        k_rulebook_combine<true><<<blocks, 256, 0, vn_stream(stream)>>>(P, index_grid, list, count, g, geom->Ds, geom->Hs,
+        k_rulebook_combine<true><<<blocks, 256, 0, vn_stream(stream)>>>(P, index_grid, list, count, cap, g, geom->Ds, geom->Hs,
                                                                         geom->Ws, geom->Cr, bias, y, stats_slab);
     else
-        k_rulebook_combine<false><<<blocks, 256, 0, vn_stream(stream)>>>(P, index_grid, list, count, g, geom->Ds, geom->Hs,
+        k_rulebook_combine<false><<<blocks, 256, 0, vn_stream(stream)>>>(P, index_grid, list, count, cap, g, geom->Ds, geom->Hs,
                                                                          geom->Ws, geom->Cr, bias, y, stats_slab);
     VN_LAUNCH_STATUS();
     return VN_OK;
